@@ -1,0 +1,129 @@
+/*
+ * ta_hip.h -- C ABI of libta_hip.so: the MI355X (gfx950) kernels behind the iterative FGSM-family
+ * hot path of Trustworthy-AI-Group/TransferAttack.
+ *
+ * The reference has no FFI: the path is Python calling ATen.  Each entry point below replaces the
+ * string of ATen ops issued by ONE reference hook (cited as file:line under /root/reference); the
+ * host-side mirror of the reference's plug-in API (transferattack_amd/attack.py etc.) binds them with
+ * ctypes (transferattack_amd/_hip.py) -- see INTEGRATION.md for the stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 NCHW data unless stated otherwise;
+ *   - n = images in the batch, e = elements per image (C*H*W); planes = N*C;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all calls are asynchronous
+ *     on it, never synchronise, never allocate -> safe inside hipGraph capture;
+ *   - return value: 0 on success, otherwise a hipError_t (>0) or TA_EINVAL (-1); the message of the
+ *     last failure on the calling thread is returned by ta_last_error();
+ *   - results are deterministic: no floating-point atomics anywhere, reduction order is fixed.
+ */
+#ifndef TA_HIP_H
+#define TA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_ABI_VERSION 1
+#define TA_EINVAL (-1)
+
+int ta_abi_version(void);
+const char* ta_last_error(void);
+/* number of floats of scratch the l1-mean reduction needs for an (n, e) batch (>= n*ceil(e/3072)) */
+int64_t ta_l1_workspace_floats(int64_t n, int64_t e);
+
+/* ---- update stack ------------------------------------------------------------------------------
+ * Attack.get_momentum  transferattack/attack.py:124-128   m <- m*decay + g / mean_{CHW}|g|
+ * Attack.update_delta  transferattack/attack.py:145-153   d <- clamp(d + a*sign(m), -eps, eps);
+ *                                                          d <- min(max(d, 0-x), 1-x)  (utils.py:68-69)
+ * `v` (nullable) is added to g first (VMI-FGSM: get_momentum(grad+variance, ...), vmifgsm.py:89).
+ * `m_in` NULL means the Python int 0 of the first iteration (attack.py:85).
+ */
+/* K1: per-image partial sums of |g (+v)|; ws[n*S + s], S = ceil(e/3072); fixed summation order */
+int ta_abs_sum_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e, void* stream);
+/* get_momentum alone (hook-compatible path): K1 + normalise-accumulate; m_out may alias m_in */
+int ta_momentum(const float* g, const float* v, const float* m_in, float* m_out, float* ws,
+                float decay, int64_t n, int64_t e, void* stream);
+/* update_delta alone, L-inf branch; alpha_t (nullable) is a per-element step (gra.py:149), else the
+ * scalar alpha (may be negative, cwa.py:69); delta_out may alias delta_in; x_adv (nullable) <- x+d */
+int ta_update_delta_linf(const float* delta_in, const float* x, const float* m, float alpha,
+                         const float* alpha_t, float eps, float* delta_out, float* x_adv,
+                         int64_t numel, void* stream);
+/* update_delta, L2 branch (attack.py:148-151): d <- renorm_2(d + alpha*g/(|g|_2+1e-20), eps), box */
+int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, float alpha, float eps,
+                       float* delta_out, float* ws, int64_t n, int64_t e, void* stream);
+/* fused get_momentum + update_delta (the headline kernel): reads g,(v),m,d,x  writes m,d,(x_adv).
+ * 24 B/element algorithmic traffic (16 when m_in==NULL && m_out==NULL, the decay=0 / FGSM case). */
+int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                 const float* x, float* x_adv, float* ws, float decay, float alpha, float eps,
+                 int64_t n, int64_t e, void* stream);
+/* same arithmetic, single launch: the |g| partial sums are exchanged between the workgroups of an
+ * image inside the kernel (agent-scope granules) so g is read from HBM exactly once.
+ * `sync_ws` = ta_fused_sync_bytes(n, e) bytes, zeroed once by the caller when (n, e) changes. */
+int64_t ta_fused_sync_bytes(int64_t n, int64_t e);
+int ta_mi_update_fused(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                       const float* x, float* x_adv, void* sync_ws, float decay, float alpha,
+                       float eps, int64_t n, int64_t e, void* stream);
+
+/* Attack.init_delta random start (attack.py:133-141, linfty): d <- box(U(-eps,eps)); counter-based
+ * Philox4x32-10 keyed by (seed, offset); noise (nullable) overrides the draw with caller noise */
+int ta_init_delta_uniform(float* delta, const float* x, const float* noise, float eps, uint64_t seed,
+                          uint64_t offset, int64_t numel, void* stream);
+
+/* ---- TIM: TIM.get_grad  input_transformation/tim.py:72-74 ------------------------------------------
+ * depthwise k x k 'same' zero-padded correlation of every (n,c) plane with ONE k x k kernel `w`
+ * (device pointer, k*k fp32, row-major).  Tap order is row-major FMA chain == the reference CPU path.
+ * `separable`!=0 uses w1d (k fp32, device) twice (fast mode; differs from the 2-D chain by <=1e-6 rel).
+ */
+int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, int k, int64_t planes,
+                             int h, int w_, void* stream);
+int ta_depthwise_conv2d_separable(const float* in, float* out, float* tmp, const float* w1d, int k,
+                                  int64_t planes, int h, int w_, void* stream);
+
+/* ---- DIM: DIM.transform  input_transformation/dim.py:42-68 ----------------------------------------
+ * y = bilinear(pad0(bilinear(x, rnd), resize, top, left), size); one geometry for the whole call.
+ * fwd: x[planes,size,size] -> y[planes,size,size];  bwd: gy -> gx (exact adjoint, gather form).
+ */
+int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top,
+               int left, void* stream);
+int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize, int rnd, int top,
+               int left, void* stream);
+
+/* ---- SIM / Admix: sim.py:36-40, admix.py:40-45 ------------------------------------------------------
+ * sim fwd : y[i*n + b] = x[b] / 2^i                              i < num_scale
+ * sim bwd : gx[b] = sum_i gy[i*n + b] / 2^i                      (i ascending)
+ * admix fwd: y[(i*num_admix + j)*n + b] = (x[b] + strength * x[perm[j*n + b]]) / 2^i
+ * admix bwd: gx[b] = sum_i sum_j gy[(i*num_admix + j)*n + b] / 2^i     (mixed-in term is detached)
+ * perm: device int64 [num_admix*n].
+ */
+int ta_scale_copies_fwd(const float* x, float* y, int64_t n, int64_t e, int num_scale, void* stream);
+int ta_scale_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_scale, void* stream);
+int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
+                 int num_scale, float strength, void* stream);
+int ta_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale,
+                 void* stream);
+
+/* ---- VMI-FGSM: VMIFGSM.get_variance  gradient/vmifgsm.py:42-58 --------------------------------------
+ * neighbour: out = x + d + U(-radius, radius)   (Philox (seed, offset) or caller `noise`)
+ * accumulate: acc (+)= g  (first!=0 -> acc = g);  finalize: var = acc / count - cur_grad
+ */
+int ta_vmi_neighbor(const float* x, const float* delta, const float* noise, float* out, float radius,
+                    uint64_t seed, uint64_t offset, int64_t numel, void* stream);
+int ta_grad_accumulate(float* acc, const float* g, int first, int64_t numel, void* stream);
+int ta_variance_finalize(const float* acc, const float* cur_grad, float* var, float count,
+                         int64_t numel, void* stream);
+
+/* ---- NI look-ahead: NIFGSM.transform  gradient/nifgsm.py:35-39:  out = x + (alpha*decay) * m ------ */
+int ta_axpy(const float* x, const float* m, float coeff, float* out, int64_t numel, void* stream);
+
+/* ---- output: save_images  transferattack/utils.py:63-66 (+ main.py:53 add) ---------------------------
+ * u8[n,h,w,c] = trunc((x + d) * 255)   NCHW fp32 -> NHWC uint8 */
+int ta_quantize_u8_nhwc(const float* x, const float* delta, uint8_t* out, int64_t n, int c, int h,
+                        int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TA_HIP_H */

@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE -- ctypes view of oracle/_build/libta_oracle.so (built from oracle/ta_oracle.c).
+
+numpy in, numpy out.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline use this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libta_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "--no-print-directory"], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.ta_oracle_aten_row_sum.restype = ctypes.c_float
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def aten_row_sum(row, lanes=8):
+    row, p = _f(row)
+    return np.float32(lib().ta_oracle_aten_row_sum(p, ctypes.c_int64(row.size), ctypes.c_int(lanes)))
+
+
+def momentum(g, m_in, decay, lanes=8):
+    g, pg = _f(g)
+    n, e = g.shape[0], g[0].size
+    out = np.empty_like(g)
+    if m_in is None:
+        pm = None
+    else:
+        m_in, pm = _f(m_in)
+    lib().ta_oracle_momentum(pg, pm, out.ctypes.data_as(_f32p), ctypes.c_float(decay), ctypes.c_int64(n),
+                             ctypes.c_int64(e), ctypes.c_int(lanes))
+    return out
+
+
+def update_delta_linf(delta, x, m, alpha, eps, alpha_t=None):
+    delta, pd = _f(delta)
+    x, px = _f(x)
+    m, pm = _f(m)
+    pa = None
+    if alpha_t is not None:
+        alpha_t, pa = _f(alpha_t)
+    out = np.empty_like(delta)
+    lib().ta_oracle_update_delta_linf(pd, px, pm, ctypes.c_float(alpha), pa, ctypes.c_float(eps),
+                                      out.ctypes.data_as(_f32p), ctypes.c_int64(delta.size))
+    return out
+
+
+def quantize_u8_nhwc(x, delta):
+    x, px = _f(x)
+    delta, pd = _f(delta)
+    n, c, h, w = x.shape
+    out = np.empty((n, h, w, c), dtype=np.uint8)
+    lib().ta_oracle_quantize_u8_nhwc(px, pd, out.ctypes.data_as(_u8p), ctypes.c_int64(n), c, h, w)
+    return out
+
+
+def depthwise_conv2d_same(x, w2d):
+    x, px = _f(x)
+    w2d, pw = _f(w2d)
+    k = w2d.shape[-1]
+    h, wd = x.shape[-2:]
+    planes = x.size // (h * wd)
+    out = np.empty_like(x)
+    lib().ta_oracle_depthwise_conv2d_same(px, out.ctypes.data_as(_f32p), pw, k, ctypes.c_int64(planes), h, wd)
+    return out
+
+
+def bilinear_fwd(x, out_size):
+    x, px = _f(x)
+    size = x.shape[-1]
+    planes = x.size // (size * size)
+    out = np.empty(x.shape[:-2] + (out_size, out_size), dtype=np.float32)
+    lib().ta_oracle_bilinear_fwd(px, out.ctypes.data_as(_f32p), ctypes.c_int64(planes), size, out_size)
+    return out
+
+
+def bilinear_bwd(gy, in_size, mode=0):
+    gy, pg = _f(gy)
+    out_size = gy.shape[-1]
+    planes = gy.size // (out_size * out_size)
+    gx = np.empty(gy.shape[:-2] + (in_size, in_size), dtype=np.float32)
+    lib().ta_oracle_bilinear_bwd(pg, gx.ctypes.data_as(_f32p), ctypes.c_int64(planes), in_size, out_size, mode)
+    return gx
+
+
+def dim_fwd(x, geom, resize):
+    apply, rnd, top, left = geom
+    x, px = _f(x)
+    if not apply:
+        return x.copy()
+    size = x.shape[-1]
+    planes = x.size // (size * size)
+    out = np.empty_like(x)
+    lib().ta_oracle_dim_fwd(px, out.ctypes.data_as(_f32p), ctypes.c_int64(planes), size, resize, rnd, top, left)
+    return out
+
+
+def dim_bwd(gy, geom, resize, mode=0):
+    apply, rnd, top, left = geom
+    gy, pg = _f(gy)
+    if not apply:
+        return gy.copy()
+    size = gy.shape[-1]
+    planes = gy.size // (size * size)
+    out = np.empty_like(gy)
+    lib().ta_oracle_dim_bwd(pg, out.ctypes.data_as(_f32p), ctypes.c_int64(planes), size, resize, rnd, top, left,
+                            mode)
+    return out
+
+
+def philox_uniform(numel, seed, offset, r):
+    out = np.empty(numel, dtype=np.float32)
+    lib().ta_oracle_philox_uniform(out.ctypes.data_as(_f32p), ctypes.c_int64(numel), ctypes.c_uint64(seed),
+                                   ctypes.c_uint64(offset), ctypes.c_float(r))
+    return out

@@ -1,0 +1,300 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the iterative FGSM-family hot path.
+
+This file is a *restatement* (not a copy) of the arithmetic the reference performs on its PyTorch
+CPU path; every function cites the reference ``file:line`` (relative to /root/reference) it follows.
+It exists only as the checker: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it; the product package ``transferattack_amd`` never does (its HIP path fails
+loudly instead of falling back here).
+
+Parity pin: the reference has no tests / golden vectors of its own, so this oracle
+is pinned against outputs of the reference's *own classes* imported in the build container through
+``oracle/ref_shim.py``; the vectors live in ``tests/golden/*.npz`` and were produced by
+``oracle/gen_golden.py`` (committed).  ``tests/test_oracle_golden.py`` checks every function here against
+them, bit for bit where the ATen op is thread-count invariant, <=2 ulp for ``F.interpolate``
+(SURVEY.md section 8c').
+
+All tensors are fp32 NCHW on the CPU.  Because the reference *is* PyTorch, the oracle uses the same
+ATen CPU ops in the same order -- that is what "the reference CPU path" means bit-wise.  The plain-C
+restatement of the same arithmetic (no torch) is ``oracle/ta_oracle.c``.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IMG_MAX, IMG_MIN = 1.0, 0  # transferattack/utils.py:13
+
+
+# ------------------------------------------------------------------------------------------------
+# update stack
+# ------------------------------------------------------------------------------------------------
+def box_clamp(x, lo, hi):
+    """min(max(x, lo), hi) with tensor bounds -- transferattack/utils.py:68-69."""
+    return torch.min(torch.max(x, lo), hi)
+
+
+def momentum_step(grad, momentum, decay):
+    """m <- m*decay + g / mean_{CHW}|g|   (no epsilon; ``momentum`` may be the Python int 0).
+
+    transferattack/attack.py:124-128.  An all-zero gradient image gives 0/0 = NaN momentum that
+    persists; ``torch.sign(NaN) == 0`` so delta_step then takes a zero step for that image.
+    """
+    l1 = grad.abs().mean(dim=(1, 2, 3), keepdim=True)
+    return momentum * decay + grad / l1
+
+
+def delta_step(delta, data, grad, alpha, epsilon, norm="linfty"):
+    """One perturbation update + projection -- transferattack/attack.py:145-153.
+
+    linfty: d <- clamp(d + alpha*sign(g), -eps, eps); l2: d <- renorm(d + alpha*g/(|g|_2+1e-20), eps);
+    then the image box d <- min(max(d, 0-x), 1-x).  ``alpha`` may be a float (also negative,
+    ensemble/cwa.py:69) or a tensor shaped like delta (gradient/gra.py:149).
+    """
+    if norm == "linfty":
+        delta = torch.clamp(delta + alpha * grad.sign(), -epsilon, epsilon)
+    else:
+        gn = torch.norm(grad.view(grad.size(0), -1), dim=1).view(-1, 1, 1, 1)
+        delta = (delta + grad / (gn + 1e-20) * alpha).view(delta.size(0), -1) \
+            .renorm(p=2, dim=0, maxnorm=epsilon).view_as(delta)
+    return box_clamp(delta, IMG_MIN - data, IMG_MAX - data)
+
+
+def delta_init(data, epsilon, random_start=False, norm="linfty", noise=None):
+    """transferattack/attack.py:130-143.  ``noise`` (optional, same shape) replaces the
+    ``uniform_(-eps, eps)`` draw so device-RNG paths can be compared on identical noise."""
+    delta = torch.zeros_like(data)
+    if random_start:
+        if norm != "linfty":
+            raise NotImplementedError("oracle restates the linfty random start only")
+        if noise is None:
+            delta.uniform_(-epsilon, epsilon)
+        else:
+            delta.copy_(noise)
+        delta = box_clamp(delta, IMG_MIN - data, IMG_MAX - data)
+    return delta
+
+
+def quantize_u8(adv):
+    """NCHW fp32 in [0,1] -> NHWC uint8 by *truncation* -- transferattack/utils.py:63-66."""
+    return (adv.detach().permute(0, 2, 3, 1).cpu().numpy() * 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# TIM
+# ------------------------------------------------------------------------------------------------
+def tim_kernel(kernel_type="gaussian", kernel_size=15, nsig=3):
+    """[3,1,k,k] fp32 depthwise kernel, built in fp64 then cast --
+    transferattack/input_transformation/tim.py:42-66.  The normal pdf is written out
+    (exp(-x^2/2)/sqrt(2pi)) instead of importing scipy; identical to scipy.stats.norm.pdf in fp64
+    up to the final normalisation (checked against the reference's kernel in the golden test)."""
+    kind = kernel_type.lower()
+    if kind == "gaussian":
+        x = np.linspace(-nsig, nsig, kernel_size)
+        k1 = np.exp(-x ** 2 / 2.0) / np.sqrt(2 * np.pi)
+        k2 = np.outer(k1, k1)
+        k2 = k2 / k2.sum()
+    elif kind == "uniform":
+        k2 = np.ones((kernel_size, kernel_size)) / (kernel_size ** 2)
+    elif kind == "linear":
+        k1 = 1 - np.abs(np.linspace((-kernel_size + 1) // 2, (kernel_size - 1) // 2, kernel_size)
+                        / (kernel_size ** 2))
+        k2 = np.outer(k1, k1)
+        k2 = k2 / k2.sum()
+    else:
+        raise Exception("Unspported kernel type {}".format(kernel_type))
+    return torch.from_numpy(np.stack([k2, k2, k2])[:, None].astype(np.float32))
+
+
+def tim_smooth(grad, kernel):
+    """Depthwise k x k 'same' (zero-padded) correlation of the gradient -- tim.py:72-74."""
+    return F.conv2d(grad, kernel, stride=1, padding="same", groups=3)
+
+
+# ------------------------------------------------------------------------------------------------
+# DIM
+# ------------------------------------------------------------------------------------------------
+def dim_draw(img_size, resize_rate=1.1, diversity_prob=0.5):
+    """Draw one DIM geometry from the *CPU default generator* in the reference's order
+    (rand -> randint(rnd) -> randint(top) -> randint(left)) -- dim.py:47-63.
+    Returns (apply, rnd, pad_top, pad_left); when ``apply`` is False nothing else is drawn."""
+    if torch.rand(1) > diversity_prob:
+        return (False, img_size, 0, 0)
+    img_resize = int(img_size * resize_rate)
+    rnd = int(torch.randint(low=min(img_size, img_resize), high=max(img_size, img_resize),
+                            size=(1,), dtype=torch.int32))
+    rem = img_resize - rnd
+    top = int(torch.randint(low=0, high=rem, size=(1,), dtype=torch.int32))
+    left = int(torch.randint(low=0, high=rem, size=(1,), dtype=torch.int32))
+    return (True, rnd, top, left)
+
+
+def dim_apply(x, geom, resize_rate=1.1):
+    """bilinear H->rnd, zero-pad to int(H*rate) at (top,left), bilinear back to H -- dim.py:55-68."""
+    apply, rnd, top, left = geom
+    if not apply:
+        return x
+    img_size = x.shape[-1]
+    img_resize = int(img_size * resize_rate)
+    rem = img_resize - rnd
+    y = F.interpolate(x, size=[rnd, rnd], mode="bilinear", align_corners=False)
+    y = F.pad(y, [left, rem - left, top, rem - top], value=0)
+    return F.interpolate(y, size=[img_size, img_size], mode="bilinear", align_corners=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# SIM / Admix
+# ------------------------------------------------------------------------------------------------
+def sim_copies(x, num_scale=5):
+    """cat_i x / 2^i along the batch axis -- sim.py:36-40."""
+    return torch.cat([x / (2 ** i) for i in range(num_scale)])
+
+
+def admix_draw(n, num_admix=3):
+    """``num_admix`` CPU-generator permutations of the batch, in call order -- admix.py:44."""
+    return [torch.randperm(n) for _ in range(num_admix)]
+
+
+def admix_copies(x, perms, admix_strength=0.2, num_scale=5):
+    """cat_j (x + s*x[perm_j].detach()) then cat_i (./2^i) -- admix.py:40-45."""
+    mixed = torch.cat([x + admix_strength * x[p].detach() for p in perms], dim=0)
+    return torch.cat([mixed / (2 ** i) for i in range(num_scale)])
+
+
+# ------------------------------------------------------------------------------------------------
+# surrogate wrapper (utils.py:37-60, 72-79) and ensemble (utils.py:82-105)
+# ------------------------------------------------------------------------------------------------
+def preprocess(x, resize, mean, std):
+    """Normalize(mean,std)(Resize(resize)(x)) -- utils.py:72-79.  torchvision's Resize on a square
+    tensor that already has that side is the identity, else bilinear align_corners=False."""
+    if x.shape[-1] != resize or x.shape[-2] != resize:
+        x = F.interpolate(x, size=(resize, resize), mode="bilinear", align_corners=False)
+    m = torch.as_tensor(mean, dtype=x.dtype).view(-1, 1, 1)
+    s = torch.as_tensor(std, dtype=x.dtype).view(-1, 1, 1)
+    return (x - m) / s
+
+
+def preprocess_cfg(backbone):
+    """(resize, mean, std) chosen as wrap_model does -- utils.py:41-56."""
+    if hasattr(backbone, "default_cfg"):
+        return 224, backbone.default_cfg["mean"], backbone.default_cfg["std"]
+    if "Inc" in backbone.__class__.__name__:
+        return 299, [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]
+    return 224, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def logits_of(backbones, x):
+    """Surrogate forward: single wrapped model, or mean of the M members' logits (EnsembleModel
+    mode='mean', utils.py:94-101)."""
+    if not isinstance(backbones, (list, tuple)):
+        return backbones(preprocess(x, *preprocess_cfg(backbones)))
+    outs = [b(preprocess(x, *preprocess_cfg(b))) for b in backbones]
+    return torch.mean(torch.stack(outs, dim=0), dim=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# loop-level oracle
+# ------------------------------------------------------------------------------------------------
+RECIPES = {
+    # name: overrides of the defaults below.  Presets: gradient/fgsm.py:28-33, ifgsm.py:30-35,
+    # mifgsm.py:31-36, nifgsm.py:35-39, vmifgsm.py:28-35, vnifgsm.py:37-41, dim.py:31-40, tim.py:35-40,
+    # sim.py:29-33, admix.py:32-38, ensemble/ens.py:31-36; DTS composition per SURVEY.md a17.
+    "fgsm": dict(alpha=16 / 255, epoch=1, decay=0.0),
+    "ifgsm": dict(decay=0.0),
+    "mifgsm": dict(),
+    "nifgsm": dict(lookahead=True),
+    "vmifgsm": dict(variance=True),
+    "vnifgsm": dict(variance=True, lookahead=True),
+    "dim": dict(dim=True),
+    "tim": dict(tim=True),
+    "sim": dict(sim=True),
+    "admix": dict(admix=True),
+    "ens": dict(),
+    "dts": dict(dim=True, tim=True, sim=True),
+}
+
+DEFAULTS = dict(epsilon=16 / 255, alpha=1.6 / 255, epoch=10, decay=1.0, targeted=False,
+                random_start=False, lookahead=False, variance=False, beta=1.5, num_neighbor=20,
+                dim=False, resize_rate=1.1, diversity_prob=0.5, tim=False, kernel_type="gaussian",
+                kernel_size=15, sim=False, admix=False, num_scale=5, num_admix=3, admix_strength=0.2)
+
+
+def run_attack(name, backbones, data, label, trace=None, **overrides):
+    """Whole K-iteration attack on the CPU; returns delta (detached) like Attack.forward
+    (attack.py:67-102; VMI variant vmifgsm.py:60-97).
+
+    RNG: DIM / Admix draw from the CPU default generator per call exactly as the reference does;
+    VMI neighbours draw ``zeros_like(delta).uniform_(-r, r)`` (vmifgsm.py:50) -- on the CPU that is
+    also the default generator, so seeding with ``torch.manual_seed`` reproduces the reference.
+    ``trace`` (optional list) receives per-iteration dicts (grad, momentum, delta, noise...) used
+    by the GPU parity tests to feed the HIP kernels the oracle's own intermediate tensors.
+    """
+    cfg = dict(DEFAULTS)
+    cfg.update(RECIPES[name])
+    cfg.update(overrides)
+    eps, alpha, decay = cfg["epsilon"], cfg["alpha"], cfg["decay"]
+    if cfg["targeted"]:
+        assert len(label) == 2  # attack.py:76-78
+        label = label[1]
+    data = data.clone().detach()
+    label = label.clone().detach()
+    kernel = tim_kernel(cfg["kernel_type"], cfg["kernel_size"]) if cfg["tim"] else None
+    copies = 1
+    if cfg["sim"]:
+        copies = cfg["num_scale"]
+    if cfg["admix"]:
+        copies = cfg["num_scale"] * cfg["num_admix"]
+    ce = torch.nn.CrossEntropyLoss()
+
+    def transform(x, momentum, rec):
+        if cfg["lookahead"]:                       # nifgsm.py:35-39
+            x = x + alpha * decay * momentum
+        if cfg["admix"]:                           # admix.py:40-45
+            perms = admix_draw(x.size(0), cfg["num_admix"])
+            rec.setdefault("perms", []).append([p.clone() for p in perms])
+            x = admix_copies(x, perms, cfg["admix_strength"], cfg["num_scale"])
+        elif cfg["sim"]:                           # sim.py:36-40
+            x = sim_copies(x, cfg["num_scale"])
+        if cfg["dim"]:                             # dim.py:42-68 (after SIM for DTS)
+            geom = dim_draw(x.shape[-1], cfg["resize_rate"], cfg["diversity_prob"])
+            rec.setdefault("geoms", []).append(geom)
+            x = dim_apply(x, geom, cfg["resize_rate"])
+        return x
+
+    def grad_at(x_in, delta, momentum, rec):
+        logits = logits_of(backbones, transform(x_in, momentum, rec))
+        lab = label.repeat(copies) if copies > 1 else label
+        loss = -ce(logits, lab) if cfg["targeted"] else ce(logits, lab)     # attack.py:110-115
+        g = torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0]
+        if kernel is not None:
+            g = tim_smooth(g, kernel)              # tim.py:72-74
+        return g
+
+    delta = delta_init(data, eps, cfg["random_start"]).requires_grad_(True)
+    momentum, variance = 0, 0
+    for it in range(cfg["epoch"]):
+        rec = {}
+        grad = grad_at(data + delta, delta, momentum, rec)
+        if cfg["variance"]:                        # vmifgsm.py:86-95
+            momentum_new = momentum_step(grad + variance, momentum, decay)
+            acc = 0
+            radius = cfg["beta"] * eps
+            noises = []
+            for _ in range(cfg["num_neighbor"]):
+                noise = torch.zeros_like(delta).uniform_(-radius, radius)
+                noises.append(noise)
+                acc = acc + grad_at(data + delta + noise, delta, momentum_new, rec)
+            variance_new = acc / cfg["num_neighbor"] - grad
+            rec["noises"] = noises
+            rec["variance_in"] = variance
+            variance = variance_new
+        else:
+            momentum_new = momentum_step(grad, momentum, decay)
+        delta_new = delta_step(delta.detach(), data, momentum_new, alpha, eps)
+        if trace is not None:
+            rec.update(grad=grad, momentum_in=momentum, momentum=momentum_new,
+                       delta_in=delta.detach().clone(), delta=delta_new.clone())
+            trace.append(rec)
+        momentum = momentum_new
+        delta = delta_new.detach().requires_grad_(True)
+    return delta.detach()

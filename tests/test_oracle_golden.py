@@ -1,0 +1,164 @@
+"""CPU: pin the oracle (oracle/fgsm_oracle.py, oracle/ta_oracle.c) to the golden vectors produced by the
+REAL reference classes (oracle/gen_golden.py).  Bit-exact everywhere except F.interpolate, whose CPU
+result depends on how ATen partitions the work (SURVEY.md 8c'): <= 2 ulp there."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import c_oracle as C
+import fgsm_oracle as O
+from conftest import u8_images, ulp_diff
+from transferattack_amd import backbones
+
+EPS, ALPHA = 16 / 255, 1.6 / 255
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def same(a, b):
+    """bit-pattern equality up to the sign of zero, NaN == NaN"""
+    a, b = np.asarray(a), np.asarray(b)
+    return np.array_equal(a, b, equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------- update stack
+@pytest.mark.parametrize("tag,decay,first", [("first", 1.0, True), ("d1", 1.0, False), ("d09", 0.9, False),
+                                             ("d0", 0.0, False)])
+def test_update_stack(golden, tag, decay, first):
+    g = golden("update_stack")
+    grad, mom, delta, x = t(g["grad"]), t(g["momentum"]), t(g["delta"]), t(g["x"])
+    m_new = O.momentum_step(grad, 0 if first else mom, decay)
+    assert same(m_new.numpy(), g["m_" + tag])
+    assert np.isnan(g["m_" + tag][2]).all()                        # zero-gradient image -> NaN momentum
+    d_new = O.delta_step(delta, x, m_new, ALPHA, EPS)
+    assert same(d_new.numpy(), g["delta_" + tag])
+    assert same(d_new[2].numpy(), delta[2].numpy())                # ... and a frozen delta
+    # plain-C restatement: same bits, no torch involved
+    m_c = C.momentum(g["grad"], None if first else g["momentum"], decay)
+    assert same(m_c, g["m_" + tag])
+    assert same(C.update_delta_linf(g["delta"], g["x"], m_c, ALPHA, EPS), g["delta_" + tag])
+
+
+def test_update_delta_variants(golden):
+    g = golden("update_stack")
+    delta, x, m = t(g["delta"]), t(g["x"]), t(g["m_d1"])
+    assert same(O.delta_step(delta, x, m, t(g["alpha_t"]), EPS).numpy(), g["delta_alpha_t"])
+    assert same(O.delta_step(delta, x, m, -ALPHA, EPS).numpy(), g["delta_alpha_neg"])
+    assert same(O.delta_step(delta, x, t(g["grad"]) + 1e-5, ALPHA, EPS, norm="l2").numpy(), g["delta_l2"])
+    assert same(C.update_delta_linf(g["delta"], g["x"], g["m_d1"], 0.0, EPS, alpha_t=g["alpha_t"]),
+                g["delta_alpha_t"])
+    assert same(C.update_delta_linf(g["delta"], g["x"], g["m_d1"], -ALPHA, EPS), g["delta_alpha_neg"])
+
+
+def test_quantiser(golden):
+    g = golden("update_stack")
+    assert np.array_equal(O.quantize_u8(t(g["x"]) + t(g["delta_d1"])), g["u8_d1"])
+    assert np.array_equal(C.quantize_u8_nhwc(g["x"], g["delta_d1"]), g["u8_d1"])
+
+
+def test_aten_row_sum_emulation():
+    """ta_oracle.c reproduces ATen's per-row cascade sum (the reduction behind
+    grad.abs().mean(dim=(1,2,3)), attack.py:128) bit for bit, ragged sizes included (E >= 8)."""
+    gen = torch.Generator().manual_seed(0)
+    for size in (8, 9, 31, 32, 33, 63, 64, 65, 511, 4097, 3 * 32 * 32, 150528, 268203):
+        rows = torch.rand(3, size, generator=gen) * 1e-3
+        ref = rows.sum(dim=1)
+        for i in range(3):
+            assert float(ref[i]) == float(C.aten_row_sum(rows[i].numpy())), size
+
+
+# ------------------------------------------------------------------------------------------------- TIM
+def test_tim(golden):
+    g = golden("tim")
+    for kind in ("gaussian", "uniform", "linear"):
+        assert same(O.tim_kernel(kind, 15).numpy(), g["kernel_" + kind]), kind
+    assert same(O.tim_kernel("gaussian", 7).numpy(), g["kernel_gaussian_7"])
+    out = O.tim_smooth(t(g["grad_in"]), O.tim_kernel())
+    assert same(out.numpy(), g["grad_out"])
+    assert same(C.depthwise_conv2d_same(g["grad_in"], g["kernel_gaussian"][0, 0]), g["grad_out"])
+    with pytest.raises(Exception):
+        O.tim_kernel("box", 15)
+
+
+# ------------------------------------------------------------------------------------------------- DIM
+def test_dim(golden):
+    g = golden("dim")
+    x, gy = t(g["x"]), t(g["gy"])
+    rate, prob = float(g["resize_rate"]), float(g["diversity_prob"])
+    resize = int(x.shape[-1] * rate)
+    n_transformed = 0
+    for i, seed in enumerate(g["seeds"]):
+        torch.manual_seed(int(seed))
+        geom = O.dim_draw(x.shape[-1], rate, prob)                 # same CPU-generator draw order
+        assert geom[0] == (not bool(g["identity"][i]))
+        xin = x.clone().requires_grad_(True)
+        y = O.dim_apply(xin, geom, rate)
+        assert ulp_diff(y.detach().numpy(), g["y"][i]) <= 2
+        if geom[0]:
+            n_transformed += 1
+            gx = torch.autograd.grad(y, xin, gy)[0]
+            assert same(gx.numpy(), g["gx"][i])
+            assert ulp_diff(C.dim_fwd(g["x"], geom, resize), g["y"][i]) <= 2
+            assert same(C.dim_bwd(g["gy"], geom, resize), g["gx"][i])
+    assert n_transformed == 3
+
+
+# ------------------------------------------------------------------------------------------ SIM / Admix
+def test_sim_admix(golden):
+    g = golden("copies")
+    x = t(g["x"])
+    xin = x.clone().requires_grad_(True)
+    y = O.sim_copies(xin)
+    assert same(y.detach().numpy(), g["sim_y"])
+    assert same(torch.autograd.grad(y, xin, t(g["sim_gy"]))[0].numpy(), g["sim_gx"])
+    torch.manual_seed(int(g["admix_seed"]))
+    perms = O.admix_draw(x.size(0))
+    xin = x.clone().requires_grad_(True)
+    y = O.admix_copies(xin, perms)
+    assert same(y.detach().numpy(), g["admix_y"])
+    assert same(torch.autograd.grad(y, xin, t(g["admix_gy"]))[0].numpy(), g["admix_gx"])
+
+
+# ----------------------------------------------------------------------------------------------- loops
+LOOP_NAMES = ["fgsm", "ifgsm", "mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim", "admix", "dts"]
+
+
+@pytest.mark.parametrize("name", LOOP_NAMES)
+def test_loops_toy(golden, name):
+    g = golden("loops_toy")
+    x = t(g["x_u8"]).float() / 255
+    label = t(g["label"])
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    torch.manual_seed(1234)
+    delta = O.run_attack(name, model, x, label)
+    assert same(delta.numpy(), g["delta_" + name])
+
+
+def test_loops_toy_variants(golden):
+    g = golden("loops_toy")
+    x = t(g["x_u8"]).float() / 255
+    label = t(g["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    torch.manual_seed(1234)
+    assert same(O.run_attack("ens", models, x, label).numpy(), g["delta_ens"])
+    d = O.run_attack("mifgsm", models[0], x, [label, t(g["target"])], targeted=True)
+    assert same(d.numpy(), g["delta_mifgsm_targeted"])
+    torch.manual_seed(77)
+    d = O.run_attack("mifgsm", models[0], x, label, random_start=True)
+    assert same(d.numpy(), g["delta_mifgsm_random_start"])
+
+
+def test_config1_ifgsm_resnet18(golden):
+    """BASELINE.json configs[0]: I-FGSM / ResNet-18 / 16 images / eps 16/255 / K=10 on the CPU path --
+    final uint8 adversarial images identical to the reference's."""
+    g = golden("config1_ifgsm_resnet18")
+    xu8 = u8_images(16, 224, int(g["seed_images"]))
+    assert zlib.crc32(xu8.numpy().tobytes()) == int(g["x_crc32"])
+    x = xu8.float() / 255
+    model = backbones.create("resnet18", seed=int(g["seed_weights"]), verbose=False)
+    delta = O.run_attack("ifgsm", model, x, t(g["label"]))
+    assert np.array_equal(O.quantize_u8(x + delta), g["adv_u8"])

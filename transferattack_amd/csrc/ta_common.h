@@ -1,0 +1,55 @@
+// Shared helpers for the gfx950 kernels of libta_hip.so (wave64, 256-thread workgroups).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ta_hip.h"
+
+namespace ta {
+
+constexpr int kBlock = 256;           // 4 wavefronts of 64
+constexpr int kWave = 64;
+constexpr int kVec = 4;               // fp32 per 16-byte lane access
+constexpr int kUnroll = 3;            // 16-byte accesses in flight per lane and operand
+constexpr int kTile = kBlock * kVec * kUnroll;   // 3072 elements per workgroup tile; 150528 = 49 tiles
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Deterministic 64-lane sum: fixed butterfly order, every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Deterministic workgroup sum (4 waves): wave butterflies, then waves added in index order.
+// `lds` must hold kBlock/kWave floats.  Every thread returns the total.
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    float t = lds[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) t += lds[w];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float sign_of(float m) {   // torch.sign: NaN -> 0, +-0 -> 0
+    return static_cast<float>(m > 0.0f) - static_cast<float>(m < 0.0f);
+}
+
+}  // namespace ta
+
+#define TA_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ta::set_error(__VA_ARGS__);       \
+            return TA_EINVAL;                 \
+        }                                     \
+    } while (0)

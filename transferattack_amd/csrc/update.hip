@@ -1,0 +1,435 @@
+// Update stack of the iterative FGSM loop for gfx950 (MI355X):
+//   K1  per-image sum|g|            (reference: grad.abs().mean(dim=(1,2,3)), attack.py:128)
+//   K2  fused momentum + sign + alpha-step + eps-ball projection + image-box clamp
+//                                    (reference: attack.py:124-128 and 145-153, utils.py:68-69)
+// Both kernels tile an image into 3072-element workgroup tiles (150528 = 49 tiles): every lane keeps
+// three 16-byte accesses per operand in flight, consecutive lanes touch consecutive 16 B (1 KiB per
+// wave instruction).  K1 and K2 use the same (tile, image) -> blockIdx map so the second read of g
+// comes from the same XCD's L2 / the Infinity Cache.  No float atomics: the partial sums are written
+// per tile and re-added in tile order by every wave of K2, so results do not depend on scheduling.
+//
+// Arithmetic is kept in the reference's order with contraction off (-ffp-contract=off):
+//   q = g / (sum|g| / E);  m' = m*decay + q;  d' = d + alpha*sign(m');  d' = min(max(d',-eps),eps);
+//   d' = min(max(d', 0 - x), 1 - x)
+#include "ta_common.h"
+
+namespace ta {
+
+template <int VEC> struct Pack;
+template <> struct Pack<4> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ float& operator[](int i) { return (&v.x)[i]; }
+    __device__ __forceinline__ float operator[](int i) const { return (&v.x)[i]; }
+};
+template <> struct Pack<1> {
+    float v;
+    __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ float& operator[](int) { return v; }
+    __device__ __forceinline__ float operator[](int) const { return v; }
+};
+
+// Per-thread slot layout of a tile: slot u (0..SLOTS-1) of thread t starts at element
+// (u*kBlock + t)*VEC of the tile; SLOTS*VEC*kBlock == kTile.
+template <int VEC> struct Slots { static constexpr int n = kTile / (kBlock * VEC); };
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+template <int VEC, bool HAS_V, bool SQUARE>
+__global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* __restrict__ g,
+                                                                  const float* __restrict__ v,
+                                                                  float* __restrict__ ws, int64_t e,
+                                                                  int tiles) {
+    __shared__ float lds[kBlock / kWave];
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    const float* gi = g + img * e;
+    const float* vi = HAS_V ? v + img * e : nullptr;
+    constexpr int S = Slots<VEC>::n;
+    Pack<VEC> a[S], b[S];
+    bool full[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        full[u] = off + VEC <= e;
+        if (full[u]) {
+            a[u].load(gi + off);
+            if (HAS_V) b[u].load(vi + off);
+        }
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        if (full[u]) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float x = HAS_V ? a[u][k] + b[u][k] : a[u][k];
+                acc += SQUARE ? x * x : fabsf(x);
+            }
+        } else if (VEC > 1) {   // ragged end of an image whose size is not a multiple of VEC
+            const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const float x = HAS_V ? gi[i] + vi[i] : gi[i];
+                acc += SQUARE ? x * x : fabsf(x);
+            }
+        }
+    }
+    const float total = block_sum(acc, lds);
+    if (threadIdx.x == 0) ws[img * tiles + blockIdx.x] = total;
+}
+
+// sum of an image's tile partials, identical in every lane of every wave (fixed order)
+__device__ __forceinline__ float image_total(const float* __restrict__ ws, int64_t img, int tiles) {
+    const int lane = threadIdx.x & 63;
+    float t = 0.0f;
+    for (int i = lane; i < tiles; i += kWave) t += ws[img * tiles + i];
+    return wave_sum(t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 (fused) and the two hook-level halves
+// ------------------------------------------------------------------------------------------------
+struct StepParams {
+    float decay, alpha, neg_eps, eps;
+};
+
+__device__ __forceinline__ float project(float d, float x, float neg_eps, float eps) {
+    d = fminf(fmaxf(d, neg_eps), eps);          // torch.clamp(., -eps, eps)   attack.py:147
+    d = fmaxf(d, 0.0f - x);                      // clamp(., img_min - x, .)    utils.py:68-69
+    return fminf(d, 1.0f - x);                   // clamp(., ., img_max - x)
+}
+
+template <int VEC, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
+__global__ __launch_bounds__(kBlock) void mi_update_kernel(
+    const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out,
+    float* delta, const float* __restrict__ x, float* __restrict__ x_adv,
+    const float* __restrict__ ws, StepParams p, int64_t e, int tiles) {
+    const int64_t img = blockIdx.y;
+    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * kTile;
+    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * kTile;   // elements of this image from tile start
+    constexpr int S = Slots<VEC>::n;
+    Pack<VEC> pg[S], pv[S], pm[S], pd[S], px[S];
+    bool full[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        full[u] = off + VEC <= left;
+        if (full[u]) {
+            pg[u].load(g + base + off);
+            if (HAS_V) pv[u].load(v + base + off);
+            if (HAS_MIN) pm[u].load(m_in + base + off);
+            pd[u].load(delta + base + off);
+            px[u].load(x + base + off);
+        }
+    }
+    const float mean = image_total(ws, img, tiles) / static_cast<float>(e);   // sum then div_ (ATen mean)
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (full[u]) {
+            Pack<VEC> om, od, oa;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float gg = HAS_V ? pg[u][k] + pv[u][k] : pg[u][k];
+                const float q = gg / mean;
+                const float mprev = HAS_MIN ? pm[u][k] : 0.0f;
+                const float mn = mprev * p.decay + q;
+                const float d = project(pd[u][k] + p.alpha * sign_of(mn), px[u][k], p.neg_eps, p.eps);
+                om[k] = mn;
+                od[k] = d;
+                oa[k] = px[u][k] + d;
+            }
+            if (HAS_MOUT) om.store(m_out + base + off);
+            od.store(delta + base + off);
+            if (HAS_XADV) oa.store(x_adv + base + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < left && i < off + VEC; ++i) {
+                const float gg = HAS_V ? g[base + i] + v[base + i] : g[base + i];
+                const float q = gg / mean;
+                const float mprev = HAS_MIN ? m_in[base + i] : 0.0f;
+                const float mn = mprev * p.decay + q;
+                const float xx = x[base + i];
+                const float d = project(delta[base + i] + p.alpha * sign_of(mn), xx, p.neg_eps, p.eps);
+                if (HAS_MOUT) m_out[base + i] = mn;
+                delta[base + i] = d;
+                if (HAS_XADV) x_adv[base + i] = xx + d;
+            }
+        }
+    }
+}
+
+template <int VEC, bool HAS_V, bool HAS_MIN>
+__global__ __launch_bounds__(kBlock) void momentum_kernel(const float* __restrict__ g,
+                                                          const float* __restrict__ v,
+                                                          const float* m_in, float* m_out,
+                                                          const float* __restrict__ ws, float decay,
+                                                          int64_t e, int tiles) {
+    const int64_t img = blockIdx.y;
+    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * kTile;
+    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * kTile;
+    const float mean = image_total(ws, img, tiles) / static_cast<float>(e);
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= left) {
+            Pack<VEC> pg, pv, pm, om;
+            pg.load(g + base + off);
+            if (HAS_V) pv.load(v + base + off);
+            if (HAS_MIN) pm.load(m_in + base + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float gg = HAS_V ? pg[k] + pv[k] : pg[k];
+                om[k] = (HAS_MIN ? pm[k] : 0.0f) * decay + gg / mean;
+            }
+            om.store(m_out + base + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < left && i < off + VEC; ++i) {
+                const float gg = HAS_V ? g[base + i] + v[base + i] : g[base + i];
+                m_out[base + i] = (HAS_MIN ? m_in[base + i] : 0.0f) * decay + gg / mean;
+            }
+        }
+    }
+}
+
+template <int VEC, bool ALPHA_T, bool HAS_XADV>
+__global__ __launch_bounds__(kBlock) void update_delta_linf_kernel(
+    const float* delta_in, const float* __restrict__ x, const float* __restrict__ m,
+    const float* __restrict__ alpha_t, float* delta_out, float* __restrict__ x_adv, float alpha,
+    float neg_eps, float eps, int64_t numel) {
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = base + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= numel) {
+            Pack<VEC> pd, px, pm, pa, od, oa;
+            pd.load(delta_in + off);
+            px.load(x + off);
+            pm.load(m + off);
+            if (ALPHA_T) pa.load(alpha_t + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float a = ALPHA_T ? pa[k] : alpha;
+                od[k] = project(pd[k] + a * sign_of(pm[k]), px[k], neg_eps, eps);
+                oa[k] = px[k] + od[k];
+            }
+            od.store(delta_out + off);
+            if (HAS_XADV) oa.store(x_adv + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < numel && i < off + VEC; ++i) {
+                const float a = ALPHA_T ? alpha_t[i] : alpha;
+                const float d = project(delta_in[i] + a * sign_of(m[i]), x[i], neg_eps, eps);
+                delta_out[i] = d;
+                if (HAS_XADV) x_adv[i] = x[i] + d;
+            }
+        }
+    }
+}
+
+// L2 branch, pass B: d' = d + (g / (|g|_2 + 1e-20)) * alpha, plus per-tile sum of d'^2 into ws2
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void l2_step_kernel(const float* delta_in,
+                                                         const float* __restrict__ g, float* delta_out,
+                                                         const float* __restrict__ ws_g2,
+                                                         float* __restrict__ ws_d2, float alpha,
+                                                         int64_t e, int tiles) {
+    __shared__ float lds[kBlock / kWave];
+    const int64_t img = blockIdx.y;
+    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * kTile;
+    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * kTile;
+    const float gnorm = sqrtf(image_total(ws_g2, img, tiles)) + 1e-20f;
+    constexpr int S = Slots<VEC>::n;
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        for (int64_t i = off; i < left && i < off + VEC; ++i) {
+            const float d = delta_in[base + i] + (g[base + i] / gnorm) * alpha;
+            delta_out[base + i] = d;
+            acc += d * d;
+        }
+    }
+    const float total = block_sum(acc, lds);
+    if (threadIdx.x == 0) ws_d2[img * tiles + blockIdx.x] = total;
+}
+
+// L2 branch, pass C: renorm(p=2, maxnorm=eps) then the image box
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void l2_renorm_kernel(float* delta, const float* __restrict__ x,
+                                                           const float* __restrict__ ws_d2, float eps,
+                                                           int64_t e, int tiles) {
+    const int64_t img = blockIdx.y;
+    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * kTile;
+    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * kTile;
+    const float norm = sqrtf(image_total(ws_d2, img, tiles));
+    const float scale = norm > eps ? eps / (norm + 1e-7f) : 1.0f;     // at::renorm
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        for (int64_t i = off; i < left && i < off + VEC; ++i) {
+            float d = delta[base + i];
+            if (norm > eps) d = d * scale;
+            const float xx = x[base + i];
+            delta[base + i] = fminf(fmaxf(d, 0.0f - xx), 1.0f - xx);
+        }
+    }
+}
+
+template <typename F> int dispatch_bool(bool b, F&& f) { return b ? f(std::true_type{}) : f(std::false_type{}); }
+
+static bool vec_ok(int64_t e, std::initializer_list<const void*> ptrs) {
+    if (e % kVec != 0) return false;
+    for (const void* p : ptrs)
+        if (p != nullptr && !aligned16(p)) return false;
+    return true;
+}
+
+static int launch_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e, bool square,
+                           hipStream_t st) {
+    const int tiles = static_cast<int>(ceil_div(e, kTile));
+    const dim3 grid(tiles, static_cast<unsigned>(n));
+    const bool vec = vec_ok(e, {g, v});
+#define TA_K1(VEC, HV, SQ) \
+    hipLaunchKernelGGL((abs_sum_partials_kernel<VEC, HV, SQ>), grid, dim3(kBlock), 0, st, g, v, ws, e, tiles)
+    if (vec) {
+        if (square) { TA_K1(4, false, true); }
+        else if (v) { TA_K1(4, true, false); }
+        else { TA_K1(4, false, false); }
+    } else {
+        if (square) { TA_K1(1, false, true); }
+        else if (v) { TA_K1(1, true, false); }
+        else { TA_K1(1, false, false); }
+    }
+#undef TA_K1
+    return check_launch("abs_sum_partials");
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+static int check_batch(int64_t n, int64_t e) {
+    TA_REQUIRE(n > 0 && e > 0, "batch (n=%lld, e=%lld) must be positive", (long long)n, (long long)e);
+    TA_REQUIRE(n <= 65535, "n=%lld exceeds the 65535 images one launch addresses", (long long)n);
+    TA_REQUIRE(ceil_div(e, kTile) < (1ll << 31), "image too large");
+    return 0;
+}
+
+extern "C" int64_t ta_l1_workspace_floats(int64_t n, int64_t e) {
+    if (n <= 0 || e <= 0) return 0;
+    return 2 * n * ceil_div(e, kTile);    // two regions: the L2 branch needs |g|^2 and |d'|^2 partials
+}
+
+extern "C" int ta_abs_sum_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e,
+                                   void* stream) {
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(g && ws, "null pointer");
+    return launch_partials(g, v, ws, n, e, false, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ta_momentum(const float* g, const float* v, const float* m_in, float* m_out, float* ws,
+                           float decay, int64_t n, int64_t e, void* stream) {
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(g && m_out && ws, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
+    const int tiles = static_cast<int>(ceil_div(e, kTile));
+    const dim3 grid(tiles, static_cast<unsigned>(n));
+    const bool vec = vec_ok(e, {g, v, m_in, m_out});
+#define TA_MOM(VEC, HV, HM) \
+    hipLaunchKernelGGL((momentum_kernel<VEC, HV, HM>), grid, dim3(kBlock), 0, st, g, v, m_in, m_out, ws, decay, e, tiles)
+    if (vec) {
+        if (v && m_in) { TA_MOM(4, true, true); } else if (v) { TA_MOM(4, true, false); }
+        else if (m_in) { TA_MOM(4, false, true); } else { TA_MOM(4, false, false); }
+    } else {
+        if (v && m_in) { TA_MOM(1, true, true); } else if (v) { TA_MOM(1, true, false); }
+        else if (m_in) { TA_MOM(1, false, true); } else { TA_MOM(1, false, false); }
+    }
+#undef TA_MOM
+    return check_launch("momentum");
+}
+
+extern "C" int ta_update_delta_linf(const float* delta_in, const float* x, const float* m, float alpha,
+                                    const float* alpha_t, float eps, float* delta_out, float* x_adv,
+                                    int64_t numel, void* stream) {
+    TA_REQUIRE(numel > 0, "numel must be positive");
+    TA_REQUIRE(delta_in && x && m && delta_out, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(static_cast<unsigned>(ceil_div(numel, kTile)));
+    const bool vec = vec_ok(0, {delta_in, x, m, alpha_t, delta_out, x_adv});
+#define TA_UPD(VEC, AT, XA)                                                                          \
+    hipLaunchKernelGGL((update_delta_linf_kernel<VEC, AT, XA>), grid, dim3(kBlock), 0, st, delta_in, x, \
+                       m, alpha_t, delta_out, x_adv, alpha, -eps, eps, numel)
+    if (vec) {
+        if (alpha_t && x_adv) { TA_UPD(4, true, true); } else if (alpha_t) { TA_UPD(4, true, false); }
+        else if (x_adv) { TA_UPD(4, false, true); } else { TA_UPD(4, false, false); }
+    } else {
+        if (alpha_t && x_adv) { TA_UPD(1, true, true); } else if (alpha_t) { TA_UPD(1, true, false); }
+        else if (x_adv) { TA_UPD(1, false, true); } else { TA_UPD(1, false, false); }
+    }
+#undef TA_UPD
+    return check_launch("update_delta_linf");
+}
+
+extern "C" int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, float alpha,
+                                  float eps, float* delta_out, float* ws, int64_t n, int64_t e,
+                                  void* stream) {
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(delta_in && x && g && delta_out && ws, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tiles = static_cast<int>(ceil_div(e, kTile));
+    float* ws_g2 = ws;
+    float* ws_d2 = ws + n * tiles;
+    if (int rc = launch_partials(g, nullptr, ws_g2, n, e, true, st)) return rc;
+    const dim3 grid(tiles, static_cast<unsigned>(n));
+    hipLaunchKernelGGL((l2_step_kernel<1>), grid, dim3(kBlock), 0, st, delta_in, g, delta_out, ws_g2, ws_d2,
+                       alpha, e, tiles);
+    if (int rc = check_launch("l2_step")) return rc;
+    hipLaunchKernelGGL((l2_renorm_kernel<1>), grid, dim3(kBlock), 0, st, delta_out, x, ws_d2, eps, e, tiles);
+    return check_launch("l2_renorm");
+}
+
+extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                            const float* x, float* x_adv, float* ws, float decay, float alpha, float eps,
+                            int64_t n, int64_t e, void* stream) {
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(g && delta && x && ws, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
+    const int tiles = static_cast<int>(ceil_div(e, kTile));
+    const dim3 grid(tiles, static_cast<unsigned>(n));
+    const StepParams p{decay, alpha, -eps, eps};
+    const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
+    const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
+#define TA_MI(VEC, HV, HMI, HMO, HXA)                                                                   \
+    hipLaunchKernelGGL((mi_update_kernel<VEC, HV, HMI, HMO, HXA>), grid, dim3(kBlock), 0, st, g, v, m_in, \
+                       m_out, delta, x, x_adv, ws, p, e, tiles)
+#define TA_MI_CASES(VEC)                                   \
+    switch (key) {                                         \
+        case 0: TA_MI(VEC, false, false, false, false); break; \
+        case 1: TA_MI(VEC, false, false, false, true); break;  \
+        case 2: TA_MI(VEC, false, false, true, false); break;  \
+        case 3: TA_MI(VEC, false, false, true, true); break;   \
+        case 4: TA_MI(VEC, false, true, false, false); break;  \
+        case 5: TA_MI(VEC, false, true, false, true); break;   \
+        case 6: TA_MI(VEC, false, true, true, false); break;   \
+        case 7: TA_MI(VEC, false, true, true, true); break;    \
+        case 8: TA_MI(VEC, true, false, false, false); break;  \
+        case 9: TA_MI(VEC, true, false, false, true); break;   \
+        case 10: TA_MI(VEC, true, false, true, false); break;  \
+        case 11: TA_MI(VEC, true, false, true, true); break;   \
+        case 12: TA_MI(VEC, true, true, false, false); break;  \
+        case 13: TA_MI(VEC, true, true, false, true); break;   \
+        case 14: TA_MI(VEC, true, true, true, false); break;   \
+        default: TA_MI(VEC, true, true, true, true); break;    \
+    }
+    if (vec) { TA_MI_CASES(4) } else { TA_MI_CASES(1) }
+#undef TA_MI_CASES
+#undef TA_MI
+    return check_launch("mi_update");
+}
