@@ -66,6 +66,8 @@ int64_t ta_fused_sync_bytes(int64_t n, int64_t e);
 int ta_mi_update_fused(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
                        const float* x, float* x_adv, void* sync_ws, float decay, float alpha,
                        float eps, int64_t n, int64_t e, void* stream);
+/* host-synchronous check (and reset) of the exchange's sticky timeout word; 0 = no timeout so far */
+int ta_fused_sync_error(void* sync_ws, int64_t n, int64_t e, void* stream);
 
 /* Attack.init_delta random start (attack.py:133-141, linfty): d <- box(U(-eps,eps)); counter-based
  * Philox4x32-10 keyed by (seed, offset); noise (nullable) overrides the draw with caller noise */
@@ -75,12 +77,10 @@ int ta_init_delta_uniform(float* delta, const float* x, const float* noise, floa
 /* ---- TIM: TIM.get_grad  input_transformation/tim.py:72-74 ------------------------------------------
  * depthwise k x k 'same' zero-padded correlation of every (n,c) plane with ONE k x k kernel `w`
  * (device pointer, k*k fp32, row-major).  Tap order is row-major FMA chain == the reference CPU path.
- * `separable`!=0 uses w1d (k fp32, device) twice (fast mode; differs from the 2-D chain by <=1e-6 rel).
+ * k <= 31; in and out must not alias.
  */
 int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, int k, int64_t planes,
                              int h, int w_, void* stream);
-int ta_depthwise_conv2d_separable(const float* in, float* out, float* tmp, const float* w1d, int k,
-                                  int64_t planes, int h, int w_, void* stream);
 
 /* ---- DIM: DIM.transform  input_transformation/dim.py:42-68 ----------------------------------------
  * y = bilinear(pad0(bilinear(x, rnd), resize, top, left), size); one geometry for the whole call.
@@ -93,9 +93,9 @@ int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize,
 
 /* ---- SIM / Admix: sim.py:36-40, admix.py:40-45 ------------------------------------------------------
  * sim fwd : y[i*n + b] = x[b] / 2^i                              i < num_scale
- * sim bwd : gx[b] = sum_i gy[i*n + b] / 2^i                      (i ascending)
+ * sim bwd : gx[b] = sum_i gy[i*n + b] / 2^i                      (i descending = autograd's order)
  * admix fwd: y[(i*num_admix + j)*n + b] = (x[b] + strength * x[perm[j*n + b]]) / 2^i
- * admix bwd: gx[b] = sum_i sum_j gy[(i*num_admix + j)*n + b] / 2^i     (mixed-in term is detached)
+ * admix bwd: gx[b] = sum_j (sum_i gy[(i*num_admix + j)*n + b] / 2^i)  j, i descending (detached mix term)
  * perm: device int64 [num_admix*n].
  */
 int ta_scale_copies_fwd(const float* x, float* y, int64_t n, int64_t e, int num_scale, void* stream);

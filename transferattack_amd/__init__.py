@@ -1,0 +1,39 @@
+"""transferattack_amd -- MI355X-native engine for the iterative FGSM-family hot path of
+Trustworthy-AI-Group/TransferAttack, behind the reference's plug-in API:
+
+    attack_zoo / load_attack_class      transferattack/__init__.py:3-160
+    Attack and its hooks                transferattack/attack.py:8-169
+
+Only the path BASELINE.json names is implemented (gradient/, input_transformation/, ensemble/ members in
+the zoo below); other reference attacks ride on the same hooks but are not shipped here.
+"""
+import importlib
+
+attack_zoo = {
+    # gradient
+    'fgsm': ('.gradient.fgsm', 'FGSM'),
+    'ifgsm': ('.gradient.ifgsm', 'IFGSM'),
+    'mifgsm': ('.gradient.mifgsm', 'MIFGSM'),
+    'nifgsm': ('.gradient.nifgsm', 'NIFGSM'),
+    'vmifgsm': ('.gradient.vmifgsm', 'VMIFGSM'),
+    'vnifgsm': ('.gradient.vnifgsm', 'VNIFGSM'),
+    # input transformation
+    'dim': ('.input_transformation.dim', 'DIM'),
+    'tim': ('.input_transformation.tim', 'TIM'),
+    'sim': ('.input_transformation.sim', 'SIM'),
+    'admix': ('.input_transformation.admix', 'Admix'),
+    'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
+    # ensemble
+    'ens': ('.ensemble.ens', 'ENS'),
+}
+
+
+def load_attack_class(attack_name):
+    if attack_name not in attack_zoo:
+        raise Exception('Unspported attack algorithm {}'.format(attack_name))
+    module_path, class_name = attack_zoo[attack_name]
+    module = importlib.import_module(module_path, __package__)
+    return getattr(module, class_name)
+
+
+__version__ = '0.1.0'

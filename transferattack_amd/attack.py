@@ -1,0 +1,177 @@
+"""``Attack``: the reference's base class / plug-in API (transferattack/attack.py:8-169) with the
+per-iteration update stack on hand-written gfx950 kernels.
+
+Hook names, signatures, defaults and error behaviour are the reference's, so its subclasses keep working:
+
+    load_model(model_name)            attack.py:40-65      get_momentum(grad, momentum, **kw)   :124-128
+    forward(data, label, **kw)        :67-102              init_delta(data, **kw)               :130-143
+    get_logits(x, **kw)               :104-108             update_delta(delta, data, grad, alpha, **kw) :145-153
+    get_loss(logits, label)           :110-115             loss_function(loss)                  :155-162
+    get_grad(loss, delta, **kw)       :118-122             transform(data, **kw)                :164-165
+
+What runs where: the surrogate forward/backward is PyTorch-ROCm (MIOpen / rocBLAS); ``get_momentum`` and
+``update_delta`` are HIP kernels (``ta_momentum``, ``ta_update_delta_linf|l2``).  When a subclass overrides
+neither hook, ``forward`` replaces the pair by ONE fused launch sequence (``ta_mi_update``): per-image sum|g|,
+then momentum accumulate + sign + alpha-step + eps-ball + image-box in a single pass (24 B/element instead of
+the reference's 13 ATen kernels / ~116 B/element).  There is no CPU fallback: tensors must be on a HIP device.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _hip, backbones
+from .utils import EnsembleModel, default_device, wrap_model, img_max, img_min, clamp  # noqa: F401
+
+
+class Attack(object):
+    """Base class for all attacks (same constructor as transferattack/attack.py:12-38)."""
+
+    # set TA_SINGLE_LAUNCH_UPDATE=1 to use the single-launch variant of the fused update (ta_mi_update_fused)
+    single_launch_update = os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0") == "1"
+
+    def __init__(self, attack, model_name, epsilon, targeted, random_start, norm, loss, device=None):
+        if norm not in ['l2', 'linfty']:
+            raise Exception("Unsupported norm {}".format(norm))
+        self.attack = attack
+        self.model = self.load_model(model_name)
+        self.epsilon = epsilon
+        self.targeted = targeted
+        self.random_start = random_start
+        self.norm = norm
+        if isinstance(self.model, EnsembleModel):
+            self.device = self.model.device
+        else:
+            self.device = next(self.model.parameters()).device if device is None else device
+        self.loss = self.loss_function(loss)
+        # RNG state of the device-side draws (random start, VMI neighbours): Philox (seed, running offset)
+        self.rng_seed = int(os.environ.get("TA_SEED", "0"))
+        self.rng_offset = 0
+        # test hook: callable(shape, low, high) -> device tensor replacing an in-kernel uniform draw
+        self.noise_source = None
+
+    # ------------------------------------------------------------------------------------------ model
+    def load_model(self, model_name):
+        """Build the surrogate(s) from ``transferattack_amd.backbones`` (torchvision names first, then timm
+        names, as attack.py:52-57), put them in eval mode on this process's HIP device and wrap them with
+        the preprocessing layer.  Override for customised surrogates, as in the reference."""
+        def load_single_model(name):
+            model = backbones.create(name)          # raises ValueError('Model {} not supported')
+            for p in model.parameters():
+                p.requires_grad_(False)             # only d(loss)/d(delta) is ever needed
+            return wrap_model(model.eval().to(default_device()))
+
+        if isinstance(model_name, list):
+            return EnsembleModel([load_single_model(name) for name in model_name])
+        return load_single_model(model_name)
+
+    # ------------------------------------------------------------------------------------------- loop
+    def forward(self, data, label, **kwargs):
+        """The general attack procedure (attack.py:67-102).
+
+        data (N, C, H, W) images in [0, 1]; label (N,) or [ground-truth, target] when targeted.
+        Returns the perturbation ``delta`` (detached, on ``self.device``)."""
+        if self.targeted:
+            assert len(label) == 2
+            label = label[1]
+        data = data.clone().detach().to(self.device)
+        label = label.clone().detach().to(self.device)
+
+        delta = self.init_delta(data)
+        momentum = 0
+        fused = self._can_fuse_update()
+        for _ in range(self.epoch):
+            logits = self.get_logits(self.transform(data + delta, momentum=momentum))
+            loss = self.get_loss(logits, label)
+            grad = self.get_grad(loss, delta)
+            if fused:
+                momentum = self._fused_update(grad, momentum, delta, data)
+            else:
+                momentum = self.get_momentum(grad, momentum)
+                delta = self.update_delta(delta, data, momentum, self.alpha)
+        return delta.detach()
+
+    def _can_fuse_update(self):
+        cls = type(self)
+        return (self.norm == 'linfty' and cls.get_momentum is Attack.get_momentum
+                and cls.update_delta is Attack.update_delta and not isinstance(self.alpha, torch.Tensor))
+
+    def _fused_update(self, grad, momentum, delta, data, variance=None):
+        """get_momentum + update_delta in one pass; ``delta`` (a leaf) is updated in place -- the graph of
+        this iteration has already been consumed by ``get_grad``.  Returns the new momentum tensor."""
+        grad = grad.contiguous()
+        m_in = momentum if isinstance(momentum, torch.Tensor) else None
+        m_out = m_in if m_in is not None else torch.empty_like(grad)
+        if variance is not None and not isinstance(variance, torch.Tensor):
+            variance = None                                   # the Python 0 of the first VMI iteration
+        _hip.mi_update(grad, m_in, m_out, delta.detach(), data, self.decay, self.alpha, self.epsilon,
+                       variance=variance, single_launch=self.single_launch_update)
+        return m_out
+
+    # ------------------------------------------------------------------------------------------ hooks
+    def get_logits(self, x, **kwargs):
+        return self.model(x)
+
+    def get_loss(self, logits, label):
+        return -self.loss(logits, label) if self.targeted else self.loss(logits, label)
+
+    def get_grad(self, loss, delta, **kwargs):
+        return torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0]
+
+    def get_momentum(self, grad, momentum, **kwargs):
+        """momentum*decay + grad / mean|grad| per image (attack.py:124-128); ``momentum`` may be 0."""
+        grad = grad.contiguous()
+        if not isinstance(momentum, torch.Tensor):
+            momentum = None if momentum == 0 else torch.full_like(grad, float(momentum))
+        out = torch.empty_like(grad)
+        _hip.momentum(grad, None if momentum is None else momentum.contiguous(), out, self.decay)
+        return out
+
+    def init_delta(self, data, **kwargs):
+        """Zeros, or a uniform / scaled-normal random start clamped to the image box (attack.py:130-143)."""
+        delta = torch.zeros_like(data).to(self.device)
+        if self.random_start:
+            if self.norm == 'linfty':
+                noise = None
+                if self.noise_source is not None:
+                    noise = self.noise_source(data.shape, -self.epsilon, self.epsilon).to(self.device).contiguous()
+                _hip.init_delta_uniform(delta, data.contiguous(), self.epsilon, self.rng_seed, self._next_offset(),
+                                        noise=noise)
+            else:
+                delta.normal_(-self.epsilon, self.epsilon)
+                d_flat = delta.view(delta.size(0), -1)
+                n = d_flat.norm(p=2, dim=-1).view(delta.size(0), 1, 1, 1)
+                r = torch.zeros_like(data).uniform_(0, 1).to(self.device)
+                delta *= r / n * self.epsilon
+                delta = clamp(delta, img_min - data, img_max - data)
+        delta.requires_grad = True
+        return delta
+
+    def update_delta(self, delta, data, grad, alpha, **kwargs):
+        """delta + alpha*sign(grad) projected on the eps-ball and the image box (attack.py:145-153);
+        returns a fresh leaf with requires_grad=True.  ``alpha``: float (may be negative) or tensor."""
+        src = delta.detach().contiguous()
+        out = torch.empty_like(src)
+        if self.norm == 'linfty':
+            _hip.update_delta_linf(src, data.contiguous(), grad.detach().contiguous(), alpha, self.epsilon, out)
+        else:
+            if isinstance(alpha, torch.Tensor):
+                raise Exception("Unsupported tensor step size for norm l2")
+            _hip.update_delta_l2(src, data.contiguous(), grad.detach().contiguous(), alpha, self.epsilon, out)
+        return out.requires_grad_(True)
+
+    def loss_function(self, loss):
+        if loss == 'crossentropy':
+            return nn.CrossEntropyLoss()
+        raise Exception("Unsupported loss {}".format(loss))
+
+    def transform(self, data, **kwargs):
+        return data
+
+    def _next_offset(self):
+        self.rng_offset += 1
+        return self.rng_offset
+
+    def __call__(self, *input, **kwargs):
+        self.model.eval()
+        return self.forward(*input, **kwargs)

@@ -1,0 +1,228 @@
+// DIM input diversity for gfx950 (reference: DIM.transform, input_transformation/dim.py:42-68):
+//     y = bilinear_{resize->size}( zero_pad_{resize, top, left}( bilinear_{size->rnd}(x) ) )
+// as ONE gather kernel forward (no rnd x rnd / resize x resize intermediates in HBM: 8 B/element) and ONE
+// gather kernel backward (exact adjoint, no float atomics, 8 B/element).
+//
+// Numerics follow ATen's CPU kernels, which is what the reference runs (restated in oracle/ta_oracle.c):
+//   taps      src = fma(in/out, dst + 0.5, -0.5) clamped at 0;  i0 = floor, i1 = min(i0+1, in-1);
+//             l1 = src - i0, l0 = 1 - l1                         (UpSample.h compute_source_index_and_lambda)
+//   forward   width first  a = fma(lx0, v[i0], lx1 * v[i1]), then height  fma(ly0, a, ly1 * b)
+//   backward  four updates per output pixel in output order, acc = fma(ly*lx, g, acc)
+//             (cpu_upsample_linear_backward).  The gather visits, for one target pixel, exactly the
+//             updates that hit it, in that same order -> bit-identical accumulation.
+// The 1-D tap tables (and, for the backward, the inverse "which outputs touch this source index" ranges)
+// are rebuilt in LDS by every workgroup: <= 250 entries, cheaper than a host round trip per iteration.
+#include <limits.h>
+#include "ta_common.h"
+
+namespace ta {
+
+struct Tap {
+    int i0, i1;
+    float l0, l1;
+};
+
+__device__ __forceinline__ Tap make_tap(int o, int in_size, int out_size) {
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    int i0 = static_cast<int>(src);
+    i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+    const int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    const float l1 = fminf(fmaxf(src - static_cast<float>(i0), 0.0f), 1.0f);
+    return Tap{i0, i1, 1.0f - l1, l1};
+}
+
+constexpr int kDimMaxSide = 1024;       // LDS tables are sized for sides up to this
+
+// ---------------------------------------------------------------------------------------- forward
+constexpr int kDimFwdTile = 32;         // 32 x 32 outputs per workgroup, 4 per lane
+
+__global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int size, int resize, int rnd, int top, int left,
+                                                         int tiles_per_side) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
+    Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
+    for (int o = threadIdx.x; o < size; o += kBlock) t2[o] = make_tap(o, resize, size);
+    for (int o = threadIdx.x; o < rnd; o += kBlock) t1[o] = make_tap(o, size, rnd);
+    __syncthreads();
+
+    const int tiles = tiles_per_side * tiles_per_side;
+    const int64_t plane = blockIdx.x / tiles;
+    const int t = blockIdx.x % tiles;
+    const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
+    const float* xp = x + plane * static_cast<int64_t>(size) * size;
+    float* yp = y + plane * static_cast<int64_t>(size) * size;
+
+    // value of the zero-padded, rescaled image at (py, px)
+    auto padded = [&](int py, int px) -> float {
+        const int ry = py - top, rx = px - left;
+        if (ry < 0 || ry >= rnd || rx < 0 || rx >= rnd) return 0.0f;
+        const Tap ty = t1[ry], tx = t1[rx];
+        const float* r0 = xp + static_cast<int64_t>(ty.i0) * size;
+        const float* r1 = xp + static_cast<int64_t>(ty.i1) * size;
+        const float a = fmaf(tx.l0, r0[tx.i0], tx.l1 * r0[tx.i1]);
+        const float b = fmaf(tx.l0, r1[tx.i0], tx.l1 * r1[tx.i1]);
+        return fmaf(ty.l0, a, ty.l1 * b);
+    };
+
+#pragma unroll
+    for (int u = 0; u < kDimFwdTile * kDimFwdTile / kBlock; ++u) {
+        const int local = u * kBlock + threadIdx.x;
+        const int oy = oy0 + local / kDimFwdTile, ox = ox0 + local % kDimFwdTile;
+        if (oy >= size || ox >= size) continue;
+        const Tap ty = t2[oy], tx = t2[ox];
+        const float a = fmaf(tx.l0, padded(ty.i0, tx.i0), tx.l1 * padded(ty.i0, tx.i1));
+        const float b = fmaf(tx.l0, padded(ty.i1, tx.i0), tx.l1 * padded(ty.i1, tx.i1));
+        yp[static_cast<int64_t>(oy) * size + ox] = fmaf(ty.l0, a, ty.l1 * b);
+    }
+}
+
+// --------------------------------------------------------------------------------------- backward
+constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
+constexpr int kDimBwdMaxMid = 80;       // side of the LDS-resident window of d(rescaled); rate <= ~2.4
+
+struct Range {
+    int lo, hi;
+};
+
+__global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                         int size, int resize, int rnd, int top, int left,
+                                                         int tiles_per_side) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Tap* t2 = reinterpret_cast<Tap*>(smem_raw);                  // [size]    out pixel  -> padded index
+    Tap* t1 = t2 + size;                                         // [rnd]     rescaled   -> x index
+    Range* inv2 = reinterpret_cast<Range*>(t1 + rnd);            // [resize]  padded idx -> out pixels touching it
+    Range* inv1 = inv2 + resize;                                 // [size]    x index    -> rescaled pixels touching it
+    float* mid = reinterpret_cast<float*>(inv1 + size);          // [kDimBwdMaxMid^2] d(rescaled) window
+
+    for (int i = threadIdx.x; i < resize; i += kBlock) inv2[i] = Range{INT_MAX, -1};
+    for (int i = threadIdx.x; i < size; i += kBlock) inv1[i] = Range{INT_MAX, -1};
+    __syncthreads();
+    for (int o = threadIdx.x; o < size; o += kBlock) {
+        const Tap tp = make_tap(o, resize, size);
+        t2[o] = tp;
+        atomicMin(&inv2[tp.i0].lo, o);
+        atomicMax(&inv2[tp.i1].hi, o);        // i1 >= i0 and taps are monotone: [lo, hi] covers both taps
+        atomicMin(&inv2[tp.i1].lo, o);
+        atomicMax(&inv2[tp.i0].hi, o);
+    }
+    for (int o = threadIdx.x; o < rnd; o += kBlock) {
+        const Tap tp = make_tap(o, size, rnd);
+        t1[o] = tp;
+        atomicMin(&inv1[tp.i0].lo, o);
+        atomicMax(&inv1[tp.i1].hi, o);
+        atomicMin(&inv1[tp.i1].lo, o);
+        atomicMax(&inv1[tp.i0].hi, o);
+    }
+    __syncthreads();
+
+    const int tiles = tiles_per_side * tiles_per_side;
+    const int64_t plane = blockIdx.x / tiles;
+    const int t = blockIdx.x % tiles;
+    const int iy0 = (t / tiles_per_side) * kDimBwdTile, ix0 = (t % tiles_per_side) * kDimBwdTile;
+    const int iy1 = min(iy0 + kDimBwdTile, size) - 1, ix1 = min(ix0 + kDimBwdTile, size) - 1;
+    const float* gyp = gy + plane * static_cast<int64_t>(size) * size;
+    float* gxp = gx + plane * static_cast<int64_t>(size) * size;
+
+    // rescaled-pixel window [ry_lo, ry_hi] x [rx_lo, rx_hi] that feeds this tile of x (ranges are monotone)
+    int ry_lo = INT_MAX, ry_hi = -1, rx_lo = INT_MAX, rx_hi = -1;
+    for (int i = iy0; i <= iy1; ++i) { ry_lo = min(ry_lo, inv1[i].lo); ry_hi = max(ry_hi, inv1[i].hi); }
+    for (int i = ix0; i <= ix1; ++i) { rx_lo = min(rx_lo, inv1[i].lo); rx_hi = max(rx_hi, inv1[i].hi); }
+    const int mh = ry_hi - ry_lo + 1, mw = rx_hi - rx_lo + 1;     // <= kDimBwdMaxMid (checked on the host)
+
+    // stage A: d(rescaled)[ry][rx] = d(padded)[ry+top][rx+left] = gather over the outputs touching it
+    for (int idx = threadIdx.x; idx < mh * mw; idx += kBlock) {
+        const int ry = ry_lo + idx / mw, rx = rx_lo + idx % mw;
+        const int py = ry + top, px = rx + left;
+        const Range oy_r = inv2[py], ox_r = inv2[px];
+        float acc = 0.0f;
+        for (int oy = oy_r.lo; oy <= oy_r.hi; ++oy) {
+            const Tap ty = t2[oy];
+            const int ys[2] = {ty.i0, ty.i1};
+            const float ly[2] = {ty.l0, ty.l1};
+            for (int ox = ox_r.lo; ox <= ox_r.hi; ++ox) {
+                const Tap tx = t2[ox];
+                const int xs[2] = {tx.i0, tx.i1};
+                const float lx[2] = {tx.l0, tx.l1};
+                const float g = gyp[static_cast<int64_t>(oy) * size + ox];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (ys[a] == py && xs[b] == px) acc = fmaf(ly[a] * lx[b], g, acc);
+            }
+        }
+        mid[idx] = acc;
+    }
+    __syncthreads();
+
+    // stage B: gx[iy][ix] = gather over the rescaled pixels touching it
+#pragma unroll
+    for (int u = 0; u < kDimBwdTile * kDimBwdTile / kBlock; ++u) {
+        const int local = u * kBlock + threadIdx.x;
+        const int iy = iy0 + local / kDimBwdTile, ix = ix0 + local % kDimBwdTile;
+        if (iy >= size || ix >= size) continue;
+        const Range ry_r = inv1[iy], rx_r = inv1[ix];
+        float acc = 0.0f;
+        for (int ry = ry_r.lo; ry <= ry_r.hi; ++ry) {
+            const Tap ty = t1[ry];
+            const int ys[2] = {ty.i0, ty.i1};
+            const float ly[2] = {ty.l0, ty.l1};
+            for (int rx = rx_r.lo; rx <= rx_r.hi; ++rx) {
+                const Tap tx = t1[rx];
+                const int xs[2] = {tx.i0, tx.i1};
+                const float lx[2] = {tx.l0, tx.l1};
+                const float g = mid[(ry - ry_lo) * mw + (rx - rx_lo)];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (ys[a] == iy && xs[b] == ix) acc = fmaf(ly[a] * lx[b], g, acc);
+            }
+        }
+        gxp[static_cast<int64_t>(iy) * size + ix] = acc;
+    }
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+static int check_geom(int64_t planes, int size, int resize, int rnd, int top, int left) {
+    TA_REQUIRE(planes > 0 && size > 0 && size <= kDimMaxSide && resize <= kDimMaxSide, "bad shape");
+    TA_REQUIRE(rnd > 0 && rnd <= resize && top >= 0 && left >= 0 && top + rnd <= resize && left + rnd <= resize,
+               "geometry (rnd=%d, top=%d, left=%d) does not fit resize=%d", rnd, top, left, resize);
+    return 0;
+}
+
+extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top, int left,
+                          void* stream) {
+    TA_REQUIRE(x && y && x != y, "null or aliased pointers");
+    if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
+    const int tps = static_cast<int>(ceil_div(size, kDimFwdTile));
+    const int64_t blocks = planes * tps * tps;
+    TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
+    const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd);
+    hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
+                       static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps);
+    return check_launch("dim_fwd");
+}
+
+extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize, int rnd, int top, int left,
+                          void* stream) {
+    TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
+    if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
+    // a 32-pixel tile of x (plus one neighbour each side) is fed by at most this many rescaled pixels per axis
+    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimBwdTile + 2) * rnd, size)) + 3;
+    TA_REQUIRE(mid_side <= kDimBwdMaxMid, "resize ratio %d/%d too large for the fused backward", rnd, size);
+    const int tps = static_cast<int>(ceil_div(size, kDimBwdTile));
+    const int64_t blocks = planes * tps * tps;
+    TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
+    const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(Range) * (static_cast<size_t>(resize) + size) +
+                        sizeof(float) * kDimBwdMaxMid * kDimBwdMaxMid;
+    hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
+                       static_cast<hipStream_t>(stream), gy, gx, size, resize, rnd, top, left, tps);
+    return check_launch("dim_bwd");
+}

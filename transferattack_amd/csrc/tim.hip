@@ -1,0 +1,168 @@
+// TIM gradient smoothing for gfx950: depthwise k x k 'same' correlation of every (n,c) plane with one
+// kernel (reference: F.conv2d(grad, kernel, padding='same', groups=3), input_transformation/tim.py:72-74).
+//
+// Roofline: 8 B/element of HBM traffic but 2*k*k = 450 FLOP/element at k = 15 -> bound by the fp32
+// VALU, not by HBM.  The tap order is the row-major FMA chain of the reference's CPU
+// path (acc = fma(w[ky][kx], in[y+ky-7][x+kx-7], acc), zero padding included in the chain), so the
+// result is bit-identical to it.
+//
+// Tiling: one workgroup = 16 rows x 224 columns of one plane (224 = the image side the path is defined
+// on, utils.py:12; wider images take several column tiles).  The (16+k-1) x (224+k-1) input window is
+// staged in LDS once; each lane produces 14 consecutive outputs of one row, re-using a 14+k-1 register
+// window per kernel row (14 ds_read_b64 per 14*k FMAs).  The LDS row stride is == 32 (mod 64) dwords, the
+// only residue for which the 32 lanes of a ds_read_b64 group (16 column groups x 2 rows, 14-dword pitch)
+// fall on distinct bank pairs.  Weights are wave-uniform -> scalar loads.
+#include "ta_common.h"
+
+namespace ta {
+
+constexpr int kConvTH = 16;        // output rows per workgroup
+constexpr int kConvPT = 14;        // outputs per lane
+constexpr int kConvXG = 16;        // lanes across a row
+constexpr int kConvTW = kConvPT * kConvXG;   // 224
+
+constexpr int conv_lds_stride(int k) {
+    int s = kConvTW + k - 1;
+    while (s % 64 != 32) ++s;
+    return s;
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out,
+                                                             const float* __restrict__ w, int h, int wd,
+                                                             int tiles_x, int tiles_y) {
+    constexpr int LO = (K - 1) / 2;
+    constexpr int LW = kConvTW + K - 1;
+    constexpr int LH = kConvTH + K - 1;
+    constexpr int LS = conv_lds_stride(K);
+    __shared__ __attribute__((aligned(16))) float tile[LH * LS];
+
+    const int tiles = tiles_x * tiles_y;
+    const int64_t plane = blockIdx.x / tiles;
+    const int t = blockIdx.x % tiles;
+    const int y0 = (t / tiles_x) * kConvTH;
+    const int x0 = (t % tiles_x) * kConvTW;
+    const float* ip = in + plane * static_cast<int64_t>(h) * wd;
+
+    for (int idx = threadIdx.x; idx < LH * LW; idx += kBlock) {
+        const int r = idx / LW, c = idx - r * LW;
+        const int gy = y0 + r - LO, gx = x0 + c - LO;
+        float v = 0.0f;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < wd) v = ip[static_cast<int64_t>(gy) * wd + gx];
+        tile[r * LS + c] = v;
+    }
+    __syncthreads();
+
+    const int xg = threadIdx.x % kConvXG;
+    const int row = threadIdx.x / kConvXG;
+    float acc[kConvPT];
+#pragma unroll
+    for (int r = 0; r < kConvPT; ++r) acc[r] = 0.0f;
+
+#pragma unroll 1      // one kernel row at a time: 14 + k - 1 window registers, not k of them
+    for (int ky = 0; ky < K; ++ky) {
+        float win[kConvPT + K - 1 + 1];
+        const float2* lp = reinterpret_cast<const float2*>(&tile[(row + ky) * LS + xg * kConvPT]);
+#pragma unroll
+        for (int j = 0; j < (kConvPT + K) / 2; ++j) {
+            const float2 v = lp[j];
+            win[2 * j] = v.x;
+            win[2 * j + 1] = v.y;
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const float wv = w[ky * K + kx];
+#pragma unroll
+            for (int r = 0; r < kConvPT; ++r) acc[r] = fmaf(wv, win[r + kx], acc[r]);
+        }
+    }
+
+    const int oy = y0 + row;
+    if (oy < h) {
+        float* op = out + plane * static_cast<int64_t>(h) * wd + static_cast<int64_t>(oy) * wd;
+        const int ox = x0 + xg * kConvPT;
+#pragma unroll
+        for (int r = 0; r < kConvPT; ++r)
+            if (ox + r < wd) op[ox + r] = acc[r];
+    }
+}
+
+// any k <= 31: weights and window in dynamic LDS, runtime loops (fallback for unusual kernel sizes)
+__global__ __launch_bounds__(kBlock) void dwconv_same_generic_kernel(const float* __restrict__ in,
+                                                                     float* __restrict__ out,
+                                                                     const float* __restrict__ w, int k, int h,
+                                                                     int wd, int tiles_x, int tiles_y, int ls) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lo = (k - 1) / 2;
+    const int lw = kConvTW + k - 1, lh = kConvTH + k - 1;
+    float* tile = smem;
+    float* wl = smem + lh * ls;
+    const int tiles = tiles_x * tiles_y;
+    const int64_t plane = blockIdx.x / tiles;
+    const int t = blockIdx.x % tiles;
+    const int y0 = (t / tiles_x) * kConvTH;
+    const int x0 = (t % tiles_x) * kConvTW;
+    const float* ip = in + plane * static_cast<int64_t>(h) * wd;
+    for (int idx = threadIdx.x; idx < k * k; idx += kBlock) wl[idx] = w[idx];
+    for (int idx = threadIdx.x; idx < lh * lw; idx += kBlock) {
+        const int r = idx / lw, c = idx - r * lw;
+        const int gy = y0 + r - lo, gx = x0 + c - lo;
+        float v = 0.0f;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < wd) v = ip[static_cast<int64_t>(gy) * wd + gx];
+        tile[r * ls + c] = v;
+    }
+    __syncthreads();
+    const int xg = threadIdx.x % kConvXG;
+    const int row = threadIdx.x / kConvXG;
+    float acc[kConvPT];
+#pragma unroll
+    for (int r = 0; r < kConvPT; ++r) acc[r] = 0.0f;
+    for (int ky = 0; ky < k; ++ky) {
+        const float* lp = &tile[(row + ky) * ls + xg * kConvPT];
+        for (int kx = 0; kx < k; ++kx) {
+            const float wv = wl[ky * k + kx];
+#pragma unroll
+            for (int r = 0; r < kConvPT; ++r) acc[r] = fmaf(wv, lp[r + kx], acc[r]);
+        }
+    }
+    const int oy = y0 + row;
+    if (oy < h) {
+        float* op = out + plane * static_cast<int64_t>(h) * wd + static_cast<int64_t>(oy) * wd;
+        const int ox = x0 + xg * kConvPT;
+#pragma unroll
+        for (int r = 0; r < kConvPT; ++r)
+            if (ox + r < wd) op[ox + r] = acc[r];
+    }
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, int k, int64_t planes, int h,
+                                        int w_, void* stream) {
+    TA_REQUIRE(in && out && w && in != out, "null or aliased pointers");
+    TA_REQUIRE(k >= 1 && k <= 31 && planes > 0 && h > 0 && w_ > 0, "bad shape (k=%d)", k);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tiles_x = static_cast<int>(ceil_div(w_, kConvTW));
+    const int tiles_y = static_cast<int>(ceil_div(h, kConvTH));
+    const int64_t blocks = planes * tiles_x * tiles_y;
+    TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
+    const dim3 grid(static_cast<unsigned>(blocks));
+    switch (k) {
+#define TA_CONV(KK)                                                                                             \
+    case KK:                                                                                                    \
+        hipLaunchKernelGGL(dwconv_same_kernel<KK>, grid, dim3(kBlock), 0, st, in, out, w, h, w_, tiles_x, tiles_y); \
+        break;
+        TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
+#undef TA_CONV
+        default: {
+            const int ls = conv_lds_stride(k);
+            const size_t smem = sizeof(float) * (static_cast<size_t>(kConvTH + k - 1) * ls + k * k);
+            hipLaunchKernelGGL(dwconv_same_generic_kernel, grid, dim3(kBlock), smem, st, in, out, w, k, h, w_, tiles_x,
+                               tiles_y, ls);
+        }
+    }
+    return check_launch("depthwise_conv2d_same");
+}

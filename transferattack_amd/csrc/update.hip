@@ -11,29 +11,9 @@
 // Arithmetic is kept in the reference's order with contraction off (-ffp-contract=off):
 //   q = g / (sum|g| / E);  m' = m*decay + q;  d' = d + alpha*sign(m');  d' = min(max(d',-eps),eps);
 //   d' = min(max(d', 0 - x), 1 - x)
-#include "ta_common.h"
+#include "update_common.h"
 
 namespace ta {
-
-template <int VEC> struct Pack;
-template <> struct Pack<4> {
-    float4 v;
-    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
-    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
-    __device__ __forceinline__ float& operator[](int i) { return (&v.x)[i]; }
-    __device__ __forceinline__ float operator[](int i) const { return (&v.x)[i]; }
-};
-template <> struct Pack<1> {
-    float v;
-    __device__ __forceinline__ void load(const float* p) { v = *p; }
-    __device__ __forceinline__ void store(float* p) const { *p = v; }
-    __device__ __forceinline__ float& operator[](int) { return v; }
-    __device__ __forceinline__ float operator[](int) const { return v; }
-};
-
-// Per-thread slot layout of a tile: slot u (0..SLOTS-1) of thread t starts at element
-// (u*kBlock + t)*VEC of the tile; SLOTS*VEC*kBlock == kTile.
-template <int VEC> struct Slots { static constexpr int n = kTile / (kBlock * VEC); };
 
 // ------------------------------------------------------------------------------------------------
 // K1
@@ -81,27 +61,9 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
     if (threadIdx.x == 0) ws[img * tiles + blockIdx.x] = total;
 }
 
-// sum of an image's tile partials, identical in every lane of every wave (fixed order)
-__device__ __forceinline__ float image_total(const float* __restrict__ ws, int64_t img, int tiles) {
-    const int lane = threadIdx.x & 63;
-    float t = 0.0f;
-    for (int i = lane; i < tiles; i += kWave) t += ws[img * tiles + i];
-    return wave_sum(t);
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2 (fused) and the two hook-level halves
 // ------------------------------------------------------------------------------------------------
-struct StepParams {
-    float decay, alpha, neg_eps, eps;
-};
-
-__device__ __forceinline__ float project(float d, float x, float neg_eps, float eps) {
-    d = fminf(fmaxf(d, neg_eps), eps);          // torch.clamp(., -eps, eps)   attack.py:147
-    d = fmaxf(d, 0.0f - x);                      // clamp(., img_min - x, .)    utils.py:68-69
-    return fminf(d, 1.0f - x);                   // clamp(., ., img_max - x)
-}
-
 template <int VEC, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
 __global__ __launch_bounds__(kBlock) void mi_update_kernel(
     const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out,

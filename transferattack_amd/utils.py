@@ -1,0 +1,200 @@
+"""Host-side utilities of the hot path, mirroring ``transferattack/utils.py`` of the reference:
+constants (:12-13), model-name lists (:15-27), ``wrap_model`` / ``PreprocessingModel`` (:37-60, :72-79),
+``EnsembleModel`` (:82-105), ``clamp`` (:68-69), ``save_images`` (:63-66) and ``AdvDataset`` (:108-153).
+
+Differences that matter on MI355X: surrogates come from ``transferattack_amd.backbones`` (no
+torchvision / timm here), tensors live on a HIP device, and ``save_images`` quantises on the GPU
+(``ta_quantize_u8_nhwc``: (x+d)*255 truncated, NCHW -> NHWC) so only uint8 crosses PCIe.
+"""
+import csv
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _hip, backbones
+
+img_height, img_width = 224, 224
+img_max, img_min = 1., 0
+
+cnn_model_paper = ['resnet50', 'vgg16', 'mobilenet_v2', 'inception_v3']
+vit_model_paper = ['vit_base_patch16_224', 'pit_b_224', 'visformer_small', 'swin_tiny_patch4_window7_224']
+cnn_model_pkg = ['vgg19', 'resnet18', 'resnet101', 'resnext50_32x4d', 'densenet121', 'mobilenet_v2']
+vit_model_pkg = ['vit_base_patch16_224', 'pit_b_224', 'cait_s24_224', 'visformer_small', 'tnt_s_patch16_224',
+                 'levit_256', 'convit_base', 'swin_tiny_patch4_window7_224']
+generation_target_classes = [24, 99, 245, 344, 471, 555, 661, 701, 802, 919]
+
+
+def default_device():
+    """The HIP device this process drives (one process per GPU: LOCAL_RANK picks it)."""
+    if not torch.cuda.is_available():
+        raise _hip.HipExtensionError("no HIP device visible: the attack path runs on MI355X only (no CPU fallback)")
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
+
+
+def load_pretrained_model(cnn_model=(), vit_model=()):
+    """(name, backbone) pairs for the eval step (utils.py:29-34); names without a local definition are
+    skipped with a note instead of being downloaded."""
+    for name in list(cnn_model) + list(vit_model):
+        if name in backbones.available():
+            yield name, backbones.create(name)
+        else:
+            print('=> Skipping victim {}: no local definition (reference pulls it from torchvision/timm)'.format(name))
+
+
+class _Resize(nn.Module):
+    """torchvision.transforms.Resize(int) on a square NCHW batch: identity at that side, else bilinear."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size = size
+
+    def forward(self, x):
+        if x.shape[-1] == self.size and x.shape[-2] == self.size:
+            return x
+        return F.interpolate(x, size=(self.size, self.size), mode="bilinear", align_corners=False)
+
+
+class _Normalize(nn.Module):
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(list(mean), dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor(list(std), dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
+
+    def forward(self, x):
+        return (x - self.mean) / self.std
+
+
+class PreprocessingModel(nn.Module):
+    """normalize(resize(x)) in front of the backbone -- utils.py:72-79."""
+
+    def __init__(self, resize, mean, std):
+        super().__init__()
+        self.resize = _Resize(resize)
+        self.normalize = _Normalize(mean, std)
+
+    def forward(self, x):
+        return self.normalize(self.resize(x))
+
+
+def wrap_model(model):
+    """nn.Sequential(PreprocessingModel, model) with the statistics chosen as utils.py:37-60 does:
+    timm-style ``default_cfg`` mean/std, Inception 299 px + 0.5/0.5, otherwise ImageNet statistics.
+    Kept a Sequential so ``self.model[1]`` and module names like '1.layer1.1' keep working."""
+    resize = 224
+    if hasattr(model, 'default_cfg'):
+        mean, std = model.default_cfg['mean'], model.default_cfg['std']
+    elif 'Inc' in model.__class__.__name__:
+        mean, std, resize = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], 299
+    else:
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    pre = PreprocessingModel(resize, mean, std)
+    try:
+        pre = pre.to(next(model.parameters()).device)
+    except StopIteration:
+        pass
+    return nn.Sequential(pre, model)
+
+
+def clamp(x, x_min, x_max):
+    return torch.min(torch.max(x, x_min), x_max)
+
+
+def quantize_images(images, perturbations):
+    """uint8 NHWC array of floor((x + d) * 255) computed on the GPU (utils.py:64 + the add of main.py:53)."""
+    dev = perturbations.device if perturbations.is_cuda else default_device()
+    x = images.to(dev, torch.float32).contiguous()
+    d = perturbations.to(dev, torch.float32).contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=dev)
+    _hip.quantize_u8_nhwc(x, d, out)
+    return out.cpu().numpy()
+
+
+def save_images(output_dir, adversaries, filenames, perturbations=None):
+    """Write PNGs.  Reference signature ``save_images(output_dir, images + perturbations.cpu(), filenames)``
+    (utils.py:63-66) is kept; passing ``perturbations`` separately lets the add + quantisation run fused on
+    the GPU."""
+    from PIL import Image
+    if perturbations is None:
+        perturbations = torch.zeros_like(adversaries)
+    arr = quantize_images(adversaries, perturbations)
+    for i, filename in enumerate(filenames):
+        Image.fromarray(arr[i]).save(os.path.join(output_dir, filename))
+
+
+class EnsembleModel(nn.Module):
+    """Several wrapped surrogates evaluated on the same input; 'mean' averages logits, 'ind' stacks them
+    (utils.py:82-105).  ``models`` stays a plain list (attacks index ``self.model.models[k]``)."""
+
+    def __init__(self, models, mode='mean'):
+        super().__init__()
+        self.device = next(models[0].parameters()).device
+        for model in models:
+            model.to(self.device)
+        self.models = models
+        self.softmax = nn.Softmax(dim=1)
+        self.type_name = 'ensemble'
+        self.num_models = len(models)
+        self.mode = mode
+
+    def forward(self, x):
+        outputs = torch.stack([model(x) for model in self.models], dim=0)
+        if self.mode == 'mean':
+            return torch.mean(outputs, dim=0)
+        if self.mode == 'ind':
+            return outputs
+        raise NotImplementedError
+
+    def eval(self):
+        for model in self.models:
+            model.eval()
+        return super().eval()
+
+    def parameters(self, recurse=True):
+        for model in self.models:
+            yield from model.parameters(recurse)
+
+
+class AdvDataset(torch.utils.data.Dataset):
+    """<input_dir>/labels.csv + <input_dir>/images/*.png -> (fp32 CHW in [0,1], label, filename)
+    (utils.py:108-153).  In eval mode images are read back from ``output_dir``."""
+
+    def __init__(self, input_dir=None, output_dir=None, targeted=False, target_class=None, eval=False):
+        self.targeted = targeted
+        self.target_class = target_class
+        self.data_dir = input_dir
+        self.f2l = self.load_labels(os.path.join(self.data_dir, 'labels.csv'))
+        self.filenames = list(self.f2l.keys())
+        if eval:
+            self.data_dir = output_dir
+            print('=> Eval mode: evaluating on {}'.format(self.data_dir))
+        else:
+            self.data_dir = os.path.join(self.data_dir, 'images')
+            print('=> Train mode: training on {}'.format(self.data_dir))
+            print('Save images to {}'.format(output_dir))
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        filename = self.filenames[idx]
+        image = Image.open(os.path.join(self.data_dir, filename))
+        image = image.resize((img_height, img_width)).convert('RGB')
+        image = torch.from_numpy(np.array(image).astype(np.float32) / 255).permute(2, 0, 1)
+        return image, self.f2l[filename], filename
+
+    def load_labels(self, file_name):
+        f2l = {}
+        with open(file_name, newline='') as fh:
+            for row in csv.DictReader(fh):
+                label = int(row['label'])
+                if self.targeted:
+                    tgt = self.target_class if self.target_class else int(row['targeted_label'])
+                    f2l[row['filename']] = [label, tgt]
+                else:
+                    f2l[row['filename']] = label
+        return f2l
