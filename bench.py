@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the FGSM-family hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (BASELINE.json configs[1]): MI-FGSM on ResNet-50, eps=16/255, alpha=1.6/255, K=10 iterations,
+synthetic 3x224x224 images in the reference's batches of 32 (main.py:15).  One "step" = one batch through
+``attacker(images, labels)`` = 10 x (surrogate forward + input-gradient backward + fused HIP update).
+Inputs are resident in HBM before the timed region; the surrogate is the ResNet-50 architecture with seeded
+random weights (no checkpoints offline); arithmetic is fp32 throughout, as in the reference.
+
+Multi-GPU: the 1000-image job shards by whole batches, no data-path collective: every rank runs
+its own K steps ("weak" scaling); value = images of all ranks / max-over-ranks time.
+
+One JSON line on rank 0, with
+  roofline      the fused momentum-sign-project update (ta_mi_update): algorithmic bytes 24 B/element
+                (read g, m, delta, x; write m, delta) x E x N per launch / mean launch duration measured with
+                HIP events on the launch stream inside the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores,
+                same surrogate / workload, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (6290 GB/s measured float4 copy)
+BYTES_PER_ELEM = 24            # fused update: r g,m,d,x  w m,d
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--attack", default="mifgsm")
+    p.add_argument("--model", default="resnet50")
+    p.add_argument("--batch", type=int, default=32, help="images per step (reference batch: 32)")
+    p.add_argument("--single-launch", type=int, default=int(os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0")))
+    p.add_argument("--cpu-images", type=int, default=8, help="images of the CPU-baseline sample (0 = skip)")
+    p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
+    return p.parse_args()
+
+
+def synthetic_batch(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255
+    y = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(seed + 1))
+    return x, y
+
+
+def kernel_sweep(single_flags=(0, 1), sizes=(32, 125, 250), reps=30):
+    """Stand-alone timing of the fused update at several batch sizes (operands rotate through 4 buffer sets,
+    ~0.3-2.4 GB, so the 256 MiB Infinity Cache cannot hold them)."""
+    from transferattack_amd import _hip
+    out = {}
+    e = 3 * 224 * 224
+    for n in sizes:
+        sets = []
+        for k in range(4):
+            g = torch.randn(n, 3, 224, 224, device="cuda") * 1e-4
+            sets.append((g, torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g)))
+        for single in single_flags:
+            for i in range(5):
+                g, m, d, x = sets[i % 4]
+                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, single_launch=bool(single))
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            start.record()
+            for i in range(reps):
+                g, m, d, x = sets[i % 4]
+                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, single_launch=bool(single))
+            end.record()
+            torch.cuda.synchronize()
+            us = start.elapsed_time(end) * 1e3 / reps
+            out["n%d_%s" % (n, "single" if single else "two")] = {
+                "us": round(us, 2), "GBps": round(BYTES_PER_ELEM * e * n / us / 1e3, 1)}
+        del sets
+    return out
+
+
+def cpu_baseline(args):
+    """Oracle = reference CPU arithmetic, timed on this host's cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fgsm_oracle as O
+    from transferattack_amd import backbones
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = backbones.create(args.model, seed=0, verbose=False)
+    x, y = synthetic_batch(args.cpu_images, 0)
+    O.run_attack(args.attack, model, x[:1], y[:1], epoch=1)            # warm the thread pool / oneDNN primitives
+    t0 = time.time()
+    O.run_attack(args.attack, model, x, y)
+    dt = time.time() - t0
+    # update stack alone (get_momentum + update_delta), reference op string, N = 32
+    n = 32
+    g = torch.randn(n, 3, 224, 224)
+    m, d, xx = torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g)
+    for _ in range(2):
+        mm = O.momentum_step(g, m, 1.0)
+        O.delta_step(d, xx, mm, 1.6 / 255, 16 / 255)
+    t1 = time.time()
+    for _ in range(5):
+        mm = O.momentum_step(g, m, 1.0)
+        O.delta_step(d, xx, mm, 1.6 / 255, 16 / 255)
+    upd_ms = (time.time() - t1) / 5 * 1e3
+    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic images, %s on %s, K=10, torch %d threads (oracle/fgsm_oracle.py)" % (
+                args.cpu_images, args.attack, args.model, cores),
+            "update_stack_ms_n32": round(upd_ms, 3),
+            "update_stack_GBps_n32": round(BYTES_PER_ELEM * 150528 * n / upd_ms / 1e6, 2)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import transferattack_amd as ta
+    from transferattack_amd import _hip
+    from transferattack_amd.attack import Attack
+    _hip.load()
+    torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
+    Attack.single_launch_update = bool(args.single_launch)
+    attacker = ta.load_attack_class(args.attack)(model_name=args.model)
+    dev = attacker.device
+
+    total = args.steps + args.warmup
+    batches = [tuple(t.to(dev) for t in synthetic_batch(args.batch, 1000 * rank + 2 * i)) for i in range(min(total, 4))]
+
+    def step(i):
+        x, y = batches[i % len(batches)]
+        return attacker(x, y)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _hip.profile_sink = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sink, _hip.profile_sink = _hip.profile_sink, None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        images = args.steps * args.batch * world
+        durs_us = [s.elapsed_time(e) * 1e3 for s, e, _, _ in sink]
+        n_, e_ = sink[0][2], sink[0][3]
+        mean_us = sum(durs_us) / len(durs_us)
+        achieved = BYTES_PER_ELEM * e_ * n_ / mean_us / 1e3          # GB/s
+        result = {
+            "metric": "adversarial images/sec (1000-img set, K=10)",
+            "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: MI-FGSM on ResNet-50 (seeded random init), eps=16/255, alpha=1.6/255, "
+                                   "K=10, synthetic 3x224x224, batches of %d, image-sharded over %d GPU(s)"
+                                   % (args.batch, world),
+                       "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
+                       "update_path": "single-launch" if args.single_launch else "two-launch",
+                       "parallelism": "image-shard x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "ta_mi_update (abs_sum_partials + mi_update)" if not args.single_launch
+                         else "ta_mi_update_fused", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
+                         "algorithmic_bytes_per_launch": BYTES_PER_ELEM * e_ * n_,
+                         "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
+        }
+        if args.kernel_sweep and world == 1:
+            result["config"]["update_kernel_sweep"] = kernel_sweep()
+        if args.cpu_images > 0 and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

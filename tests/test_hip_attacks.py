@@ -1,0 +1,166 @@
+"""GPU (-m gpu): loop-level parity of the product's attack classes running on MI355X.
+
+Two tiers:
+  * identical gradient source -> bit-exact: the oracle's per-iteration gradients (CPU, reference arithmetic) are
+    replayed through the HIP update kernels; every iterate and the final uint8 images must equal the
+    reference's golden output (BASELINE.json configs[0]: I-FGSM / ResNet-18 / 16 images / K=10).
+  * end to end (GPU surrogate forward/backward, MIOpen/rocBLAS rounding): fp32 input-gradients within 1e-5
+    (relative to max|g|) of the CPU path, uint8 mismatch rate and attack-success-rate reported and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+import fgsm_oracle as O
+import transferattack_amd as ta
+from conftest import u8_images
+from transferattack_amd import _hip, backbones
+from transferattack_amd.utils import EnsembleModel, quantize_images, wrap_model
+
+pytestmark = pytest.mark.gpu
+EPS, ALPHA = 16 / 255, 1.6 / 255
+DEV = "cuda"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def make(name, models=None, **kw):
+    base = ta.load_attack_class(name)
+    models = models or [backbones.create("toy_cnn", seed=3, verbose=False)]
+
+    def load_model(self, model_name):
+        wrapped = [wrap_model(m.eval().to(DEV)) for m in models]
+        return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
+
+    cls = type("Gpu" + base.__name__, (base,), {"load_model": load_model})
+    atk = cls(model_name="injected", **kw)
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)      # reference's CPU draws
+    return atk
+
+
+def test_config1_trajectory_replay(golden):
+    """configs[0] with the oracle's gradients fed to the HIP update path: bit-exact iterates and final uint8."""
+    g = golden("config1_ifgsm_resnet18")
+    xu8 = u8_images(16, 224, int(g["seed_images"]))
+    x = xu8.float() / 255
+    model = backbones.create("resnet18", seed=int(g["seed_weights"]), verbose=False)
+    trace = []
+    delta_ref = O.run_attack("ifgsm", model, x, t(g["label"]), trace=trace)
+    assert np.array_equal(O.quantize_u8(x + delta_ref), g["adv_u8"])          # the oracle on this host == reference
+    xd = x.to(DEV)
+    d = torch.zeros_like(xd)
+    m = None
+    for it, rec in enumerate(trace):
+        m_out = torch.empty_like(xd)
+        _hip.mi_update(rec["grad"].to(DEV), m, m_out, d, xd, 0.0, ALPHA, EPS, single_launch=bool(it % 2))
+        m = m_out
+        assert torch.equal(d.cpu(), rec["delta"]), "iterate %d differs" % it
+    out = torch.empty((16, 224, 224, 3), dtype=torch.uint8, device=DEV)
+    _hip.quantize_u8_nhwc(xd, d, out)
+    assert np.array_equal(out.cpu().numpy(), g["adv_u8"])                     # final uint8 bit-exact vs reference
+
+
+@pytest.mark.parametrize("name", ["mifgsm", "tim", "sim", "admix", "dim", "dts", "nifgsm"])
+def test_trajectory_replay_transforms(golden, name):
+    """Same tier for the transform attacks on the toy surrogate: the product runs on the GPU with its HIP
+    transforms, but every iteration's gradient is checked against / replaced by the oracle's so that rounding
+    differences of the surrogate cannot accumulate; the final delta equals the reference's golden delta."""
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    trace = []
+    torch.manual_seed(1234)
+    O.run_attack(name, model, x, label, trace=trace)
+    atk = make(name)
+    worst = [0.0]
+    it = [0]
+    orig_get_grad = type(atk).get_grad
+
+    def get_grad(self, loss, delta, **kw):
+        gpu = orig_get_grad(self, loss, delta, **kw)
+        ref = trace[it[0]]["grad"]
+        worst[0] = max(worst[0], float((gpu.cpu() - ref).abs().max() / ref.abs().max()))
+        it[0] += 1
+        return ref.to(DEV)
+
+    type(atk).get_grad = get_grad
+    torch.manual_seed(1234)
+    delta = atk(x, label)
+    assert worst[0] <= 1e-5, "fp32 input-gradient deviates by %.2e of max|g|" % worst[0]
+    assert np.array_equal(delta.cpu().numpy(), g["delta_" + name])
+
+
+@pytest.mark.parametrize("name", ["fgsm", "ifgsm", "mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim",
+                                  "admix", "dts", "ens"])
+def test_end_to_end_gpu_vs_reference(golden, name):
+    """Whole loop on the GPU (surrogate included) against the reference's golden result: invariants hold, the
+    uint8 images agree up to the few pixels whose gradient sign is decided by the last bits of the surrogate's
+    arithmetic, and the attack success rate on the surrogate is the same."""
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False)]
+    if name == "ens":
+        models.append(backbones.create("toy_cnn", seed=4, verbose=False))
+    atk = make(name, models)
+    torch.manual_seed(1234)
+    delta = atk(x, label).cpu()
+    ref = t(g["delta_" + name])
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    adv = x + delta
+    assert float(adv.min()) >= 0.0 and float(adv.max()) <= 1.0 + 1e-7
+    u8_gpu = quantize_images(x, delta)
+    u8_ref = O.quantize_u8(x + ref)
+    mismatch = float((u8_gpu != u8_ref).mean())
+    print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
+    assert mismatch <= 0.03
+    victim = O.logits_of(models if name == "ens" else models[0].cpu(), t(u8_gpu).permute(0, 3, 1, 2).float() / 255)
+    victim_ref = O.logits_of(models if name == "ens" else models[0].cpu(), t(u8_ref).permute(0, 3, 1, 2).float() / 255)
+    asr_gpu = float((victim.argmax(1) != label).float().mean())
+    asr_ref = float((victim_ref.argmax(1) != label).float().mean())
+    assert asr_gpu == asr_ref
+
+
+def test_variants_run_on_gpu(golden):
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    d = make("mifgsm", targeted=True)(x, [label, t(g["target"])])
+    assert float(d.abs().max()) <= EPS + 1e-7
+    atk = make("mifgsm", random_start=True)
+    atk.noise_source = None                                               # in-kernel Philox random start
+    d1 = atk(x, label)
+    atk2 = make("mifgsm", random_start=True)
+    atk2.noise_source = None
+    assert torch.equal(d1, atk2(x, label))                                # same seed, same offset -> same stream
+    atk = make("vmifgsm", num_neighbor=3, epoch=2)
+    atk.noise_source = None
+    assert float(atk(x, label).abs().max()) <= EPS + 1e-7
+    atk = make("mifgsm", norm="l2", epsilon=3.0, alpha=0.3)
+    d = atk(x, label)
+    assert float(d.flatten(1).norm(dim=1).max()) <= 3.0 * (1 + 1e-5)
+
+
+def test_resnet50_gradients_gpu_vs_cpu():
+    """fp32 input-gradient of the BASELINE surrogate on MI355X vs the CPU path, one iteration, 4 images."""
+    x = u8_images(4, 224, 5).float() / 255
+    label = torch.randint(0, 1000, (4,), generator=torch.Generator().manual_seed(6))
+    model = backbones.create("resnet50", seed=0, verbose=False)
+    trace = []
+    O.run_attack("mifgsm", model, x, label, trace=trace, epoch=1)
+    atk = make("mifgsm", [model])
+    grads = []
+    orig = type(atk).get_grad
+
+    def get_grad(self, loss, delta, **kw):
+        grads.append(orig(self, loss, delta, **kw))
+        return grads[-1]
+
+    type(atk).get_grad = get_grad
+    atk.epoch = 1
+    atk(x, label)
+    ref = trace[0]["grad"]
+    dev_rel = float((grads[0].cpu() - ref).abs().max() / ref.abs().max())
+    sign_flip = float((torch.sign(grads[0].cpu()) != torch.sign(ref)).float().mean())
+    print("resnet50 grad: max deviation %.3e of max|g|, sign flips %.5f%%" % (dev_rel, 100 * sign_flip))
+    assert dev_rel <= 1e-4 and sign_flip <= 0.01

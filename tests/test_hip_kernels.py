@@ -1,0 +1,318 @@
+"""GPU (-m gpu): the HIP kernels, called through the C-ABI (ctypes binding), against
+  (a) the golden vectors produced by the REAL reference (tests/golden, oracle/gen_golden.py),
+  (b) the plain-C oracle (oracle/ta_oracle.c) and the torch-CPU oracle (oracle/fgsm_oracle.py) on seeded inputs.
+
+Tolerances (written out, per BASELINE.json north_star: fp32 within 1e-5, final uint8 bit-exact):
+  * delta / uint8 / TIM / DIM fwd+bwd / SIM / Admix / quantiser / Philox stream: BIT-EXACT.
+  * momentum: the per-image sum|g| is added in a different (fixed) order than ATen's AVX2 cascade, so the
+    mean can differ in its last bits -> momentum within 4 ulp; the *sign* (all that reaches delta) can then
+    differ only where |m'| is itself within rounding of zero: such elements are counted and must be
+    < 1e-6 of all elements with |m'| < 1e-5 (none observed).
+  * DIM forward vs the torch op: <= 2 ulp (ATen's own result depends on its work partitioning); vs the C
+    oracle (same recipe): bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle as C
+import fgsm_oracle as O
+from conftest import ulp_diff
+from transferattack_amd import _hip
+
+pytestmark = pytest.mark.gpu
+EPS, ALPHA = 16 / 255, 1.6 / 255
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV).contiguous()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_delta_equal(d_hip, d_ref, m_ref):
+    """bit-exact, except where the reference momentum is within rounding of zero (see module docstring)."""
+    d_hip, d_ref, m_ref = np.asarray(d_hip), np.asarray(d_ref), np.asarray(m_ref)
+    bad = d_hip != d_ref
+    if bad.any():
+        assert (np.abs(m_ref[bad]) < 1e-5).all(), "delta differs where the momentum sign is unambiguous"
+        assert bad.sum() <= max(1, int(1e-6 * bad.size)), "too many sign flips: %d" % bad.sum()
+
+
+# ------------------------------------------------------------------------------------------ update stack
+@pytest.mark.parametrize("tag,decay,first", [("first", 1.0, True), ("d1", 1.0, False), ("d09", 0.9, False),
+                                             ("d0", 0.0, False)])
+def test_update_stack_golden(golden, tag, decay, first):
+    g = golden("update_stack")
+    grad, mom, delta, x = dev(g["grad"]), dev(g["momentum"]), dev(g["delta"]), dev(g["x"])
+    # hook-level kernels
+    m_out = torch.empty_like(grad)
+    _hip.momentum(grad, None if first else mom, m_out, decay)
+    assert ulp_diff(host(m_out), g["m_" + tag]) <= 4
+    assert np.isnan(host(m_out)[2]).all()                               # zero-gradient image: NaN momentum
+    d_out = torch.empty_like(delta)
+    _hip.update_delta_linf(delta, x, dev(g["m_" + tag]), ALPHA, EPS, d_out)
+    assert np.array_equal(host(d_out), g["delta_" + tag])               # same momentum in -> same bytes out
+    # fused path, two-launch and single-launch: identical to each other, and to the reference
+    outs = []
+    for single in (False, True):
+        d = delta.clone()
+        m = torch.empty_like(grad)
+        _hip.mi_update(grad, None if first else mom.clone(), m, d, x, decay, ALPHA, EPS, single_launch=single)
+        if single:
+            _hip.fused_sync_check(grad, grad.shape[0], grad[0].numel())
+        assert ulp_diff(host(m), g["m_" + tag]) <= 4
+        assert_delta_equal(host(d), g["delta_" + tag], g["m_" + tag])
+        assert np.array_equal(host(d)[2], g["delta"][2])                # NaN momentum -> frozen delta
+        outs.append((host(m), host(d)))
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_update_delta_variants_golden(golden):
+    g = golden("update_stack")
+    delta, x, m = dev(g["delta"]), dev(g["x"]), dev(g["m_d1"])
+    out = torch.empty_like(delta)
+    _hip.update_delta_linf(delta, x, m, dev(g["alpha_t"]), EPS, out)            # tensor step (gra.py:149)
+    assert np.array_equal(host(out), g["delta_alpha_t"])
+    _hip.update_delta_linf(delta, x, m, -ALPHA, EPS, out)                       # negative step (cwa.py:69)
+    assert np.array_equal(host(out), g["delta_alpha_neg"])
+    xadv = torch.empty_like(delta)
+    _hip.update_delta_linf(delta, x, m, ALPHA, EPS, out, x_adv=xadv)
+    assert np.array_equal(host(xadv), g["x"] + g["delta_d1"])
+    _hip.update_delta_l2(delta, x, dev(g["grad"] + np.float32(1e-5)), ALPHA, EPS, out)     # attack.py:148-151
+    np.testing.assert_allclose(host(out), g["delta_l2"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (3, 3, 299, 299), (2, 1, 1, 7)])
+@pytest.mark.parametrize("single", [False, True])
+def test_fused_update_random(shape, single):
+    """BASELINE sizes and ragged ones (E not a multiple of 4, E < one tile, N = 1) against the torch oracle."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(0, 256, shape, generator=gen).float() / 255
+    grad = torch.randn(shape, generator=gen) * 1e-4
+    grad[torch.rand(shape, generator=gen) < 0.01] = 0
+    mom = torch.randn(shape, generator=gen)
+    var = torch.randn(shape, generator=gen) * 1e-5
+    delta = O.box_clamp((torch.randint(-10, 11, shape, generator=gen).float() * ALPHA).clamp(-EPS, EPS), 0 - x, 1 - x)
+    for decay, use_var in ((1.0, False), (0.9, True)):
+        gsum = grad + var if use_var else grad
+        m_ref = O.momentum_step(gsum, mom, decay)
+        d_ref = O.delta_step(delta, x, m_ref, ALPHA, EPS)
+        d, m, xa = delta.to(DEV), mom.to(DEV), torch.empty(shape, device=DEV)
+        _hip.mi_update(grad.to(DEV), m, m, d, x.to(DEV), decay, ALPHA, EPS,
+                       variance=var.to(DEV) if use_var else None, x_adv=xa, single_launch=single)
+        if single:
+            _hip.fused_sync_check(d, shape[0], d[0].numel())
+        assert ulp_diff(host(m), m_ref.numpy()) <= 4
+        assert_delta_equal(host(d), d_ref.numpy(), m_ref.numpy())
+        assert np.array_equal(host(xa), host(x.to(DEV) + d))
+        # plain-C oracle says the same
+        assert_delta_equal(host(d), C.update_delta_linf(delta.numpy(), x.numpy(), m_ref.numpy(), ALPHA, EPS),
+                           m_ref.numpy())
+
+
+def test_single_launch_repeats_and_interleaves():
+    """The in-kernel exchange re-arms itself: many launches on the same sync buffer, different batches."""
+    gen = torch.Generator().manual_seed(0)
+    for shape in ((32, 3, 224, 224), (7, 3, 224, 224), (32, 3, 224, 224)):
+        x = torch.rand(shape, generator=gen).to(DEV)
+        grad = torch.randn(shape, generator=gen).to(DEV)
+        d1, d2 = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+        m1, m2 = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+        for it in range(12):
+            _hip.mi_update(grad, m1, m1, d1, x, 1.0, ALPHA, EPS, single_launch=False)
+            _hip.mi_update(grad, m2, m2, d2, x, 1.0, ALPHA, EPS, single_launch=True)
+            grad = grad.roll(1, 0) * 1.01
+        _hip.fused_sync_check(x, shape[0], x[0].numel())
+        assert torch.equal(d1, d2) and torch.equal(m1, m2)
+
+
+def test_fused_update_under_graph_capture():
+    shape = (8, 3, 224, 224)
+    x, grad = torch.rand(shape, device=DEV), torch.randn(shape, device=DEV)
+    d, m = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+    d_ref, m_ref = d.clone(), m.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _hip.mi_update(grad, m, m, d, x, 1.0, ALPHA, EPS)          # warm-up on the side stream (allocates scratch)
+    torch.cuda.current_stream().wait_stream(s)
+    d.zero_(); m.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        _hip.mi_update(grad, m, m, d, x, 1.0, ALPHA, EPS)
+    d.zero_(); m.zero_()
+    for _ in range(3):
+        graph.replay()
+        _hip.mi_update(grad, m_ref, m_ref, d_ref, x, 1.0, ALPHA, EPS)
+    torch.cuda.synchronize()
+    assert torch.equal(d, d_ref) and torch.equal(m, m_ref)
+
+
+def test_quantiser(golden):
+    g = golden("update_stack")
+    x, d = dev(g["x"]), dev(g["delta_d1"])
+    out = torch.empty((3, 64, 64, 3), dtype=torch.uint8, device=DEV)
+    _hip.quantize_u8_nhwc(x, d, out)
+    assert np.array_equal(host(out), g["u8_d1"])
+    gen = torch.Generator().manual_seed(3)
+    for shape in ((4, 3, 224, 224), (2, 3, 5, 7), (2, 1, 9, 9)):
+        x = torch.randint(0, 256, shape, generator=gen).float() / 255
+        d = O.box_clamp((torch.rand(shape, generator=gen) - 0.5) * 2 * EPS, 0 - x, 1 - x)
+        out = torch.empty((shape[0], shape[2], shape[3], shape[1]), dtype=torch.uint8, device=DEV)
+        _hip.quantize_u8_nhwc(x.to(DEV), d.to(DEV), out)
+        assert np.array_equal(host(out), O.quantize_u8(x + d))
+        assert np.array_equal(host(out), C.quantize_u8_nhwc(x.numpy(), d.numpy()))
+
+
+# --------------------------------------------------------------------------------------------------- TIM
+def test_tim_golden(golden):
+    g = golden("tim")
+    out = torch.empty(g["grad_in"].shape, device=DEV)
+    _hip.depthwise_conv2d_same(dev(g["grad_in"]), out, dev(g["kernel_gaussian"][0, 0]))
+    assert np.array_equal(host(out), g["grad_out"])
+
+
+@pytest.mark.parametrize("shape,k", [((4, 3, 224, 224), 15), ((2, 3, 299, 299), 15), ((2, 3, 37, 41), 15),
+                                     ((2, 3, 64, 64), 3), ((2, 3, 64, 64), 5), ((2, 3, 64, 64), 7),
+                                     ((2, 3, 50, 70), 9), ((1, 3, 33, 33), 4)])
+def test_tim_random(shape, k):
+    gen = torch.Generator().manual_seed(k)
+    grad = torch.randn(shape, generator=gen)
+    w = torch.rand(k, k, generator=gen)
+    w = w / w.sum()
+    out = torch.empty(shape, device=DEV)
+    _hip.depthwise_conv2d_same(grad.to(DEV), out, w.to(DEV))
+    assert np.array_equal(host(out), C.depthwise_conv2d_same(grad.numpy(), w.numpy()))     # FMA chain, bit-exact
+    ref = torch.nn.functional.conv2d(grad, w[None, None].repeat(shape[1], 1, 1, 1), padding="same", groups=shape[1])
+    np.testing.assert_allclose(host(out), ref.numpy(), rtol=0, atol=2e-6)
+
+
+# --------------------------------------------------------------------------------------------------- DIM
+def test_dim_golden(golden):
+    g = golden("dim")
+    x, gy = dev(g["x"]), dev(g["gy"])
+    size = x.shape[-1]
+    resize = int(size * float(g["resize_rate"]))
+    for i, seed in enumerate(g["seeds"]):
+        if g["identity"][i]:
+            continue
+        torch.manual_seed(int(seed))
+        _, rnd, top, left = O.dim_draw(size, float(g["resize_rate"]), float(g["diversity_prob"]))
+        y, gx = torch.empty_like(x), torch.empty_like(x)
+        _hip.dim_fwd(x, y, resize, rnd, top, left)
+        _hip.dim_bwd(gy, gx, resize, rnd, top, left)
+        assert ulp_diff(host(y), g["y"][i]) <= 2
+        assert np.array_equal(host(gx), g["gx"][i])
+
+
+@pytest.mark.parametrize("size,rate,geoms", [
+    (224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)]),
+    (64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)]),
+    (33, 2.0, [(40, 5, 20), (65, 0, 1)]),
+])
+def test_dim_random(size, rate, geoms):
+    gen = torch.Generator().manual_seed(size)
+    resize = int(size * rate)
+    x = torch.rand(3, 3, size, size, generator=gen)
+    gy = torch.randn(3, 3, size, size, generator=gen)
+    for rnd, top, left in geoms:
+        geom = (True, rnd, top, left)
+        y, gx = torch.empty(x.shape, device=DEV), torch.empty(x.shape, device=DEV)
+        _hip.dim_fwd(x.to(DEV), y, resize, rnd, top, left)
+        _hip.dim_bwd(gy.to(DEV), gx, resize, rnd, top, left)
+        assert np.array_equal(host(y), C.dim_fwd(x.numpy(), geom, resize)), geom
+        assert np.array_equal(host(gx), C.dim_bwd(gy.numpy(), geom, resize)), geom
+        xin = x.clone().requires_grad_(True)
+        yt = O.dim_apply(xin, geom, rate)
+        assert ulp_diff(host(y), yt.detach().numpy()) <= 2
+        np.testing.assert_allclose(host(gx), torch.autograd.grad(yt, xin, gy)[0].numpy(), rtol=0, atol=1e-6)
+
+
+# -------------------------------------------------------------------------------------------- SIM / Admix
+def test_sim_admix_golden(golden):
+    g = golden("copies")
+    x = dev(g["x"])
+    y = torch.empty(g["sim_y"].shape, device=DEV)
+    _hip.scale_copies_fwd(x, y, 5)
+    assert np.array_equal(host(y), g["sim_y"])
+    gx = torch.empty_like(x)
+    _hip.scale_copies_bwd(dev(g["sim_gy"]), gx, 5)
+    assert np.array_equal(host(gx), g["sim_gx"])
+    torch.manual_seed(int(g["admix_seed"]))
+    perm = torch.cat(O.admix_draw(x.shape[0])).to(DEV)
+    y = torch.empty(g["admix_y"].shape, device=DEV)
+    _hip.admix_fwd(x, perm, y, 3, 5, 0.2)
+    assert np.array_equal(host(y), g["admix_y"])
+    _hip.admix_bwd(dev(g["admix_gy"]), gx, 3, 5)
+    assert np.array_equal(host(gx), g["admix_gx"])
+
+
+def test_sim_admix_ragged():
+    gen = torch.Generator().manual_seed(1)
+    for shape in ((3, 3, 224, 224), (2, 3, 7, 9), (1, 1, 1, 5)):
+        x = torch.rand(shape, generator=gen)
+        perms = [torch.randperm(shape[0], generator=gen) for _ in range(2)]
+        xin = x.clone().requires_grad_(True)
+        y_ref = O.admix_copies(xin, perms, 0.3, 4)
+        gy = torch.randn(y_ref.shape, generator=gen)
+        gx_ref = torch.autograd.grad(y_ref, xin, gy)[0]
+        y, gx = torch.empty(y_ref.shape, device=DEV), torch.empty(shape, device=DEV)
+        _hip.admix_fwd(x.to(DEV), torch.cat(perms).to(DEV), y, 2, 4, 0.3)
+        _hip.admix_bwd(gy.to(DEV), gx, 2, 4)
+        assert np.array_equal(host(y), y_ref.detach().numpy()) and np.array_equal(host(gx), gx_ref.numpy())
+        xin = x.clone().requires_grad_(True)
+        y_ref = O.sim_copies(xin, 3)
+        gy = torch.randn(y_ref.shape, generator=gen)
+        y, gx = torch.empty(y_ref.shape, device=DEV), torch.empty(shape, device=DEV)
+        _hip.scale_copies_fwd(x.to(DEV), y, 3)
+        _hip.scale_copies_bwd(gy.to(DEV), gx, 3)
+        assert np.array_equal(host(y), y_ref.detach().numpy())
+        assert np.array_equal(host(gx), torch.autograd.grad(y_ref, xin, gy)[0].numpy())
+
+
+# ------------------------------------------------------------------------------------------- VMI / NI / init
+def test_vmi_kernels_and_philox():
+    gen = torch.Generator().manual_seed(2)
+    shape = (3, 3, 31, 33)                                              # numel not a multiple of 4
+    x, d = torch.rand(shape, generator=gen), (torch.rand(shape, generator=gen) - 0.5) * EPS
+    noise = (torch.rand(shape, generator=gen) - 0.5) * 3 * EPS
+    out = torch.empty(shape, device=DEV)
+    _hip.vmi_neighbor(x.to(DEV), d.to(DEV), out, 1.5 * EPS, noise=noise.to(DEV))
+    assert np.array_equal(host(out), (x + d + noise).numpy())           # injected-noise mode == reference expression
+    _hip.vmi_neighbor(x.to(DEV), d.to(DEV), out, 1.5 * EPS, seed=1234, offset=7)
+    stream = C.philox_uniform(x.numel(), 1234, 7, np.float32(1.5 * EPS)).reshape(shape)
+    assert np.array_equal(host(out), (x + d).numpy() + stream)          # in-kernel Philox == restated stream
+    assert np.abs(stream).max() <= 1.5 * EPS and abs(float(stream.mean())) < 0.01 * EPS * 10
+    big = C.philox_uniform(1 << 20, 5, 0, np.float32(1.0))
+    assert abs(big.mean()) < 5e-3 and abs(big.std() - 1 / np.sqrt(3)) < 5e-3
+    acc, g1, g2 = torch.empty(shape, device=DEV), torch.randn(shape, generator=gen), torch.randn(shape, generator=gen)
+    _hip.grad_accumulate(acc, g1.to(DEV), first=True)
+    _hip.grad_accumulate(acc, g2.to(DEV), first=False)
+    assert np.array_equal(host(acc), (g1 + g2).numpy())
+    var = torch.empty(shape, device=DEV)
+    _hip.variance_finalize(acc, g1.to(DEV), var, 20)
+    assert np.array_equal(host(var), ((g1 + g2) / 20 - g1).numpy())     # vmifgsm.py:58
+    _hip.axpy(x.to(DEV), g1.to(DEV), ALPHA * 1.0, out)
+    assert np.array_equal(host(out), (x + ALPHA * 1.0 * g1).numpy())    # nifgsm.py:39
+    dl = torch.empty(shape, device=DEV)
+    _hip.init_delta_uniform(dl, x.to(DEV), EPS, noise=noise.clamp(-EPS, EPS).to(DEV))
+    assert np.array_equal(host(dl), O.delta_init(x, EPS, True, noise=noise.clamp(-EPS, EPS)).numpy())
+    _hip.init_delta_uniform(dl, x.to(DEV), EPS, seed=9, offset=1)
+    ref = O.box_clamp(torch.from_numpy(C.philox_uniform(x.numel(), 9, 1, np.float32(EPS)).reshape(shape)), 0 - x, 1 - x)
+    assert np.array_equal(host(dl), ref.numpy())
+
+
+def test_bad_arguments_fail_loudly():
+    x = torch.rand(2, 3, 8, 8, device=DEV)
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.depthwise_conv2d_same(x, x, torch.rand(3, 3, device=DEV))          # aliasing
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.dim_fwd(x, torch.empty_like(x), 8, 9, 0, 0)                        # rnd > resize
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.momentum(x.cpu(), None, torch.empty_like(x), 1.0)                  # CPU tensor
+    with pytest.raises(TypeError):
+        _hip.momentum(x.double(), None, torch.empty_like(x), 1.0)

@@ -177,10 +177,27 @@ def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
                                      _stream()), "ta_update_delta_l2")
 
 
+# bench.py sets this to a list to time every fused-update launch with HIP events on the launch stream
+profile_sink = None
+
+
 def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None,
               single_launch=False):
     """Fused get_momentum + update_delta; ``delta`` is updated in place, momentum_out may alias momentum_in."""
     n, e = _batch(grad)
+    if profile_sink is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch,
+                   n, e)
+        end.record()
+        profile_sink.append((start, end, n, e))
+        return
+    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch, n, e)
+
+
+def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch,
+               n, e):
     args = (_ptr(grad, name="grad"), _ptr(variance, name="variance"), _ptr(momentum_in, name="momentum"),
             _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"), _ptr(data, name="data"),
             _ptr(x_adv, name="x_adv"))
