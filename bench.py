@@ -86,19 +86,22 @@ def kernel_sweep(single_flags=(0, 1), sizes=(32, 125, 250), reps=30):
 
 
 def cpu_baseline(args):
-    """Oracle = reference CPU arithmetic, timed on this host's cores on a bounded sample."""
+    """Oracle = the reference's ATen CPU arithmetic (oracle/fgsm_oracle.py), timed on this host's cores on a
+    bounded sample: ``cpu_images`` images x ``CPU_ITERS`` of the K=10 iterations (every iteration costs the same:
+    one surrogate forward/backward + the 13-kernel update stack), scaled to K=10."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fgsm_oracle as O
     from transferattack_amd import backbones
+    cpu_iters = 3
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = torch.get_num_threads()
     model = backbones.create(args.model, seed=0, verbose=False)
     x, y = synthetic_batch(args.cpu_images, 0)
-    O.run_attack(args.attack, model, x[:1], y[:1], epoch=1)            # warm the thread pool / oneDNN primitives
+    O.run_attack(args.attack, model, x[:2], y[:2], epoch=1)            # warm the thread pool / oneDNN primitives
     t0 = time.time()
-    O.run_attack(args.attack, model, x, y)
-    dt = time.time() - t0
-    # update stack alone (get_momentum + update_delta), reference op string, N = 32
+    O.run_attack(args.attack, model, x, y, epoch=cpu_iters)
+    dt = (time.time() - t0) / cpu_iters * 10
+    # update stack alone (get_momentum + update_delta), the reference's op string, N = 32
     n = 32
     g = torch.randn(n, 3, 224, 224)
     m, d, xx = torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g)
@@ -110,9 +113,10 @@ def cpu_baseline(args):
         mm = O.momentum_step(g, m, 1.0)
         O.delta_step(d, xx, mm, 1.6 / 255, 16 / 255)
     upd_ms = (time.time() - t1) / 5 * 1e3
-    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic images, %s on %s, K=10, torch %d threads (oracle/fgsm_oracle.py)" % (
-                args.cpu_images, args.attack, args.model, cores),
+    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d synthetic images, %s on %s, %d of the K=10 iterations timed and scaled to 10, torch CPU "
+                      "with %d threads on a %d-hw-thread host (oracle/fgsm_oracle.py)" % (
+                          args.cpu_images, args.attack, args.model, cpu_iters, threads, cores),
             "update_stack_ms_n32": round(upd_ms, 3),
             "update_stack_GBps_n32": round(BYTES_PER_ELEM * 150528 * n / upd_ms / 1e6, 2)}
 
@@ -177,7 +181,9 @@ def main():
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: MI-FGSM on ResNet-50 (seeded random init), eps=16/255, alpha=1.6/255, "
+            "config": {"fold_bn": os.environ.get("TA_FOLD_BN", "0") == "1",
+                       "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
+                       "workload": "configs[1]: MI-FGSM on ResNet-50 (seeded random init), eps=16/255, alpha=1.6/255, "
                                    "K=10, synthetic 3x224x224, batches of %d, image-sharded over %d GPU(s)"
                                    % (args.batch, world),
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
@@ -191,9 +197,16 @@ def main():
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
         }
         if args.kernel_sweep and world == 1:
-            result["config"]["update_kernel_sweep"] = kernel_sweep()
+            try:
+                result["config"]["update_kernel_sweep"] = kernel_sweep()
+            except Exception as exc:  # noqa: BLE001
+                result["config"]["update_kernel_sweep"] = {"error": repr(exc)[:200]}
         if args.cpu_images > 0 and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args)
+            try:
+                result["cpu_baseline"] = cpu_baseline(args)
+            except Exception as exc:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": "failed: " + repr(exc)[:200]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

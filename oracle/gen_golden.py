@@ -151,10 +151,26 @@ def gen_loops():
     x = u8_images(n, size, 20).float() / 255
     label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
     out = dict(x_u8=u8_images(n, size, 20), label=label)
+    def record_grads(atk):
+        """per-iteration output of the reference's own get_grad (after TIM smoothing where it applies)"""
+        grads = []
+        orig = atk.get_grad
+
+        def get_grad(loss, delta, **kw):
+            grads.append(orig(loss, delta, **kw).clone())
+            return grads[-1]
+
+        atk.get_grad = get_grad
+        return grads
+
+    traced = ("mifgsm", "nifgsm", "dim", "tim", "sim", "admix")
     for name in ("fgsm", "ifgsm", "mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim", "admix"):
         atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False))
+        grads = record_grads(atk) if name in traced else None
         torch.manual_seed(1234)
         out["delta_" + name] = atk(x, label)
+        if grads is not None:
+            out["grads_" + name] = torch.stack(grads)
     atk = ref_shim.make_reference_attack(
         "ens", [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)])
     torch.manual_seed(1234)
@@ -163,8 +179,11 @@ def gen_loops():
     from transferattack.utils import wrap_model
     DTS = _dts_class()
     DTS.load_model = lambda self, name: wrap_model(backbone.eval())
+    dts = DTS(model_name="injected")
+    grads = record_grads(dts)
     torch.manual_seed(1234)
-    out["delta_dts"] = DTS(model_name="injected")(x, label)
+    out["delta_dts"] = dts(x, label)
+    out["grads_dts"] = torch.stack(grads)
     # targeted + random_start variants of MI-FGSM
     atk = ref_shim.make_reference_attack("mifgsm", backbones.create("toy_cnn", seed=3, verbose=False), targeted=True)
     tgt = (label + 1) % 10

@@ -51,3 +51,19 @@ def ulp_diff(a, b):
     d = np.abs(ia - ib)
     d[nan_a] = 0
     return int(d.max()) if d.size else 0
+
+
+def assert_momentum_close(m_hip, m_ref, grad, m_prev, decay):
+    """m' = m*decay + g/mean|g|: the HIP path adds the |g| partial sums in its own fixed order, so the mean (and
+    q = g/mean) can differ from ATen's in the last bits; the error of m' is bounded by a few ulp of its two
+    terms (NOT of m' itself -- the terms may cancel).  Bound used: 8 * 2^-24 * (|m*decay| + |q|)."""
+    m_hip, m_ref = np.asarray(m_hip, dtype=np.float64), np.asarray(m_ref, dtype=np.float64)
+    assert np.array_equal(np.isnan(m_hip), np.isnan(m_ref)), "NaN patterns differ"
+    g = np.asarray(grad, dtype=np.float64)
+    mean = np.abs(g).reshape(g.shape[0], -1).mean(axis=1).reshape((-1,) + (1,) * (g.ndim - 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.abs(g / mean)
+    prev = 0.0 if m_prev is None else np.abs(np.asarray(m_prev, dtype=np.float64) * decay)
+    bound = 8 * 2.0 ** -24 * (prev + q) + 1e-30
+    ok = np.isnan(m_ref) | (np.abs(m_hip - m_ref) <= bound)
+    assert ok.all(), "momentum off by %.3e (bound %.3e)" % (np.nanmax(np.abs(m_hip - m_ref)), np.nanmax(bound))

@@ -59,7 +59,12 @@ class Attack(object):
             model = backbones.create(name)          # raises ValueError('Model {} not supported')
             for p in model.parameters():
                 p.requires_grad_(False)             # only d(loss)/d(delta) is ever needed
-            return wrap_model(model.eval().to(default_device()))
+            if os.environ.get("TA_FOLD_BN", "0") == "1":
+                backbones.fold_batchnorm(model)     # opt-in: eval-mode BN folded into the convolutions
+            wrapped = wrap_model(model.eval().to(default_device()))
+            if os.environ.get("TA_CHANNELS_LAST", "0") == "1":
+                wrapped = wrapped.to(memory_format=torch.channels_last)
+            return wrapped
 
         if isinstance(model_name, list):
             return EnsembleModel([load_single_model(name) for name in model_name])

@@ -53,6 +53,72 @@ def available():
     return sorted(list(TORCHVISION_ZOO) + list(TIMM_ZOO) + list(LOCAL_ZOO))
 
 
+def calibrate_batchnorm(model, seed=0, size=224, batch=4):
+    """Give a randomly initialised network the activation statistics of a trained one: one seeded forward in
+    train mode with BatchNorm momentum 1 sets every running mean/var to the batch statistics, so eval-mode
+    activations stay O(1) through the depth instead of growing ~2x per residual block (which saturates the
+    soft-max, makes input-gradients vanish and would turn throughput / parity measurements meaningless).
+    No-op for networks without BatchNorm; never applied when a checkpoint is loaded."""
+    bns = [m for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+    if not bns:
+        return model
+    saved = [(m.momentum, m.training) for m in bns]
+    gen = torch.Generator().manual_seed(seed + 12345)
+    x = torch.rand(batch, 3, size, size, generator=gen)
+    x = (x - 0.45) / 0.225
+    was_training = model.training
+    model.train()
+    for m in bns:
+        m.momentum = 1.0
+    if "Inc" in model.__class__.__name__:      # 299-pixel network (utils.py:49-53 of the reference)
+        x = torch.nn.functional.interpolate(x, size=(299, 299), mode="bilinear", align_corners=False)
+    with torch.no_grad():
+        model(x)
+    for m, (mom, _) in zip(bns, saved):
+        m.momentum = mom
+    model.train(was_training)
+    return model
+
+
+def fold_batchnorm(model):
+    """Fold every eval-mode BatchNorm2d that directly follows a Conv2d into that convolution
+    (w' = w * gamma/sqrt(var+eps), b' = beta + (b - mean) * gamma/sqrt(var+eps)) and replace the BatchNorm by
+    nn.Identity, keeping all module names (hooks on '1.layer1.1' etc. keep working).  Algebraically exact in
+    eval mode; numerically it changes the surrogate's rounding (one multiply less per activation), which is why
+    it is opt-in (TA_FOLD_BN=1) and reported: it removes two memory-bound passes over every activation map in
+    the forward and two in the backward.  Pairs are recognised by name: (convK, bnK), (conv, bn), and
+    Sequential[i] = Conv2d followed by Sequential[i+1] = BatchNorm2d."""
+    def fuse(conv, bn):
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight.mul_(scale.view(-1, 1, 1, 1))
+            bias = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+            new_bias = bn.bias + (bias - bn.running_mean) * scale
+            conv.bias = nn.Parameter(new_bias.detach().clone(), requires_grad=False)
+
+    folded = 0
+    for parent in model.modules():
+        names = dict(parent.named_children())
+        pairs = []
+        for cname, child in names.items():
+            if isinstance(child, nn.Conv2d):
+                bname = cname.replace("conv", "bn")
+                if bname != cname and isinstance(names.get(bname), nn.BatchNorm2d):
+                    pairs.append((cname, bname))
+        if isinstance(parent, nn.Sequential):
+            keys = list(names)
+            for a, b in zip(keys, keys[1:]):
+                if isinstance(names[a], nn.Conv2d) and isinstance(names[b], nn.BatchNorm2d):
+                    pairs.append((a, b))
+        for cname, bname in pairs:
+            bn = getattr(parent, bname)
+            if isinstance(bn, nn.BatchNorm2d) and not bn.training:
+                fuse(getattr(parent, cname), bn)
+                setattr(parent, bname, nn.Identity())
+                folded += 1
+    return folded
+
+
 def create(name, seed=0, verbose=True, **kw):
     """Build backbone ``name``; raises ValueError('Model {} not supported') like attack.py:59."""
     for zoo, origin in ((TORCHVISION_ZOO, "torchvision-compatible"), (TIMM_ZOO, "timm-compatible"),
@@ -74,7 +140,9 @@ def create(name, seed=0, verbose=True, **kw):
         model.load_state_dict(torch.load(path, map_location="cpu"))
         if verbose:
             print('=> Loading model {} ({}) with weights {}'.format(name, origin, path))
-    elif verbose:
-        print('=> Loading model {} ({}) with seeded random init (seed={}); set TA_WEIGHTS_DIR for '
-              'pretrained weights'.format(name, origin, seed))
+    else:
+        calibrate_batchnorm(model, seed)
+        if verbose:
+            print('=> Loading model {} ({}) with seeded random init (seed={}); set TA_WEIGHTS_DIR for '
+                  'pretrained weights'.format(name, origin, seed))
     return model.eval()

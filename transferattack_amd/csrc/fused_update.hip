@@ -39,16 +39,16 @@ __host__ __device__ inline FusedSync carve(void* ws, int64_t n, int tiles) {
     return s;
 }
 
-constexpr unsigned kSpinLimit = 1u << 21;
+constexpr unsigned kSpinLimit = 1u << 17;      // ~0.1 s of polling, then give up (sticky error word)
 
 template <int VEC, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
 __global__ __launch_bounds__(kBlock) void mi_update_fused_kernel(
     const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out, float* delta,
     const float* __restrict__ x, float* __restrict__ x_adv, void* sync_ws, StepParams p, int64_t n, int64_t e,
-    int tiles) {
+    int tiles, int64_t img0) {
     __shared__ float lds[kBlock / kWave + 1];
     const FusedSync sync = carve(sync_ws, n, tiles);
-    const int64_t img = blockIdx.y;
+    const int64_t img = img0 + blockIdx.y;
     const int tile = blockIdx.x;
     const int64_t base = img * e + static_cast<int64_t>(tile) * kTile;
     const int64_t left = e - static_cast<int64_t>(tile) * kTile;
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlock) void mi_update_fused_kernel(
     if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
         float t = 0.0f;
-        bool timed_out = false;
+        // once any exchange of this buffer has timed out, later workgroups do not wait again
+        bool timed_out = __hip_atomic_load((gu32*)(sync.err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         for (int i0 = 0; i0 < tiles; i0 += kWave) {         // lane-strided, tile order within a lane
             const int i = i0 + lane;
             float val = 0.0f;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void mi_update_fused_kernel(
                     ok = static_cast<unsigned>(gr >> 32) == tag;
                     val = __uint_as_float(static_cast<unsigned>(gr));
                 }
-                if (__all(ok)) break;
+                if (__all(ok) || timed_out) break;
                 if (++spins > kSpinLimit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -180,6 +181,21 @@ __global__ __launch_bounds__(kBlock) void mi_update_fused_kernel(
     }
 }
 
+// how many whole images (tiles workgroups each) the device holds at once for this kernel
+static int64_t resident_images(const void* kernel, int tiles) {
+    static thread_local const void* last_kernel = nullptr;
+    static thread_local int64_t last_blocks = 0;
+    if (kernel != last_kernel) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess) return 0;
+        last_kernel = kernel;
+        last_blocks = static_cast<int64_t>(cus) * per_cu;
+    }
+    return last_blocks / tiles;
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -218,16 +234,28 @@ extern "C" int ta_mi_update_fused(const float* g, const float* v, const float* m
     TA_REQUIRE(g && delta && x && sync_ws, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tiles = static_cast<int>(ceil_div(e, kTile));
-    const dim3 grid(tiles, static_cast<unsigned>(n));
     const StepParams p{decay, alpha, -eps, eps};
     bool vec = e % kVec == 0;
     for (const void* ptr : {(const void*)g, (const void*)v, (const void*)m_in, (const void*)m_out, (const void*)delta,
                             (const void*)x, (const void*)x_adv})
         if (ptr && !aligned16(ptr)) vec = false;
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
-#define TA_MF(VEC, HV, HMI, HMO, HXA)                                                                          \
-    hipLaunchKernelGGL((mi_update_fused_kernel<VEC, HV, HMI, HMO, HXA>), grid, dim3(kBlock), 0, st, g, v, m_in, \
-                       m_out, delta, x, x_adv, sync_ws, p, n, e, tiles)
+    // The exchange needs every workgroup of an image resident at once.  A launch therefore never exceeds what the
+    // device can hold (occupancy query x CU count, same stream => the device is otherwise drained): bigger
+    // batches are cut into several launches of whole images.
+    int64_t img0 = 0;
+    int64_t chunk = 0;
+#define TA_MF(VEC, HV, HMI, HMO, HXA)                                                                            \
+    {                                                                                                            \
+        auto kern = mi_update_fused_kernel<VEC, HV, HMI, HMO, HXA>;                                              \
+        if (chunk == 0) chunk = resident_images(reinterpret_cast<const void*>(kern), tiles);                     \
+        TA_REQUIRE(chunk > 0, "an image of %d tiles does not fit the device at once", tiles);                   \
+        for (img0 = 0; img0 < n; img0 += chunk) {                                                                \
+            const dim3 grid(tiles, static_cast<unsigned>(n - img0 < chunk ? n - img0 : chunk));                  \
+            hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, st, g, v, m_in, m_out, delta, x, x_adv, sync_ws, p, n, e, \
+                               tiles, img0);                                                                     \
+        }                                                                                                        \
+    }
 #define TA_MF_CASES(VEC)                                       \
     switch (key) {                                             \
         case 0: TA_MF(VEC, false, false, false, false); break; \
