@@ -1,0 +1,141 @@
+"""CPU, world_size = 2, gloo: the N>1 paths -- image sharding by whole batches with per-batch seeding, and the
+ensemble exchange (logit all-reduce + input-gradient all-reduce) -- against the single-process result.
+The kernel binding is replaced by the oracle-backed fake in every rank (tests/fake_hip.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Patch:
+    """minimal stand-in for pytest's monkeypatch inside a spawned rank"""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def _setup(rank, world, port):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import fake_hip
+    fake_hip.install(_Patch())
+    from transferattack_amd import dist as tadist
+    tadist.init("gloo")
+    return tadist
+
+
+def _make(name, models, **kw):
+    import transferattack_amd as ta
+    from transferattack_amd.utils import EnsembleModel, wrap_model
+    base = ta.load_attack_class(name)
+
+    def load_model(self, model_name):
+        if isinstance(models, torch.nn.Module) and not isinstance(models, torch.nn.Sequential):
+            return models                       # a ready ShardedEnsemble
+        wrapped = [wrap_model(m.eval()) for m in models]
+        return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
+
+    return type("T" + base.__name__, (base,), {"load_model": load_model})(model_name="injected", **kw)
+
+
+def _rank_shard(rank, world, port, out):
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from conftest import u8_images
+    images = u8_images(20, 32, 3).float() / 255             # 20 images in batches of 8 -> 8, 8, 4
+    labels = torch.randint(0, 10, (20,), generator=torch.Generator().manual_seed(4))
+    atk = _make("dim", [backbones.create("toy_cnn", seed=3, verbose=False)], epoch=3)
+    result = {}
+    for b in tadist.shard_batches(3, rank, world):
+        tadist.seed_batch(99, b)
+        sl = slice(8 * b, min(8 * b + 8, 20))
+        result[b] = atk(images[sl], labels[sl]).numpy()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, result)
+    if rank == 0:
+        merged = {}
+        for g in gathered:
+            merged.update(g)
+        np.savez(out, **{"b%d" % k: v for k, v in merged.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rank_ensemble(rank, world, port, out):
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import wrap_model
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    grp, idx, shard, nshards = tadist.model_groups(world, 2)
+    assert (idx, shard, nshards) == (rank, 0, 1)
+    member = wrap_model(backbones.create("toy_cnn", seed=3 + rank, verbose=False).eval())
+    atk = _make("ens", tadist.ShardedEnsemble(member, grp, 2), epoch=4)
+    delta = atk(x, y)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, delta.numpy())
+    if rank == 0:
+        np.savez(out, r0=gathered[0], r1=gathered[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(fn, tmp_path):
+    out = str(tmp_path / "out.npz")
+    mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
+    return np.load(out)
+
+
+def test_image_sharding_is_gpu_count_invariant(tmp_path, monkeypatch):
+    """2 ranks x round-robin batches == 1 process over all batches, bit for bit (per-batch seeding)."""
+    got = _run(_rank_shard, tmp_path)
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones, dist as tadist
+    from conftest import u8_images
+    assert tadist.shard_batches(32, 3, 8) == [3, 11, 19, 27] and tadist.shard_batches(3, 1, 2) == [1]
+    assert sorted(sum((tadist.shard_batches(32, r, 8) for r in range(8)), [])) == list(range(32))
+    images = u8_images(20, 32, 3).float() / 255
+    labels = torch.randint(0, 10, (20,), generator=torch.Generator().manual_seed(4))
+    atk = _make("dim", [backbones.create("toy_cnn", seed=3, verbose=False)], epoch=3)
+    for b in range(3):
+        tadist.seed_batch(99, b)
+        sl = slice(8 * b, min(8 * b + 8, 20))
+        assert np.array_equal(atk(images[sl], labels[sl]).numpy(), got["b%d" % b]), b
+
+
+def test_sharded_ensemble_matches_single_process(tmp_path, monkeypatch):
+    """one member per rank + 2 all-reduces == EnsembleModel on one device (fp32 sums in a different order:
+    gradients agree to rounding, the final perturbation to the few pixels rounding can flip)."""
+    got = _run(_rank_ensemble, tmp_path)
+    assert np.array_equal(got["r0"], got["r1"])                      # both ranks hold the same delta
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    ref = _make("ens", models, epoch=4)(x, y).numpy()
+    assert float((got["r0"] != ref).mean()) <= 0.002
+    assert np.abs(got["r0"] - ref).max() <= 2 * 1.6 / 255 + 1e-7

@@ -1,0 +1,111 @@
+"""One process per GPU: how the 1000-image job is spread over the GPUs of a node.
+
+The reference is single-process, single-GPU (main.py:31, 43); nothing here has a counterpart to port.
+
+* Single-surrogate attacks shard by WHOLE reference batches (``shard_batches``): DIM draws one geometry per
+  batch and Admix mixes images within a batch (dim.py:54-63, admix.py:44), so batches are never re-cut.  Every
+  batch is seeded from (base_seed, batch_idx) (``seed_batch``) so the output does not depend on the GPU count.
+  No collective on the data path.
+* Ensemble attacks (ENS) put one surrogate per rank of a model group: ``ShardedEnsemble`` averages the logits with
+  one RCCL all-reduce ([N,1000] fp32) and ``allreduce_input_grad`` sums the input gradients with another
+  ([N,3,224,224] fp32) -- the only two exchange steps the path has.  Ranks of a group see the same images and,
+  after the second all-reduce, hold identical gradients, so each runs the identical fused update locally.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Join the job torch.distributed.run started (nccl == RCCL on ROCm; gloo for the CPU tests)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return rank_world()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return rank_world()
+
+
+def shard_batches(num_batches, rank, world):
+    """Indices of the reference batches rank ``rank`` of ``world`` processes: round-robin, so the short tail batch
+    (1000 = 31 x 32 + 8) lands on the rank with the fewest full batches and every rank's share differs by <= 1."""
+    return list(range(rank, num_batches, world))
+
+
+def seed_batch(base_seed, batch_idx):
+    """Seed the host generator for one batch; (base_seed, batch_idx) -> the DIM / Admix draws of that batch are the
+    same whichever rank processes it."""
+    seed = (int(base_seed) * 1000003 + int(batch_idx) * 7919 + 12345) % (2 ** 63 - 1)
+    torch.manual_seed(seed)
+    return seed
+
+
+def model_groups(world, group_size):
+    """Partition the ranks into groups of ``group_size`` consecutive ranks (one ensemble member per rank);
+    returns (my_group, my_index_in_group, image_shard_index, num_image_shards).  Must be called by every rank."""
+    rank, _ = rank_world()
+    assert world % group_size == 0, "world size must be a multiple of the ensemble size"
+    mine = None
+    for first in range(0, world, group_size):
+        ranks = list(range(first, first + group_size))
+        grp = dist.new_group(ranks)
+        if rank in ranks:
+            mine = (grp, rank - first, first // group_size, world // group_size)
+    return mine
+
+
+class _AllReduceMean(torch.autograd.Function):
+    """z = (1/M) sum_m z_m over the group; d(loss)/d z_m = (1/M) d(loss)/d z."""
+
+    @staticmethod
+    def forward(ctx, logits, group, members):
+        out = logits.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        ctx.members = members
+        return out / members
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad / ctx.members, None, None
+
+
+class ShardedEnsemble(nn.Module):
+    """Drop-in for ``EnsembleModel`` (utils.py:82-105, mode 'mean') when each rank of ``group`` holds ONE member:
+    forward = local member + all-reduce(mean) of the logits.  ``models`` / ``num_models`` / ``device`` keep the
+    attribute contract of the reference class."""
+
+    def __init__(self, local_model, group, members):
+        super().__init__()
+        self.local = local_model
+        self.models = [local_model]
+        self.group = group
+        self.num_models = members
+        self.mode = 'mean'
+        self.type_name = 'ensemble'
+        self.device = next(local_model.parameters()).device
+
+    def forward(self, x):
+        return _AllReduceMean.apply(self.local(x), self.group, self.num_models)
+
+
+def allreduce_input_grad(grad, group):
+    """Sum over the members of d(loss)/d(delta) -- the second exchange step of the ensemble path."""
+    grad = grad.contiguous()
+    dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    return grad
