@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 1
+#define TA_ABI_VERSION 2
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -55,10 +55,19 @@ int ta_update_delta_linf(const float* delta_in, const float* x, const float* m, 
 int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, float alpha, float eps,
                        float* delta_out, float* ws, int64_t n, int64_t e, void* stream);
 /* fused get_momentum + update_delta (the headline kernel): reads g,(v),m,d,x  writes m,d,(x_adv).
- * 24 B/element algorithmic traffic (16 when m_in==NULL && m_out==NULL, the decay=0 / FGSM case). */
+ * 24 B/element algorithmic traffic (16 when m_in==NULL && m_out==NULL, the decay=0 / FGSM case).
+ * partials_ready != 0: ws already holds the |g| tile sums (written by ta_normalize_bwd, the producer of g),
+ * so the K1 pass over g is skipped and g is read exactly once. */
 int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                 const float* x, float* x_adv, float* ws, float decay, float alpha, float eps,
-                 int64_t n, int64_t e, void* stream);
+                 const float* x, float* x_adv, float* ws, int partials_ready, float decay, float alpha,
+                 float eps, int64_t n, int64_t e, void* stream);
+/* PreprocessingModel's Normalize (transferattack/utils.py:72-79, torchvision Normalize): y = (x - mean[c]) / std[c]
+ * over [n, c, hw]; mean/std: device fp32 [c].  Backward gx = gy / std[c] (the last kernel of the surrogate's
+ * backward, i.e. the producer of the gradient) also writes the |gx| tile sums to ws in K1's layout. */
+int ta_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
+                     int64_t hw, void* stream);
+int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int64_t hw,
+                     void* stream);
 /* same arithmetic, single launch: the |g| partial sums are exchanged between the workgroups of an
  * image inside the kernel (agent-scope granules) so g is read from HBM exactly once.
  * `sync_ws` = ta_fused_sync_bytes(n, e) bytes, zeroed once by the caller when (n, e) changes. */

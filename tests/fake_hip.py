@@ -127,6 +127,16 @@ def axpy(x, m, coeff, out):
     out.copy_(x + coeff * m)
 
 
+def normalize_fwd(x, y, mean, std):
+    calls.append("normalize_fwd")
+    y.copy_((x - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
+
+
+def normalize_bwd(gy, gx, std):
+    calls.append("normalize_bwd")
+    gx.copy_(gy / std.view(1, -1, 1, 1))
+
+
 def quantize_u8_nhwc(data, delta, out):
     calls.append("quantize_u8_nhwc")
     out.copy_(_t(O.quantize_u8(data + delta)))
@@ -134,7 +144,8 @@ def quantize_u8_nhwc(data, delta, out):
 
 _NAMES = ["momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "admix_fwd",
-          "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc"]
+          "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
+          "normalize_bwd"]
 
 
 def install(monkeypatch):

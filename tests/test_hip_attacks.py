@@ -143,6 +143,10 @@ def test_end_to_end_gpu_vs_reference(golden, name):
 def test_variants_run_on_gpu(golden):
     g = golden("loops_toy")
     x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    before = dict(_hip.stats)
+    make("mifgsm")(x, label)                                              # plain MI-FGSM: the normalize backward
+    assert _hip.stats["partials_reused"] - before["partials_reused"] == 10   # feeds all 10 fused updates, no K1 pass
+    assert _hip.stats["k1_passes"] == before["k1_passes"]
     d = make("mifgsm", targeted=True)(x, [label, t(g["target"])])
     assert float(d.abs().max()) <= EPS + 1e-7
     atk = make("mifgsm", random_start=True)

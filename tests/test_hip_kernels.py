@@ -152,6 +152,44 @@ def test_fused_update_under_graph_capture():
     assert torch.equal(d, d_ref) and torch.equal(m, m_ref)
 
 
+@pytest.mark.parametrize("shape", [(8, 3, 224, 224), (3, 3, 37, 41), (2, 1, 5, 7)])
+def test_normalize_and_producer_side_partials(shape):
+    """PreprocessingModel's Normalize as HIP kernels: forward/backward bit-identical to the torch expression the
+    reference evaluates ((x-mean)/std, grad/std), and the |g| tile sums the backward leaves behind make the fused
+    update produce exactly what it produces when it runs its own K1 pass."""
+    from transferattack_amd.utils import _Normalize
+    gen = torch.Generator().manual_seed(shape[0])
+    c = shape[1]
+    mean, std = [0.485, 0.456, 0.406][:c], [0.229, 0.224, 0.225][:c]
+    norm = _Normalize(mean, std).to(DEV)
+    x = torch.rand(shape, generator=gen)
+    gy = torch.randn(shape, generator=gen) * 1e-3
+    xin = x.clone().requires_grad_(True)
+    y_ref = (xin - torch.tensor(mean).view(1, -1, 1, 1)) / torch.tensor(std).view(1, -1, 1, 1)
+    gx_ref = torch.autograd.grad(y_ref, xin, gy)[0]
+    xd = x.to(DEV).requires_grad_(True)
+    y = norm(xd)
+    assert np.array_equal(host(y), y_ref.detach().numpy())
+    gx = torch.autograd.grad(y, xd, gy.to(DEV))[0]
+    assert np.array_equal(host(gx), gx_ref.numpy())
+    assert _hip._partials is not None and _hip._partials[0].data_ptr() == gx.data_ptr()
+    mom, data = torch.randn(shape, generator=gen).to(DEV), torch.rand(shape, generator=gen).to(DEV)
+    d1, m1 = torch.zeros(shape, device=DEV), mom.clone()
+    _hip.mi_update(gx, m1, m1, d1, data, 1.0, ALPHA, EPS)                 # consumes the registered partials
+    assert _hip._partials is None
+    d2, m2 = torch.zeros(shape, device=DEV), mom.clone()
+    _hip.mi_update(gx.clone(), m2, m2, d2, data, 1.0, ALPHA, EPS)         # different tensor -> own K1 pass
+    assert torch.equal(d1, d2) and torch.equal(m1, m2)
+    # an in-place edit of the gradient invalidates the registered sums
+    gx2 = torch.autograd.grad(norm(xd), xd, gy.to(DEV))[0]
+    gx2.mul_(2.0)
+    d3, m3 = torch.zeros(shape, device=DEV), mom.clone()
+    _hip.mi_update(gx2, m3, m3, d3, data, 1.0, ALPHA, EPS)
+    d4, m4 = torch.zeros(shape, device=DEV), mom.clone()
+    _hip.mi_update(gx2.clone(), m4, m4, d4, data, 1.0, ALPHA, EPS)
+    assert torch.equal(d3, d4) and torch.equal(m3, m4)
+
+
 def test_quantiser(golden):
     g = golden("update_stack")
     x, d = dev(g["x"]), dev(g["delta_d1"])

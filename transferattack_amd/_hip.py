@@ -33,7 +33,9 @@ SIGNATURES = {
     "ta_momentum": (_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp]),
     "ta_update_delta_linf": (_int, [_vp, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _i64, _vp]),
     "ta_update_delta_l2": (_int, [_vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _vp]),
-    "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _i64, _vp]),
+    "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
+    "ta_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_fused_sync_bytes": (_i64, [_i64, _i64]),
     "ta_mi_update_fused": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_fused_sync_error": (_int, [_vp, _i64, _i64, _vp]),
@@ -52,7 +54,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipExtensionError(RuntimeError):
@@ -206,9 +208,47 @@ def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsil
         _check(load().ta_mi_update_fused(*args, sync.data_ptr(), float(decay), float(alpha), float(epsilon), n, e,
                                          _stream()), "ta_mi_update_fused")
     else:
-        ws = workspace.l1(grad, n, e)
-        _check(load().ta_mi_update(*args, _ptr(ws), float(decay), float(alpha), float(epsilon), n, e, _stream()),
-               "ta_mi_update")
+        ready = _take_partials(grad) if variance is None else None
+        stats["partials_reused" if ready is not None else "k1_passes"] += 1
+        ws = ready if ready is not None else workspace.l1(grad, n, e)
+        _check(load().ta_mi_update(*args, _ptr(ws), 1 if ready is not None else 0, float(decay), float(alpha),
+                                   float(epsilon), n, e, _stream()), "ta_mi_update")
+
+
+# ---- producer-side |g| partial sums ---------------------------------------------------------------------
+# normalize_bwd (the last kernel of the surrogate's backward) leaves the per-tile sums of |g| of the gradient it
+# produced here; mi_update consumes them if -- and only if -- it is handed that very tensor, unmodified.  The
+# entry holds a strong reference to the gradient, so its memory cannot be recycled while the entry is live.
+_partials = None            # (grad tensor, grad._version, ws tensor)
+stats = {"partials_reused": 0, "k1_passes": 0}
+
+
+def _take_partials(grad):
+    global _partials
+    entry, _partials = _partials, None
+    if entry is None:
+        return None
+    tensor, version, ws = entry
+    if (tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
+            and tensor._version == version):
+        return ws
+    return None
+
+
+def normalize_fwd(x, y, mean, std):
+    n, c = x.shape[0], x.shape[1]
+    _check(load().ta_normalize_fwd(_ptr(x, name="x"), _ptr(y, name="y"), _ptr(mean, name="mean"), _ptr(std, name="std"),
+                                   n, c, x[0, 0].numel(), _stream()), "ta_normalize_fwd")
+
+
+def normalize_bwd(gy, gx, std):
+    """gx = gy / std[c]; also registers the |gx| tile sums for the fused update that consumes gx next."""
+    global _partials
+    n, c = gy.shape[0], gy.shape[1]
+    ws = torch.empty(max(load().ta_l1_workspace_floats(n, gy[0].numel()), 1), dtype=torch.float32, device=gy.device)
+    _check(load().ta_normalize_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"), _ptr(ws), n, c,
+                                   gy[0, 0].numel(), _stream()), "ta_normalize_bwd")
+    _partials = (gx, gx._version, ws)
 
 
 def fused_sync_check(like, n, e):

@@ -62,6 +62,75 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Surrogate pre-processing Normalize (reference: transforms.Normalize inside PreprocessingModel,
+// utils.py:72-79): y = (x - mean[c]) / std[c].  Its backward gx = gy / std[c] is the LAST kernel of the
+// surrogate's backward pass, i.e. the producer of the gradient the update stack consumes -- so it also emits the
+// per-tile sums of |gx| in K1's layout, and the separate K1 pass over g disappears (g is read once, by K2).
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void normalize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ stdv, int64_t e, int64_t hw) {
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= e) {
+            Pack<VEC> a, o;
+            a.load(x + img * e + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = static_cast<int>((off + k) / hw);
+                o[k] = (a[k] - mean[c]) / stdv[c];
+            }
+            o.store(y + img * e + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const int c = static_cast<int>(i / hw);
+                y[img * e + i] = (x[img * e + i] - mean[c]) / stdv[c];
+            }
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                               const float* __restrict__ stdv,
+                                                               float* __restrict__ ws, int64_t e, int64_t hw,
+                                                               int tiles) {
+    __shared__ float lds[kBlock / kWave];
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= e) {
+            Pack<VEC> a, o;
+            a.load(gy + img * e + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = static_cast<int>((off + k) / hw);
+                o[k] = a[k] / stdv[c];
+                acc += fabsf(o[k]);                      // same per-thread order as abs_sum_partials_kernel
+            }
+            o.store(gx + img * e + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const float o = gy[img * e + i] / stdv[static_cast<int>(i / hw)];
+                gx[img * e + i] = o;
+                acc += fabsf(o);
+            }
+        }
+    }
+    const float total = block_sum(acc, lds);
+    if (threadIdx.x == 0) ws[img * tiles + blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2 (fused) and the two hook-level halves
 // ------------------------------------------------------------------------------------------------
 template <int VEC, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
@@ -356,13 +425,44 @@ extern "C" int ta_update_delta_l2(const float* delta_in, const float* x, const f
     return check_launch("l2_renorm");
 }
 
+extern "C" int ta_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
+                                int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(x && y && mean && stdv && c > 0, "null pointer");
+    const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec_ok(e, {x, y}))
+        hipLaunchKernelGGL(normalize_fwd_kernel<4>, grid, dim3(kBlock), 0, st, x, y, mean, stdv, e, hw);
+    else
+        hipLaunchKernelGGL(normalize_fwd_kernel<1>, grid, dim3(kBlock), 0, st, x, y, mean, stdv, e, hw);
+    return check_launch("normalize_fwd");
+}
+
+extern "C" int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int64_t hw,
+                                void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(gy && gx && stdv && ws && c > 0, "null pointer");
+    const int tiles = static_cast<int>(ceil_div(e, kTile));
+    const dim3 grid(tiles, static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec_ok(e, {gy, gx}))
+        hipLaunchKernelGGL(normalize_bwd_kernel<4>, grid, dim3(kBlock), 0, st, gy, gx, stdv, ws, e, hw, tiles);
+    else
+        hipLaunchKernelGGL(normalize_bwd_kernel<1>, grid, dim3(kBlock), 0, st, gy, gx, stdv, ws, e, hw, tiles);
+    return check_launch("normalize_bwd");
+}
+
 extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                            const float* x, float* x_adv, float* ws, float decay, float alpha, float eps,
-                            int64_t n, int64_t e, void* stream) {
+                            const float* x, float* x_adv, float* ws, int partials_ready, float decay, float alpha,
+                            float eps, int64_t n, int64_t e, void* stream) {
     if (int rc = check_batch(n, e)) return rc;
     TA_REQUIRE(g && delta && x && ws, "null pointer");
+    TA_REQUIRE(!(partials_ready && v), "partials of |g| cannot be reused when a variance term is added");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
+    if (!partials_ready)
+        if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
     const int tiles = static_cast<int>(ceil_div(e, kTile));
     const dim3 grid(tiles, static_cast<unsigned>(n));
     const StepParams p{decay, alpha, -eps, eps};

@@ -57,6 +57,27 @@ class _Resize(nn.Module):
         return F.interpolate(x, size=(self.size, self.size), mode="bilinear", align_corners=False)
 
 
+class _NormalizeFn(torch.autograd.Function):
+    """(x - mean[c]) / std[c] as one HIP kernel each way; the backward is the producer of the input-gradient the
+    update stack consumes, so it also leaves the per-tile |g| sums for the fused update (no separate K1 pass)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, std):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _hip.normalize_fwd(x, y, mean, std)
+        ctx.save_for_backward(std)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (std,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        _hip.normalize_bwd(gy, gx, std)
+        return gx, None, None
+
+
 class _Normalize(nn.Module):
     def __init__(self, mean, std):
         super().__init__()
@@ -64,6 +85,8 @@ class _Normalize(nn.Module):
         self.register_buffer("std", torch.tensor(list(std), dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous():
+            return _NormalizeFn.apply(x, self.mean.reshape(-1).contiguous(), self.std.reshape(-1).contiguous())
         return (x - self.mean) / self.std
 
 
