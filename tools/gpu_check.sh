@@ -20,6 +20,13 @@ bench)
   timeout 600 python bench.py --steps 6 --warmup 2 --single-launch 1 --cpu-images 0 --kernel-sweep 0 > $OUT/bench_single.json 2>> $OUT/bench.err; cat $OUT/bench_single.json ;;
 batches)
   for b in 64 125 250; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+kernels)
+  timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
+k2sweep)
+  timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
+fast)
+  TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 4 --warmup 2 --batch 125 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast125.json
+  TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast32.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
 rocprof)

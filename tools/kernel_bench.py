@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Per-kernel timing of every HIP entry point on MI355X: mean launch time (HIP events on the launch stream, operands
+rotating over several buffer sets) and achieved GB/s at the ALGORITHMIC bytes of SURVEY.md 8(d).  One JSON line."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transferattack_amd import _hip  # noqa: E402
+
+E = 3 * 224 * 224
+DEV = "cuda"
+
+
+def timed(fn, reps=20):
+    for i in range(4):
+        fn(i)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for i in range(reps):
+        fn(i)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps
+
+
+def main():
+    _hip.load()
+    out = {}
+    for n in (32, 160):
+        sets = [[torch.randn(n, 3, 224, 224, device=DEV) * 1e-3 for _ in range(4)] for _ in range(3)]
+        big = [torch.empty(5 * n, 3, 224, 224, device=DEV) for _ in range(2)] if n == 32 else None
+        big15 = [torch.empty(15 * n, 3, 224, 224, device=DEV) for _ in range(2)] if n == 32 else None
+        w = torch.rand(15, 15, device=DEV)
+        w = (w / w.sum()).contiguous()
+        perm = torch.cat([torch.randperm(n) for _ in range(3)]).to(DEV)
+        u8 = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device=DEV)
+        mean = torch.tensor([0.485, 0.456, 0.406], device=DEV)
+        std = torch.tensor([0.229, 0.224, 0.225], device=DEV)
+        ws = torch.empty(4 * n * 49, device=DEV)
+
+        def rec(name, us, bytes_per_elem, flop_per_elem=0):
+            d = {"us": round(us, 2), "GBps": round(bytes_per_elem * E * n / us / 1e3, 1)}
+            if flop_per_elem:
+                d["TFLOPs"] = round(flop_per_elem * E * n / us / 1e6, 2)
+            out["n%d_%s" % (n, name)] = d
+
+        rec("tim_conv15", timed(lambda i: _hip.depthwise_conv2d_same(sets[i % 3][0], sets[i % 3][1], w)), 8, 450)
+        rec("dim_fwd", timed(lambda i: _hip.dim_fwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
+        rec("dim_bwd", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
+        rec("vmi_neighbor_philox", timed(lambda i: _hip.vmi_neighbor(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
+                                                                      0.09, seed=1, offset=i)), 12)
+        rec("grad_accumulate", timed(lambda i: _hip.grad_accumulate(sets[i % 3][0], sets[i % 3][1], False)), 12)
+        rec("variance_finalize", timed(lambda i: _hip.variance_finalize(sets[i % 3][0], sets[i % 3][1],
+                                                                        sets[i % 3][2], 20)), 12)
+        rec("axpy", timed(lambda i: _hip.axpy(sets[i % 3][0], sets[i % 3][1], 0.006, sets[i % 3][2])), 12)
+        rec("quantize_u8", timed(lambda i: _hip.quantize_u8_nhwc(sets[i % 3][0], sets[i % 3][1], u8)), 9)
+        rec("normalize_fwd", timed(lambda i: _hip.normalize_fwd(sets[i % 3][0], sets[i % 3][1], mean, std)), 8)
+        rec("normalize_bwd_partials", timed(lambda i: _hip.load().ta_normalize_bwd(
+            sets[i % 3][0].data_ptr(), sets[i % 3][1].data_ptr(), std.data_ptr(), ws.data_ptr(), n, 3, 224 * 224,
+            torch.cuda.current_stream().cuda_stream)), 8)
+        rec("momentum_hook", timed(lambda i: _hip.momentum(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2], 1.0)), 12)
+        rec("update_delta_hook", timed(lambda i: _hip.update_delta_linf(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
+                                                                        0.006, 0.06, sets[i % 3][3])), 16)
+        rec("mi_update_two_launch", timed(lambda i: _hip.mi_update(sets[i % 3][0], sets[i % 3][1], sets[i % 3][1],
+                                                                   sets[i % 3][2], sets[i % 3][3], 1.0, 0.006, 0.06)), 24)
+        if big is not None:
+            rec("sim_fwd_x5", timed(lambda i: _hip.scale_copies_fwd(sets[i % 3][0], big[i % 2], 5)), 24)
+            rec("sim_bwd_x5", timed(lambda i: _hip.scale_copies_bwd(big[i % 2], sets[i % 3][0], 5)), 24)
+            rec("admix_fwd_x15", timed(lambda i: _hip.admix_fwd(sets[i % 3][0], perm, big15[i % 2], 3, 5, 0.2)), 76)
+            rec("admix_bwd_x15", timed(lambda i: _hip.admix_bwd(big15[i % 2], sets[i % 3][0], 3, 5)), 64)
+        del sets, big, big15
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
