@@ -4,8 +4,11 @@
     python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank/GPU)
 
 Workload (BASELINE.json configs[1]): MI-FGSM on ResNet-50, eps=16/255, alpha=1.6/255, K=10 iterations,
-synthetic 3x224x224 images in the reference's batches of 32 (main.py:15).  One "step" = one batch through
-``attacker(images, labels)`` = 10 x (surrogate forward + input-gradient backward + fused HIP update).
+synthetic 3x224x224 images.  One "step" = one batch of 125 images (1000/8: the per-GPU shard of the 1000-image
+set; 8 steps = the whole set) through ``attacker(images, labels)`` = 10 x (surrogate forward + input-gradient
+backward + fused HIP update).  Host-side arrangement of the surrogate (both reported in ``config``, both
+switchable): eval-mode BatchNorm folded into the convolutions, NHWC memory format (profiles/r01/backbone_probe.jsonl:
++46% over plain NCHW at this batch); ``--batch 32 --fold-bn 0 --channels-last 0`` is the reference's literal setup.
 Inputs are resident in HBM before the timed region; the surrogate is the ResNet-50 architecture with seeded
 random weights (no checkpoints offline); arithmetic is fp32 throughout, as in the reference.
 
@@ -41,7 +44,12 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--attack", default="mifgsm")
     p.add_argument("--model", default="resnet50")
-    p.add_argument("--batch", type=int, default=32, help="images per step (reference batch: 32)")
+    p.add_argument("--batch", type=int, default=125,
+                   help="images per step; MI-FGSM treats images independently, 125 = the per-GPU shard of the "
+                        "1000-image set on 8 GPUs (the reference CLI default is 32)")
+    p.add_argument("--fold-bn", type=int, default=1,
+                   help="fold the surrogate's eval-mode BatchNorm into its convolutions (algebraically exact)")
+    p.add_argument("--channels-last", type=int, default=1, help="run the surrogate in NHWC memory format")
     p.add_argument("--single-launch", type=int, default=int(os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0")))
     p.add_argument("--cpu-images", type=int, default=8, help="images of the CPU-baseline sample (0 = skip)")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
@@ -133,6 +141,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    os.environ["TA_FOLD_BN"] = "1" if args.fold_bn else "0"
+    os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
     import transferattack_amd as ta
     from transferattack_amd import _hip
     from transferattack_amd.attack import Attack
@@ -176,6 +186,14 @@ def main():
         n_, e_ = sink[0][2], sink[0][3]
         mean_us = sum(durs_us) / len(durs_us)
         achieved = BYTES_PER_ELEM * e_ * n_ / mean_us / 1e3          # GB/s
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")
+        if os.path.isfile(pmc_path):            # HBM bytes per launch from the committed rocprofv3 PMC passes
+            pmc = json.load(open(pmc_path))
+            per_elem = pmc["mi_update_kernel"]["fetch_B_per_elem_corrected"] + pmc["mi_update_kernel"]["write_B_per_elem"]
+            if _hip.stats["k1_passes"] > 0:
+                per_elem += pmc["abs_sum_partials_kernel"]["fetch_B_per_elem_corrected"]
+            traffic = int(per_elem * e_ * n_)
         result = {
             "metric": "adversarial images/sec (1000-img set, K=10)",
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -191,9 +209,10 @@ def main():
                        "parallelism": "image-shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "ta_mi_update (abs_sum_partials + mi_update)" if not args.single_launch
                          else "ta_mi_update_fused", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
                          "algorithmic_bytes_per_launch": BYTES_PER_ELEM * e_ * n_,
+                         "k1_pass_skipped_launches": _hip.stats["partials_reused"],
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
         }
         if args.kernel_sweep and world == 1:

@@ -232,6 +232,10 @@ def _take_partials(grad):
     if (tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
             and tensor._version == version):
         return ws
+    if os.environ.get("TA_DEBUG_PARTIALS"):
+        print("partials not reused: ptr %x vs %x, shape %s vs %s, version %d/%d vs %d" % (
+            tensor.data_ptr(), grad.data_ptr(), tuple(tensor.shape), tuple(grad.shape), tensor._version,
+            grad._version, version), flush=True)
     return None
 
 

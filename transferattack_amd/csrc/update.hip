@@ -133,33 +133,47 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 // K2 (fused) and the two hook-level halves
 // ------------------------------------------------------------------------------------------------
-template <int VEC, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
-__global__ __launch_bounds__(kBlock) void mi_update_kernel(
-    const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out,
-    float* delta, const float* __restrict__ x, float* __restrict__ x_adv,
-    const float* __restrict__ ws, StepParams p, int64_t e, int tiles) {
+// K2 has its own tiling (it only SUMS the K1-layout partials): on MI355X one 16-byte access per operand and lane
+// with 512-lane workgroups streams fastest (tools/k2_sweep.hip: 6.19 TB/s at N=32, vs 5.72 for 256 x 3), and
+// non-temporal loads/stores win once a launch moves more than the 256 MiB Infinity Cache holds (6.35 vs 5.45 TB/s
+// at N=125) but lose below it -- NT is therefore a launch-time choice.
+constexpr int kK2Block = 512;
+
+template <int VEC, int BLOCK, int SLOTS, bool NT, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
+__global__ __launch_bounds__(BLOCK) void mi_update_kernel(
+    const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out, float* delta,
+    const float* __restrict__ x, float* __restrict__ x_adv, const float* __restrict__ ws, StepParams p, int64_t e,
+    int tiles_ws) {
+    constexpr int TILE = BLOCK * VEC * SLOTS;
     const int64_t img = blockIdx.y;
-    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * kTile;
-    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * kTile;   // elements of this image from tile start
-    constexpr int S = Slots<VEC>::n;
-    Pack<VEC> pg[S], pv[S], pm[S], pd[S], px[S];
-    bool full[S];
+    const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * TILE;
+    const int64_t left = e - static_cast<int64_t>(blockIdx.x) * TILE;   // elements of this image from tile start
+    Pack<VEC> pg[SLOTS], pv[SLOTS], pm[SLOTS], pd[SLOTS], px[SLOTS];
+    bool full[SLOTS];
 #pragma unroll
-    for (int u = 0; u < S; ++u) {
-        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+    for (int u = 0; u < SLOTS; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * BLOCK + threadIdx.x) * VEC;
         full[u] = off + VEC <= left;
         if (full[u]) {
-            pg[u].load(g + base + off);
-            if (HAS_V) pv[u].load(v + base + off);
-            if (HAS_MIN) pm[u].load(m_in + base + off);
-            pd[u].load(delta + base + off);
-            px[u].load(x + base + off);
+            if (NT) {
+                pg[u].load_nt(g + base + off);
+                if (HAS_V) pv[u].load_nt(v + base + off);
+                if (HAS_MIN) pm[u].load_nt(m_in + base + off);
+                pd[u].load_nt(delta + base + off);
+                px[u].load_nt(x + base + off);
+            } else {
+                pg[u].load(g + base + off);
+                if (HAS_V) pv[u].load(v + base + off);
+                if (HAS_MIN) pm[u].load(m_in + base + off);
+                pd[u].load(delta + base + off);
+                px[u].load(x + base + off);
+            }
         }
     }
-    const float mean = image_total(ws, img, tiles) / static_cast<float>(e);   // sum then div_ (ATen mean)
+    const float mean = image_total(ws, img, tiles_ws) / static_cast<float>(e);   // sum then div_ (ATen mean)
 #pragma unroll
-    for (int u = 0; u < S; ++u) {
-        const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+    for (int u = 0; u < SLOTS; ++u) {
+        const int64_t off = (static_cast<int64_t>(u) * BLOCK + threadIdx.x) * VEC;
         if (full[u]) {
             Pack<VEC> om, od, oa;
 #pragma unroll
@@ -173,9 +187,14 @@ __global__ __launch_bounds__(kBlock) void mi_update_kernel(
                 od[k] = d;
                 oa[k] = px[u][k] + d;
             }
-            if (HAS_MOUT) om.store(m_out + base + off);
-            od.store(delta + base + off);
-            if (HAS_XADV) oa.store(x_adv + base + off);
+            if (NT) {
+                if (HAS_MOUT) om.store_nt(m_out + base + off);
+                od.store_nt(delta + base + off);
+            } else {
+                if (HAS_MOUT) om.store(m_out + base + off);
+                od.store(delta + base + off);
+            }
+            if (HAS_XADV) oa.store(x_adv + base + off);      // read again by the next kernel: keep cacheable
         } else if (VEC > 1) {
             for (int64_t i = off; i < left && i < off + VEC; ++i) {
                 const float gg = HAS_V ? g[base + i] + v[base + i] : g[base + i];
@@ -463,34 +482,38 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!partials_ready)
         if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
-    const int tiles = static_cast<int>(ceil_div(e, kTile));
-    const dim3 grid(tiles, static_cast<unsigned>(n));
+    const int tiles_ws = static_cast<int>(ceil_div(e, kTile));
     const StepParams p{decay, alpha, -eps, eps};
     const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
+    // stream past the caches only when one launch moves more than the Infinity Cache can hold
+    const bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
-#define TA_MI(VEC, HV, HMI, HMO, HXA)                                                                   \
-    hipLaunchKernelGGL((mi_update_kernel<VEC, HV, HMI, HMO, HXA>), grid, dim3(kBlock), 0, st, g, v, m_in, \
-                       m_out, delta, x, x_adv, ws, p, e, tiles)
-#define TA_MI_CASES(VEC)                                   \
-    switch (key) {                                         \
-        case 0: TA_MI(VEC, false, false, false, false); break; \
-        case 1: TA_MI(VEC, false, false, false, true); break;  \
-        case 2: TA_MI(VEC, false, false, true, false); break;  \
-        case 3: TA_MI(VEC, false, false, true, true); break;   \
-        case 4: TA_MI(VEC, false, true, false, false); break;  \
-        case 5: TA_MI(VEC, false, true, false, true); break;   \
-        case 6: TA_MI(VEC, false, true, true, false); break;   \
-        case 7: TA_MI(VEC, false, true, true, true); break;    \
-        case 8: TA_MI(VEC, true, false, false, false); break;  \
-        case 9: TA_MI(VEC, true, false, false, true); break;   \
-        case 10: TA_MI(VEC, true, false, true, false); break;  \
-        case 11: TA_MI(VEC, true, false, true, true); break;   \
-        case 12: TA_MI(VEC, true, true, false, false); break;  \
-        case 13: TA_MI(VEC, true, true, false, true); break;   \
-        case 14: TA_MI(VEC, true, true, true, false); break;   \
-        default: TA_MI(VEC, true, true, true, true); break;    \
+#define TA_MI(VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA)                                                         \
+    hipLaunchKernelGGL((mi_update_kernel<VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA>),                            \
+                       dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),  \
+                       dim3(BLOCK), 0, st, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws)
+#define TA_MI_CASES(VEC, BLOCK, SLOTS, NT)                                   \
+    switch (key) {                                                           \
+        case 0: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, false, false); break; \
+        case 1: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, false, true); break;  \
+        case 2: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, true, false); break;  \
+        case 3: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, true, true); break;   \
+        case 4: TA_MI(VEC, BLOCK, SLOTS, NT, false, true, false, false); break;  \
+        case 5: TA_MI(VEC, BLOCK, SLOTS, NT, false, true, false, true); break;   \
+        case 6: TA_MI(VEC, BLOCK, SLOTS, NT, false, true, true, false); break;   \
+        case 7: TA_MI(VEC, BLOCK, SLOTS, NT, false, true, true, true); break;    \
+        case 8: TA_MI(VEC, BLOCK, SLOTS, NT, true, false, false, false); break;  \
+        case 9: TA_MI(VEC, BLOCK, SLOTS, NT, true, false, false, true); break;   \
+        case 10: TA_MI(VEC, BLOCK, SLOTS, NT, true, false, true, false); break;  \
+        case 11: TA_MI(VEC, BLOCK, SLOTS, NT, true, false, true, true); break;   \
+        case 12: TA_MI(VEC, BLOCK, SLOTS, NT, true, true, false, false); break;  \
+        case 13: TA_MI(VEC, BLOCK, SLOTS, NT, true, true, false, true); break;   \
+        case 14: TA_MI(VEC, BLOCK, SLOTS, NT, true, true, true, false); break;   \
+        default: TA_MI(VEC, BLOCK, SLOTS, NT, true, true, true, true); break;    \
     }
-    if (vec) { TA_MI_CASES(4) } else { TA_MI_CASES(1) }
+    if (vec && nt) { TA_MI_CASES(4, kK2Block, 1, true) }
+    else if (vec) { TA_MI_CASES(4, kK2Block, 1, false) }
+    else { TA_MI_CASES(1, kBlock, kTile / kBlock, false) }
 #undef TA_MI_CASES
 #undef TA_MI
     return check_launch("mi_update");

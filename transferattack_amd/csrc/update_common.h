@@ -4,11 +4,23 @@
 
 namespace ta {
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
 template <int VEC> struct Pack;
 template <> struct Pack<4> {
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    // streaming (non-temporal) forms: the operand is touched once per launch, do not keep it in L2 / MALL
+    __device__ __forceinline__ void load_nt(const float* p) {
+        const floatx4 t = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(p));
+        v = make_float4(t.x, t.y, t.z, t.w);
+    }
+    __device__ __forceinline__ void store_nt(float* p) const {
+        floatx4 t;
+        t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<floatx4*>(p));
+    }
     __device__ __forceinline__ float& operator[](int i) { return (&v.x)[i]; }
     __device__ __forceinline__ float operator[](int i) const { return (&v.x)[i]; }
 };
@@ -16,6 +28,8 @@ template <> struct Pack<1> {
     float v;
     __device__ __forceinline__ void load(const float* p) { v = *p; }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ void load_nt(const float* p) { v = *p; }
+    __device__ __forceinline__ void store_nt(float* p) const { *p = v; }
     __device__ __forceinline__ float& operator[](int) { return v; }
     __device__ __forceinline__ float operator[](int) const { return v; }
 };
