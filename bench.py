@@ -207,8 +207,10 @@ def main():
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "update_path": "single-launch" if args.single_launch else "two-launch",
                        "parallelism": "image-shard x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "ta_mi_update (abs_sum_partials + mi_update)" if not args.single_launch
-                         else "ta_mi_update_fused", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": ("ta_mi_update_fused" if args.single_launch else
+                                    "ta_mi_update (mi_update_kernel; |g| tile sums produced by ta_normalize_bwd)"
+                                    if _hip.stats["k1_passes"] == 0 else
+                                    "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
                          "algorithmic_bytes_per_launch": BYTES_PER_ELEM * e_ * n_,

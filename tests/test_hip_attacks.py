@@ -144,9 +144,12 @@ def test_variants_run_on_gpu(golden):
     g = golden("loops_toy")
     x, label = t(g["x_u8"]).float() / 255, t(g["label"])
     before = dict(_hip.stats)
-    make("mifgsm")(x, label)                                              # plain MI-FGSM: the normalize backward
-    assert _hip.stats["partials_reused"] - before["partials_reused"] == 10   # feeds all 10 fused updates, no K1 pass
+    x224 = u8_images(2, 224, 9).float() / 255                             # 224 px: no resize in PreprocessingModel, so
+    make("mifgsm")(x224, label[:2])                                       # the Normalize backward is the producer of g
+    assert _hip.stats["partials_reused"] - before["partials_reused"] == 10   # and feeds all 10 fused updates: no K1 pass
     assert _hip.stats["k1_passes"] == before["k1_passes"]
+    make("mifgsm")(x, label)                                              # 32 px -> resized to 224: bilinear backward is
+    assert _hip.stats["k1_passes"] - before["k1_passes"] == 10            # the producer, the update runs its own K1
     d = make("mifgsm", targeted=True)(x, [label, t(g["target"])])
     assert float(d.abs().max()) <= EPS + 1e-7
     atk = make("mifgsm", random_start=True)
