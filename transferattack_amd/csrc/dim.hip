@@ -37,13 +37,18 @@ constexpr int kDimMaxSide = 1024;       // LDS tables are sized for sides up to 
 
 // ---------------------------------------------------------------------------------------- forward
 constexpr int kDimFwdTile = 32;         // 32 x 32 outputs per workgroup, 4 per lane
+constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of the padded image; resize/size <= ~2.4
 
+// Two stages through LDS: (1) the window of the zero-padded, rescaled image that this output tile touches is
+// computed once per pixel (4 taps of x each) into LDS; (2) every output pixel blends 4 LDS values.  Each padded pixel
+// is evaluated once per tile instead of up to 4 times, and no intermediate ever reaches HBM.
 __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          int size, int resize, int rnd, int top, int left,
                                                          int tiles_per_side) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
     Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
+    float* mid = reinterpret_cast<float*>(t1 + rnd);     // [mh][mw] padded-image window
     for (int o = threadIdx.x; o < size; o += kBlock) t2[o] = make_tap(o, resize, size);
     for (int o = threadIdx.x; o < rnd; o += kBlock) t1[o] = make_tap(o, size, rnd);
     __syncthreads();
@@ -52,20 +57,28 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
     const int64_t plane = blockIdx.x / tiles;
     const int t = blockIdx.x % tiles;
     const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
+    const int oy1 = min(oy0 + kDimFwdTile, size) - 1, ox1 = min(ox0 + kDimFwdTile, size) - 1;
     const float* xp = x + plane * static_cast<int64_t>(size) * size;
     float* yp = y + plane * static_cast<int64_t>(size) * size;
 
-    // value of the zero-padded, rescaled image at (py, px)
-    auto padded = [&](int py, int px) -> float {
+    const int py_lo = t2[oy0].i0, py_hi = t2[oy1].i1, px_lo = t2[ox0].i0, px_hi = t2[ox1].i1;   // taps are monotone
+    const int mh = py_hi - py_lo + 1, mw = px_hi - px_lo + 1;                                     // <= kDimFwdMaxMid
+
+    for (int idx = threadIdx.x; idx < mh * mw; idx += kBlock) {
+        const int py = py_lo + idx / mw, px = px_lo + idx % mw;
         const int ry = py - top, rx = px - left;
-        if (ry < 0 || ry >= rnd || rx < 0 || rx >= rnd) return 0.0f;
-        const Tap ty = t1[ry], tx = t1[rx];
-        const float* r0 = xp + static_cast<int64_t>(ty.i0) * size;
-        const float* r1 = xp + static_cast<int64_t>(ty.i1) * size;
-        const float a = fmaf(tx.l0, r0[tx.i0], tx.l1 * r0[tx.i1]);
-        const float b = fmaf(tx.l0, r1[tx.i0], tx.l1 * r1[tx.i1]);
-        return fmaf(ty.l0, a, ty.l1 * b);
-    };
+        float val = 0.0f;                                                  // the zero padding of dim.py:65
+        if (ry >= 0 && ry < rnd && rx >= 0 && rx < rnd) {
+            const Tap ty = t1[ry], tx = t1[rx];
+            const float* r0 = xp + static_cast<int64_t>(ty.i0) * size;
+            const float* r1 = xp + static_cast<int64_t>(ty.i1) * size;
+            const float a = fmaf(tx.l0, r0[tx.i0], tx.l1 * r0[tx.i1]);
+            const float b = fmaf(tx.l0, r1[tx.i0], tx.l1 * r1[tx.i1]);
+            val = fmaf(ty.l0, a, ty.l1 * b);
+        }
+        mid[idx] = val;
+    }
+    __syncthreads();
 
 #pragma unroll
     for (int u = 0; u < kDimFwdTile * kDimFwdTile / kBlock; ++u) {
@@ -73,8 +86,10 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
         const int oy = oy0 + local / kDimFwdTile, ox = ox0 + local % kDimFwdTile;
         if (oy >= size || ox >= size) continue;
         const Tap ty = t2[oy], tx = t2[ox];
-        const float a = fmaf(tx.l0, padded(ty.i0, tx.i0), tx.l1 * padded(ty.i0, tx.i1));
-        const float b = fmaf(tx.l0, padded(ty.i1, tx.i0), tx.l1 * padded(ty.i1, tx.i1));
+        const float* m0 = mid + (ty.i0 - py_lo) * mw - px_lo;
+        const float* m1 = mid + (ty.i1 - py_lo) * mw - px_lo;
+        const float a = fmaf(tx.l0, m0[tx.i0], tx.l1 * m0[tx.i1]);
+        const float b = fmaf(tx.l0, m1[tx.i0], tx.l1 * m1[tx.i1]);
         yp[static_cast<int64_t>(oy) * size + ox] = fmaf(ty.l0, a, ty.l1 * b);
     }
 }
@@ -204,7 +219,10 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     const int tps = static_cast<int>(ceil_div(size, kDimFwdTile));
     const int64_t blocks = planes * tps * tps;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
-    const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd);
+    // a 32-pixel output tile reads at most this many padded pixels per axis
+    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimFwdTile) * resize, size)) + 3;
+    TA_REQUIRE(mid_side <= kDimFwdMaxMid, "resize ratio %d/%d too large for the fused forward", resize, size);
+    const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * mid_side * mid_side;
     hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
                        static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps);
     return check_launch("dim_fwd");

@@ -27,7 +27,7 @@ constexpr int conv_lds_stride(int k) {
     return s;
 }
 
-template <int K>
+template <int K, bool FAST_LOAD>
 __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __restrict__ in,
                                                              float* __restrict__ out,
                                                              const float* __restrict__ w, int h, int wd,
@@ -45,12 +45,44 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
     const int x0 = (t % tiles_x) * kConvTW;
     const float* ip = in + plane * static_cast<int64_t>(h) * wd;
 
-    for (int idx = threadIdx.x; idx < LH * LW; idx += kBlock) {
-        const int r = idx / LW, c = idx - r * LW;
-        const int gy = y0 + r - LO, gx = x0 + c - LO;
-        float v = 0.0f;
-        if (gy >= 0 && gy < h && gx >= 0 && gx < wd) v = ip[static_cast<int64_t>(gy) * wd + gx];
-        tile[r * LS + c] = v;
+    if (FAST_LOAD) {
+        // wd <= 224, wd % 4 == 0, 16-byte aligned rows (the 224 x 224 case): the left/right halo is pure zero
+        // padding, the interior is fetched with 16-byte loads -- ALL of a lane's loads are issued before the first
+        // LDS write, so the window arrives in one HBM/L2 round trip instead of one per element.
+        constexpr int Q = kConvTW / 4;                       // 16-byte groups per row
+        constexpr int PER_LANE = (LH * Q + kBlock - 1) / kBlock;
+        const int quads = wd / 4;
+        float4 v[PER_LANE];
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int idx = j * kBlock + threadIdx.x;
+            const int r = idx / Q, q = idx - r * Q;
+            const int gy = y0 + r - LO;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < LH && q < quads && gy >= 0 && gy < h)
+                v[j] = *reinterpret_cast<const float4*>(ip + static_cast<int64_t>(gy) * wd + q * 4);
+        }
+        for (int idx = threadIdx.x; idx < LH * (K - 1); idx += kBlock) {     // zero the two halo strips
+            const int r = idx / (K - 1), c = idx - r * (K - 1);
+            tile[r * LS + (c < LO ? c : kConvTW + c)] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < PER_LANE; ++j) {
+            const int idx = j * kBlock + threadIdx.x;
+            const int r = idx / Q, q = idx - r * Q;
+            if (r < LH) {
+                float* dst = &tile[r * LS + LO + q * 4];
+                dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < LH * LW; idx += kBlock) {
+            const int r = idx / LW, c = idx - r * LW;
+            const int gy = y0 + r - LO, gx = x0 + c - LO;
+            float v = 0.0f;
+            if (gy >= 0 && gy < h && gx >= 0 && gx < wd) v = ip[static_cast<int64_t>(gy) * wd + gx];
+            tile[r * LS + c] = v;
+        }
     }
     __syncthreads();
 
@@ -60,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < kConvPT; ++r) acc[r] = 0.0f;
 
-#pragma unroll 1      // one kernel row at a time: 14 + k - 1 window registers, not k of them
+#pragma unroll 1      // one kernel row at a time (full unrolling spills: the compiler hoists all 15 windows)
     for (int ky = 0; ky < K; ++ky) {
         float win[kConvPT + K - 1 + 1];
         const float2* lp = reinterpret_cast<const float2*>(&tile[(row + ky) * LS + xg * kConvPT]);
@@ -150,10 +182,16 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
     const int64_t blocks = planes * tiles_x * tiles_y;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
     const dim3 grid(static_cast<unsigned>(blocks));
+    const bool fast = w_ <= kConvTW && w_ % 4 == 0 && aligned16(in) && (static_cast<int64_t>(h) * w_) % 4 == 0;
     switch (k) {
-#define TA_CONV(KK)                                                                                             \
-    case KK:                                                                                                    \
-        hipLaunchKernelGGL(dwconv_same_kernel<KK>, grid, dim3(kBlock), 0, st, in, out, w, h, w_, tiles_x, tiles_y); \
+#define TA_CONV(KK)                                                                                          \
+    case KK:                                                                                                 \
+        if (fast)                                                                                            \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, true>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,  \
+                               tiles_x, tiles_y);                                                            \
+        else                                                                                                 \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_, \
+                               tiles_x, tiles_y);                                                            \
         break;
         TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
 #undef TA_CONV
