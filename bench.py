@@ -149,7 +149,8 @@ def main():
     _hip.load()
     torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
     Attack.single_launch_update = bool(args.single_launch)
-    attacker = ta.load_attack_class(args.attack)(model_name=args.model)
+    model_name = args.model.split(",") if "," in args.model else args.model      # list -> EnsembleModel, as main.py:39-40
+    attacker = ta.load_attack_class(args.attack)(model_name=model_name)
     dev = attacker.device
 
     total = args.steps + args.warmup
@@ -210,9 +211,10 @@ def main():
             "config": {"fold_bn": os.environ.get("TA_FOLD_BN", "0") == "1",
                        "images_per_step": args.batch,
                        "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
-                       "workload": "configs[1]: MI-FGSM on ResNet-50 (seeded random init), eps=16/255, alpha=1.6/255, "
-                                   "K=10, synthetic 3x224x224, batches of %d, image-sharded over %d GPU(s)"
-                                   % (args.batch, world),
+                       "workload": "%s on %s (seeded random init), eps=16/255, alpha=1.6/255, K=10, synthetic "
+                                   "3x224x224, batches of %d, image-sharded over %d GPU(s)"
+                                   % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
+                                      args.batch, world),
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "update_path": "single-launch" if args.single_launch else "two-launch",
                        "parallelism": "image-shard x%d, no collective" % world},

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
     Tap* t1 = t2 + size;                                         // [rnd]     rescaled   -> x index
     Range* inv2 = reinterpret_cast<Range*>(t1 + rnd);            // [resize]  padded idx -> out pixels touching it
     Range* inv1 = inv2 + resize;                                 // [size]    x index    -> rescaled pixels touching it
-    float* mid = reinterpret_cast<float*>(inv1 + size);          // [kDimBwdMaxMid^2] d(rescaled) window
+    float* mid = reinterpret_cast<float*>(inv1 + size);          // [mh][mw] d(rescaled) window (host-sized)
 
     for (int i = threadIdx.x; i < resize; i += kBlock) inv2[i] = Range{INT_MAX, -1};
     for (int i = threadIdx.x; i < size; i += kBlock) inv1[i] = Range{INT_MAX, -1};
@@ -238,8 +238,9 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, 
     const int tps = static_cast<int>(ceil_div(size, kDimBwdTile));
     const int64_t blocks = planes * tps * tps;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
+    // LDS is sized for the window this geometry needs (not the 80 x 80 worst case): ~18 KB at 224/246 -> 8 workgroups/CU
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(Range) * (static_cast<size_t>(resize) + size) +
-                        sizeof(float) * kDimBwdMaxMid * kDimBwdMaxMid;
+                        sizeof(float) * mid_side * mid_side;
     hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
                        static_cast<hipStream_t>(stream), gy, gx, size, resize, rnd, top, left, tps);
     return check_launch("dim_bwd");
