@@ -12,6 +12,7 @@
 // window per kernel row (14 ds_read_b64 per 14*k FMAs).  The LDS row stride is == 32 (mod 64) dwords, the
 // only residue for which the 32 lanes of a ds_read_b64 group (16 column groups x 2 rows, 14-dword pitch)
 // fall on distinct bank pairs.  Weights are wave-uniform -> scalar loads.
+#include <stdlib.h>
 #include "ta_common.h"
 
 namespace ta {
@@ -21,13 +22,15 @@ constexpr int kConvPT = 14;        // outputs per lane
 constexpr int kConvXG = 16;        // lanes across a row
 constexpr int kConvTW = kConvPT * kConvXG;   // 224
 
+constexpr bool kTimPipelinedDefault = false;
+
 constexpr int conv_lds_stride(int k) {
     int s = kConvTW + k - 1;
     while (s % 64 != 32) ++s;
     return s;
 }
 
-template <int K, bool FAST_LOAD>
+template <int K, bool FAST_LOAD, bool PIPELINED>
 __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __restrict__ in,
                                                              float* __restrict__ out,
                                                              const float* __restrict__ w, int h, int wd,
@@ -92,9 +95,11 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < kConvPT; ++r) acc[r] = 0.0f;
 
-#pragma unroll 1      // one kernel row at a time (full unrolling spills: the compiler hoists all 15 windows)
-    for (int ky = 0; ky < K; ++ky) {
-        float win[kConvPT + K - 1 + 1];
+    // Software-pipelined over kernel rows with two register sets: while row ky is being multiplied, the LDS window
+    // and the 15 scalar weights of row ky+1 are already in flight, so a wave never stalls on lgkmcnt at the top of a
+    // row (full unrolling would let the compiler hoist all 15 windows and spill).  Tap order is unchanged.
+    constexpr int WN = kConvPT + K - 1 + 1;
+    auto load_window = [&](float (&win)[WN], int ky) {
         const float2* lp = reinterpret_cast<const float2*>(&tile[(row + ky) * LS + xg * kConvPT]);
 #pragma unroll
         for (int j = 0; j < (kConvPT + K) / 2; ++j) {
@@ -102,11 +107,40 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
             win[2 * j] = v.x;
             win[2 * j + 1] = v.y;
         }
+    };
+    auto load_weights = [&](float (&wk)[K], int ky) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const float wv = w[ky * K + kx];
+        for (int kx = 0; kx < K; ++kx) wk[kx] = w[ky * K + kx];
+    };
+    auto fma_row = [&](const float (&win)[WN], const float (&wk)[K]) {
 #pragma unroll
-            for (int r = 0; r < kConvPT; ++r) acc[r] = fmaf(wv, win[r + kx], acc[r]);
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int r = 0; r < kConvPT; ++r) acc[r] = fmaf(wk[kx], win[r + kx], acc[r]);
+    };
+    if constexpr (PIPELINED) {
+        float win_a[WN], win_b[WN], wk_a[K], wk_b[K];
+        load_window(win_a, 0);
+        load_weights(wk_a, 0);
+#pragma unroll 1
+        for (int ky = 0; ky + 1 < K; ky += 2) {
+            load_window(win_b, ky + 1);
+            load_weights(wk_b, ky + 1);
+            fma_row(win_a, wk_a);
+            if (ky + 2 < K) {
+                load_window(win_a, ky + 2);
+                load_weights(wk_a, ky + 2);
+            }
+            fma_row(win_b, wk_b);
+        }
+        if (K % 2 == 1) fma_row(win_a, wk_a);        // odd K: the last row was loaded by the final loop trip (or is row 0)
+    } else {
+#pragma unroll 1      // one kernel row at a time (full unrolling spills: the compiler hoists all 15 windows)
+        for (int ky = 0; ky < K; ++ky) {
+            float win[WN], wk[K];
+            load_window(win, ky);
+            load_weights(wk, ky);
+            fma_row(win, wk);
         }
     }
 
@@ -183,15 +217,22 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
     const dim3 grid(static_cast<unsigned>(blocks));
     const bool fast = w_ <= kConvTW && w_ % 4 == 0 && aligned16(in) && (static_cast<int64_t>(h) * w_) % 4 == 0;
+    static const bool pipelined = []() {                 // TA_TIM_PIPELINED=0/1 selects the row schedule (tuning knob)
+        const char* e = getenv("TA_TIM_PIPELINED");
+        return e == nullptr ? kTimPipelinedDefault : e[0] == '1';
+    }();
     switch (k) {
-#define TA_CONV(KK)                                                                                          \
-    case KK:                                                                                                 \
-        if (fast)                                                                                            \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, true>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,  \
-                               tiles_x, tiles_y);                                                            \
-        else                                                                                                 \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_, \
-                               tiles_x, tiles_y);                                                            \
+#define TA_CONV(KK)                                                                                                 \
+    case KK:                                                                                                        \
+        if (fast && pipelined)                                                                                      \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, true, true>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,   \
+                               tiles_x, tiles_y);                                                                   \
+        else if (fast)                                                                                              \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, true, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,  \
+                               tiles_x, tiles_y);                                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, false, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_, \
+                               tiles_x, tiles_y);                                                                   \
         break;
         TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
 #undef TA_CONV
