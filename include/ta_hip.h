@@ -109,6 +109,8 @@ int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize,
  */
 int ta_scale_copies_fwd(const float* x, float* y, int64_t n, int64_t e, int num_scale, void* stream);
 int ta_scale_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_scale, void* stream);
+/* gx[b] = sum_i gy[i*n + b], i descending: backward of EMI-FGSM's stack of x + c_i*alpha*g_bar (emifgsm.py:57-58) */
+int ta_sum_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int copies, void* stream);
 int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
                  int num_scale, float strength, void* stream);
 int ta_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale,

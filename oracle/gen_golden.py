@@ -195,6 +195,24 @@ def gen_loops():
     save("loops_toy", **out)
 
 
+def gen_loops_more():
+    """further gradient-family attacks riding on the same kernels -- whole loops by the
+    reference's own classes on the toy CNN (same inputs / seeds as gen_loops)."""
+    ref_shim.neutralise_cuda_calls()                       # pifgsm.py:52 builds its kernel with .cuda()
+    n, size = 4, 32
+    x = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    out = {}
+    for name, kw in (("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}), ("gra", dict(num_neighbor=5)),
+                     ("pgn", dict(num_neighbor=4))):
+        atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False), **kw)
+        torch.manual_seed(1234)
+        out["delta_" + name] = atk(x, label)
+    atk = ref_shim.make_reference_attack("pifgsm", backbones.create("toy_cnn", seed=3, verbose=False), decay=1.0)
+    out["delta_mpifgsm"] = atk(x, label)
+    save("loops_more", **out)
+
+
 def gen_config1():
     """BASELINE.json configs[0]: I-FGSM on ResNet-18, 16 images, eps=16/255, K=10, CPU reference path."""
     n = 16
@@ -211,6 +229,6 @@ def gen_config1():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "config1"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "config1"]
     for w in which:
         globals()["gen_" + w]()

@@ -73,6 +73,12 @@ def _install_stubs():
         sys.modules["timm"] = timm
 
 
+def neutralise_cuda_calls():
+    """A few reference classes hard-code ``.cuda()`` on freshly built tensors (e.g. gradient/pifgsm.py:52).  For
+    golden generation on the CPU box make the call the identity; nothing else about the class is touched."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
 def import_reference():
     """Return the reference's ``transferattack`` package (imported from REFERENCE_ROOT)."""
     if not reference_available():

@@ -87,6 +87,15 @@ def scale_copies_bwd(gy, gx, num_scale):
     gx.copy_(res)
 
 
+def sum_copies_bwd(gy, gx, copies):
+    calls.append("sum_copies_bwd")
+    parts = gy.view((copies,) + tuple(gx.shape))
+    acc = parts[copies - 1].clone()
+    for i in range(copies - 2, -1, -1):
+        acc = acc + parts[i]
+    gx.copy_(acc)
+
+
 def admix_fwd(x, perm, y, num_admix, num_scale, strength):
     calls.append("admix_fwd")
     y.copy_(O.admix_copies(x, list(perm.view(num_admix, -1)), strength, num_scale))
@@ -143,7 +152,7 @@ def quantize_u8_nhwc(data, delta, out):
 
 
 _NAMES = ["momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
-          "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "admix_fwd",
+          "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd"]
 

@@ -140,6 +140,21 @@ def test_end_to_end_gpu_vs_reference(golden, name):
     assert asr_gpu == asr_ref
 
 
+@pytest.mark.parametrize("name,kw", [("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}),
+                                     ("gra", dict(num_neighbor=5)), ("pgn", dict(num_neighbor=4))])
+def test_more_gradient_attacks_gpu_vs_reference(golden, name, kw):
+    """SURVEY 8(f) rank 3 on the GPU: PI / EMI / IE-FGSM, GNP, GRA, PGN end to end against the reference's golden."""
+    g, base = golden("loops_more"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    atk = make(name, **kw)
+    torch.manual_seed(1234)
+    delta = atk(x, label).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
+    print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
+    assert mismatch <= 0.05
+
+
 def test_variants_run_on_gpu(golden):
     g = golden("loops_toy")
     x, label = t(g["x_u8"]).float() / 255, t(g["label"])

@@ -289,6 +289,17 @@ def test_sim_admix_golden(golden):
     assert np.array_equal(host(gx), g["admix_gx"])
 
 
+def test_sum_copies_bwd():
+    gen = torch.Generator().manual_seed(4)
+    for shape, copies in (((3, 3, 224, 224), 11), ((2, 3, 7, 9), 5), ((1, 1, 1, 5), 2)):
+        gy = torch.randn((copies * shape[0],) + shape[1:], generator=gen)
+        x = torch.zeros(shape, requires_grad=True)
+        ref = torch.autograd.grad(torch.cat([x + float(i) for i in range(copies)]), x, gy)[0]    # autograd's own order
+        gx = torch.empty(shape, device=DEV)
+        _hip.sum_copies_bwd(gy.to(DEV), gx, copies)
+        assert np.array_equal(host(gx), ref.numpy())
+
+
 def test_sim_admix_ragged():
     gen = torch.Generator().manual_seed(1)
     for shape in ((3, 3, 224, 224), (2, 3, 7, 9), (1, 1, 1, 5)):

@@ -166,3 +166,26 @@ def test_abi_symbols_exported():
     assert lib.ta_abi_version() == _hip.ABI_VERSION == 2
     assert lib.ta_l1_workspace_floats(32, 150528) == 2 * 32 * 49
     assert lib.ta_fused_sync_bytes(32, 150528) >= 32 * 49 * 8
+
+
+# ------------------------------------------------------------------ wider gradient family
+MORE = [("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}), ("gra", dict(num_neighbor=5)),
+        ("pgn", dict(num_neighbor=4))]
+
+
+@pytest.mark.parametrize("name,kw", MORE)
+def test_more_gradient_attacks_match_reference(golden, monkeypatch, name, kw):
+    """PI / EMI / IE-FGSM, GNP, GRA (tensor-valued step), PGN: the product's loops over the same hooks reproduce the
+    REAL reference's perturbations bit for bit (kernels replaced by the oracle-backed fake)."""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_more"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    torch.manual_seed(1234)
+    delta = make(name, **kw)(x, label)
+    assert np.array_equal(delta.numpy(), g["delta_" + name])
+    if name == "gra":
+        assert "update_delta_linf" in fake_hip.calls          # per-element step -> hook path, not the fused one
+    if name == "pifgsm":
+        assert "depthwise_conv2d_same" in fake_hip.calls      # projection kernel = the TIM conv kernel, k = 3
+        d = make("pifgsm", decay=1.0)(x, label)               # MPI-FGSM
+        assert np.array_equal(d.numpy(), g["delta_mpifgsm"])

@@ -17,6 +17,12 @@ attack_zoo = {
     'nifgsm': ('.gradient.nifgsm', 'NIFGSM'),
     'vmifgsm': ('.gradient.vmifgsm', 'VMIFGSM'),
     'vnifgsm': ('.gradient.vnifgsm', 'VNIFGSM'),
+    'pifgsm': ('.gradient.pifgsm', 'PIFGSM'),
+    'emifgsm': ('.gradient.emifgsm', 'EMIFGSM'),
+    'iefgsm': ('.gradient.iefgsm', 'IEFGSM'),
+    'gra': ('.gradient.gra', 'GRA'),
+    'gnp': ('.gradient.gnp', 'GNP'),
+    'pgn': ('.gradient.pgn', 'PGN'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),

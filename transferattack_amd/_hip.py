@@ -45,6 +45,7 @@ SIGNATURES = {
     "ta_dim_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_scale_copies_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
+    "ta_sum_copies_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_admix_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _f32, _vp]),
     "ta_admix_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp]),
     "ta_vmi_neighbor": (_int, [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
@@ -296,6 +297,12 @@ def scale_copies_bwd(gy, gx, num_scale):
     n, e = _batch(gx)
     _check(load().ta_scale_copies_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, num_scale, _stream()),
            "ta_scale_copies_bwd")
+
+
+def sum_copies_bwd(gy, gx, copies):
+    n, e = _batch(gx)
+    _check(load().ta_sum_copies_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, copies, _stream()),
+           "ta_sum_copies_bwd")
 
 
 def admix_fwd(x, perm, y, num_admix, num_scale, strength):

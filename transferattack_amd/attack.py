@@ -62,7 +62,9 @@ class Attack(object):
             if os.environ.get("TA_FOLD_BN", "0") == "1":
                 backbones.fold_batchnorm(model)     # opt-in: eval-mode BN folded into the convolutions
             wrapped = wrap_model(model.eval().to(default_device()))
-            if os.environ.get("TA_CHANNELS_LAST", "0") == "1":
+            # NHWC is opt-in and skipped for Inception-v3: on ROCm 7.2 the NHWC fp32 backward-data kernels fault on
+            # its asymmetric 1x7 / 7x1 convolutions (profiles/r01/ens_diag/inc_nhwc.txt)
+            if os.environ.get("TA_CHANNELS_LAST", "0") == "1" and "Inc" not in model.__class__.__name__:
                 wrapped = wrapped.to(memory_format=torch.channels_last)
             return wrapped
 
@@ -172,6 +174,29 @@ class Attack(object):
 
     def transform(self, data, **kwargs):
         return data
+
+    # ------------------------------------------------------------------------------- helpers for subclasses
+    def _to_device(self, data, label):
+        """The prologue every ``forward`` of the reference repeats (attack.py:76-80)."""
+        if self.targeted:
+            assert len(label) == 2
+            label = label[1]
+        return data.clone().detach().to(self.device), label.clone().detach().to(self.device)
+
+    def l1_normalize(self, grad):
+        """grad / mean_{CHW}|grad| -- the normalisation inside get_momentum, used on its own by several
+        gradient attacks (e.g. gnp.py:74, iefgsm.py:70, emifgsm.py:98); same HIP kernels as get_momentum."""
+        grad = grad.contiguous()
+        out = torch.empty_like(grad)
+        _hip.momentum(grad, None, out, 1.0)
+        return out
+
+    def _uniform_like(self, data, radius):
+        """Noise tensor for neighbour sampling when a test injects the reference's CPU draws, else None (the HIP
+        kernel then draws from its Philox stream)."""
+        if self.noise_source is None:
+            return None
+        return self.noise_source(data.shape, -radius, radius).to(self.device).contiguous()
 
     def _next_offset(self):
         self.rng_offset += 1

@@ -110,6 +110,24 @@ __global__ __launch_bounds__(kBlock) void scale_copies_bwd_kernel(const float* _
     });
 }
 
+// gx = sum_i gy_i accumulated i = copies-1 .. 0: backward of a stack of `copies` unit-gain views of x
+// (EMI-FGSM's sample stack, emifgsm.py:57-58), in the order autograd's input buffer adds them
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void sum_copies_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                int64_t ne, int copies) {
+    for_tile<VEC>(ne, [&](int64_t i, auto vec) {
+        if constexpr (decltype(vec)::value) {
+            float4 acc = ld4(gy + (copies - 1) * ne + i);
+            for (int c = copies - 2; c >= 0; --c) acc = add4(acc, ld4(gy + c * ne + i));
+            st4(gx + i, acc);
+        } else {
+            float acc = gy[(copies - 1) * ne + i];
+            for (int c = copies - 2; c >= 0; --c) acc += gy[c * ne + i];
+            gx[i] = acc;
+        }
+    });
+}
+
 // ---- Admix --------------------------------------------------------------------------------------
 // grid (tiles, n): one image per blockIdx.y so the permuted partner row is a single indirection
 template <bool VEC>
@@ -321,6 +339,17 @@ extern "C" int ta_scale_copies_bwd(const float* gy, float* gx, int64_t n, int64_
     else
         hipLaunchKernelGGL(scale_copies_bwd_kernel<false>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, num_scale);
     return check_launch("scale_copies_bwd");
+}
+
+extern "C" int ta_sum_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int copies, void* stream) {
+    TA_REQUIRE(gy && gx && n > 0 && e > 0 && copies > 0, "bad arguments");
+    const int64_t ne = n * e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ne % 4 == 0 && all16({gy, gx}))
+        hipLaunchKernelGGL(sum_copies_bwd_kernel<true>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, copies);
+    else
+        hipLaunchKernelGGL(sum_copies_bwd_kernel<false>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, copies);
+    return check_launch("sum_copies_bwd");
 }
 
 extern "C" int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
