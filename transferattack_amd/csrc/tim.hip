@@ -22,7 +22,7 @@ constexpr int kConvPT = 14;        // outputs per lane
 constexpr int kConvXG = 16;        // lanes across a row
 constexpr int kConvTW = kConvPT * kConvXG;   // 224
 
-constexpr bool kTimPipelinedDefault = false;
+constexpr bool kTimPipelinedDefault = true;    // +9 % at N=32, equal at N=160 (profiles/r01/tim_variants.txt)
 
 constexpr int conv_lds_stride(int k) {
     int s = kConvTW + k - 1;
