@@ -12,6 +12,7 @@ len(models) ranks holds one surrogate each and exchanges logits / input-gradient
 """
 import argparse
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import tqdm
@@ -41,6 +42,7 @@ def get_parser():
     parser.add_argument('--targeted', action='store_true', help='targeted attack')
     parser.add_argument('--GPU_ID', default='0', type=str)
     parser.add_argument('--seed', default=0, type=int, help='base seed of the per-batch host RNG (DIM / Admix draws)')
+    parser.add_argument('--io_threads', default=4, type=int, help='host threads decoding / encoding PNGs')
     return parser.parse_args()
 
 
@@ -55,8 +57,11 @@ def main():
     dataset = AdvDataset(input_dir=args.input_dir, output_dir=args.output_dir, targeted=args.targeted, eval=args.eval)
     num_batches = (len(dataset) + args.batchsize - 1) // args.batchsize
 
+    decoders = ThreadPoolExecutor(max_workers=args.io_threads)        # PNG decode (PIL releases the GIL)
+
     def batch(idx):
-        items = [dataset[i] for i in range(idx * args.batchsize, min((idx + 1) * args.batchsize, len(dataset)))]
+        lo, hi = idx * args.batchsize, min((idx + 1) * args.batchsize, len(dataset))
+        items = list(decoders.map(dataset.__getitem__, range(lo, hi)))
         images = torch.stack([it[0] for it in items])
         if args.targeted:
             labels = [torch.tensor([it[1][0] for it in items]), torch.tensor([it[1][1] for it in items])]
@@ -83,12 +88,23 @@ def main():
         else:
             attacker = transferattack.load_attack_class(args.attack)(model_name=args.model, targeted=args.targeted)
             writer = True
-        for batch_idx in tqdm.tqdm(tadist.shard_batches(num_batches, shard_rank, shard_world), disable=rank != 0):
-            images, labels, filenames = batch(batch_idx)
+        # three-stage software pipeline: batch i+1 is decoded and batch i-1 is quantised / PNG-encoded on host
+        # threads while batch i runs on the GPU (the reference decodes in DataLoader workers and writes inline)
+        mine = tadist.shard_batches(num_batches, shard_rank, shard_world)
+        io = ThreadPoolExecutor(max_workers=2)
+        pending_write, next_batch = None, io.submit(batch, mine[0]) if mine else None
+        for pos, batch_idx in enumerate(tqdm.tqdm(mine, disable=rank != 0)):
+            images, labels, filenames = next_batch.result()
+            if pos + 1 < len(mine):
+                next_batch = io.submit(batch, mine[pos + 1])
             tadist.seed_batch(args.seed, batch_idx)
             perturbations = attacker(images, labels)
+            if pending_write is not None:
+                pending_write.result()
             if writer:
-                save_images(args.output_dir, images, filenames, perturbations=perturbations)
+                pending_write = io.submit(save_images, args.output_dir, images, filenames, perturbations)
+        if pending_write is not None:
+            pending_write.result()
     elif rank == 0:
         res = '|'
         for model_name, model in load_pretrained_model(cnn_model_paper, vit_model_paper):

@@ -144,8 +144,13 @@ def save_images(output_dir, adversaries, filenames, perturbations=None):
     if perturbations is None:
         perturbations = torch.zeros_like(adversaries)
     arr = quantize_images(adversaries, perturbations)
-    for i, filename in enumerate(filenames):
-        Image.fromarray(arr[i]).save(os.path.join(output_dir, filename))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def write(i):
+        Image.fromarray(arr[i]).save(os.path.join(output_dir, filenames[i]))
+
+    with ThreadPoolExecutor(max_workers=4) as pool:            # zlib releases the GIL: PNG encodes run in parallel
+        list(pool.map(write, range(len(filenames))))
 
 
 class EnsembleModel(nn.Module):
