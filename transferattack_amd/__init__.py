@@ -23,6 +23,9 @@ attack_zoo = {
     'gra': ('.gradient.gra', 'GRA'),
     'gnp': ('.gradient.gnp', 'GNP'),
     'pgn': ('.gradient.pgn', 'PGN'),
+    'gifgsm': ('.gradient.gifgsm', 'GIFGSM'),
+    'dta': ('.gradient.dta', 'DTA'),
+    'pcifgsm': ('.gradient.pcifgsm', 'PCIFGSM'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),

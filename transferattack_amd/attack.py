@@ -103,7 +103,7 @@ class Attack(object):
         return (self.norm == 'linfty' and cls.get_momentum is Attack.get_momentum
                 and cls.update_delta is Attack.update_delta and not isinstance(self.alpha, torch.Tensor))
 
-    def _fused_update(self, grad, momentum, delta, data, variance=None):
+    def _fused_update(self, grad, momentum, delta, data, variance=None, alpha=None):
         """get_momentum + update_delta in one pass; ``delta`` (a leaf) is updated in place -- the graph of
         this iteration has already been consumed by ``get_grad``.  Returns the new momentum tensor."""
         grad = grad.contiguous()
@@ -111,8 +111,8 @@ class Attack(object):
         m_out = m_in if m_in is not None else torch.empty_like(grad)
         if variance is not None and not isinstance(variance, torch.Tensor):
             variance = None                                   # the Python 0 of the first VMI iteration
-        _hip.mi_update(grad, m_in, m_out, delta.detach(), data, self.decay, self.alpha, self.epsilon,
-                       variance=variance, single_launch=self.single_launch_update)
+        _hip.mi_update(grad, m_in, m_out, delta.detach(), data, self.decay, self.alpha if alpha is None else alpha,
+                       self.epsilon, variance=variance, single_launch=self.single_launch_update)
         return m_out
 
     # ------------------------------------------------------------------------------------------ hooks
