@@ -210,6 +210,18 @@ def gen_loops_more():
         out["delta_" + name] = atk(x, label)
     atk = ref_shim.make_reference_attack("pifgsm", backbones.create("toy_cnn", seed=3, verbose=False), decay=1.0)
     out["delta_mpifgsm"] = atk(x, label)
+    # per-member ensemble attacks on EnsembleModel.models[k] (random start: CPU generator;
+    # SVRE's member choice: numpy generator)
+    for name in ("svre", "cwa"):
+        members = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+        ta = ref_shim.import_reference()
+        from transferattack.utils import wrap_model, EnsembleModel
+        base = ta.load_attack_class(name)
+        cls = type("Ref_" + name, (base,), {"load_model": lambda self, mn: EnsembleModel([wrap_model(m.eval()) for m in members])})
+        atk = cls(model_name=["a", "b"])
+        torch.manual_seed(1234)
+        np.random.seed(99)
+        out["delta_" + name] = atk(x, label)
     save("loops_more", **out)
 
 

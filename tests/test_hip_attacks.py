@@ -256,3 +256,25 @@ def test_main_cli_roundtrip(tmp_path, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["main.py", "--input_dir", str(inp), "--output_dir", str(out), "--eval"])
     cli.main()
     assert "|" in open(tmp_path / "results_eval.txt").read()
+
+
+@pytest.mark.parametrize("name", ["svre", "cwa"])
+def test_per_member_ensemble_attacks_gpu(golden, name):
+    """SURVEY 8(f) rank 4 on the GPU: SVRE / CWA over EnsembleModel.models[k] vs the reference's golden result."""
+    g, base = golden("loops_more"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    cls = ta.load_attack_class(name)
+
+    def load_model(self, model_name):
+        return EnsembleModel([wrap_model(m.eval().to(DEV)) for m in models])
+
+    atk = type("Gpu" + cls.__name__, (cls,), {"load_model": load_model})(model_name=["a", "b"])
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    torch.manual_seed(1234)
+    np.random.seed(99)
+    delta = atk(x, label).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
+    print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
+    assert mismatch <= 0.05

@@ -189,3 +189,23 @@ def test_more_gradient_attacks_match_reference(golden, monkeypatch, name, kw):
         assert "depthwise_conv2d_same" in fake_hip.calls      # projection kernel = the TIM conv kernel, k = 3
         d = make("pifgsm", decay=1.0)(x, label)               # MPI-FGSM
         assert np.array_equal(d.numpy(), g["delta_mpifgsm"])
+
+
+@pytest.mark.parametrize("name", ["svre", "cwa"])
+def test_per_member_ensemble_attacks_match_reference(golden, monkeypatch, name):
+    """SVRE / CWA index EnsembleModel.models[k]; random start and member choice follow the
+    reference's host generators; negative step (cwa.py:69) goes through the update_delta hook."""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_more"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    cls = ta.load_attack_class(name)
+
+    def load_model(self, model_name):
+        return EnsembleModel([wrap_model(m.eval()) for m in models])
+
+    atk = type("Cpu" + cls.__name__, (cls,), {"load_model": load_model})(model_name=["a", "b"])
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    torch.manual_seed(1234)
+    np.random.seed(99)
+    assert np.array_equal(atk(x, label).numpy(), g["delta_" + name])

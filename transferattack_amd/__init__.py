@@ -34,6 +34,8 @@ attack_zoo = {
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
     # ensemble
     'ens': ('.ensemble.ens', 'ENS'),
+    'svre': ('.ensemble.svre', 'SVRE'),
+    'cwa': ('.ensemble.cwa', 'CWA'),
 }
 
 
