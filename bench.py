@@ -150,7 +150,9 @@ def main():
     torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
     Attack.single_launch_update = bool(args.single_launch)
     model_name = args.model.split(",") if "," in args.model else args.model      # list -> EnsembleModel, as main.py:39-40
-    attacker = ta.load_attack_class(args.attack)(model_name=model_name)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):              # stdout carries exactly one line: the JSON result
+        attacker = ta.load_attack_class(args.attack)(model_name=model_name)
     dev = attacker.device
 
     total = args.steps + args.warmup
