@@ -23,8 +23,8 @@ batches)
 kernels)
   timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
 timvariants)
-  for v in 0 1; do TA_TIM_PIPELINED=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('pipelined=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
-  TA_TIM_PIPELINED=1 timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2 ;;
+  for v in 0 1 2; do TA_TIM_VARIANT=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('variant=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
+  TA_TIM_VARIANT=2 timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2 ;;
 k2sweep)
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
 fast)

@@ -22,7 +22,7 @@ constexpr int kConvPT = 14;        // outputs per lane
 constexpr int kConvXG = 16;        // lanes across a row
 constexpr int kConvTW = kConvPT * kConvXG;   // 224
 
-constexpr bool kTimPipelinedDefault = true;    // +9 % at N=32, equal at N=160 (profiles/r01/tim_variants.txt)
+constexpr int kTimVariantDefault = 1;           // pipelined: +9 % at N=32, equal at N=160 (profiles/r01/tim_variants.txt)
 
 constexpr int conv_lds_stride(int k) {
     int s = kConvTW + k - 1;
@@ -30,21 +30,22 @@ constexpr int conv_lds_stride(int k) {
     return s;
 }
 
-template <int K, bool FAST_LOAD, bool PIPELINED>
-__global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __restrict__ in,
+template <int K, int TH, bool FAST_LOAD, bool PIPELINED>
+__global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* __restrict__ in,
                                                              float* __restrict__ out,
                                                              const float* __restrict__ w, int h, int wd,
                                                              int tiles_x, int tiles_y) {
     constexpr int LO = (K - 1) / 2;
     constexpr int LW = kConvTW + K - 1;
-    constexpr int LH = kConvTH + K - 1;
+    constexpr int LH = TH + K - 1;
+    constexpr int NT = TH * kConvXG;                   // lanes of the workgroup
     constexpr int LS = conv_lds_stride(K);
     __shared__ __attribute__((aligned(16))) float tile[LH * LS];
 
     const int tiles = tiles_x * tiles_y;
     const int64_t plane = blockIdx.x / tiles;
     const int t = blockIdx.x % tiles;
-    const int y0 = (t / tiles_x) * kConvTH;
+    const int y0 = (t / tiles_x) * TH;
     const int x0 = (t % tiles_x) * kConvTW;
     const float* ip = in + plane * static_cast<int64_t>(h) * wd;
 
@@ -53,25 +54,25 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
         // padding, the interior is fetched with 16-byte loads -- ALL of a lane's loads are issued before the first
         // LDS write, so the window arrives in one HBM/L2 round trip instead of one per element.
         constexpr int Q = kConvTW / 4;                       // 16-byte groups per row
-        constexpr int PER_LANE = (LH * Q + kBlock - 1) / kBlock;
+        constexpr int PER_LANE = (LH * Q + NT - 1) / NT;
         const int quads = wd / 4;
         float4 v[PER_LANE];
 #pragma unroll
         for (int j = 0; j < PER_LANE; ++j) {
-            const int idx = j * kBlock + threadIdx.x;
+            const int idx = j * NT + threadIdx.x;
             const int r = idx / Q, q = idx - r * Q;
             const int gy = y0 + r - LO;
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < LH && q < quads && gy >= 0 && gy < h)
                 v[j] = *reinterpret_cast<const float4*>(ip + static_cast<int64_t>(gy) * wd + q * 4);
         }
-        for (int idx = threadIdx.x; idx < LH * (K - 1); idx += kBlock) {     // zero the two halo strips
+        for (int idx = threadIdx.x; idx < LH * (K - 1); idx += NT) {     // zero the two halo strips
             const int r = idx / (K - 1), c = idx - r * (K - 1);
             tile[r * LS + (c < LO ? c : kConvTW + c)] = 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < PER_LANE; ++j) {
-            const int idx = j * kBlock + threadIdx.x;
+            const int idx = j * NT + threadIdx.x;
             const int r = idx / Q, q = idx - r * Q;
             if (r < LH) {
                 float* dst = &tile[r * LS + LO + q * 4];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_kernel(const float* __rest
             }
         }
     } else {
-        for (int idx = threadIdx.x; idx < LH * LW; idx += kBlock) {
+        for (int idx = threadIdx.x; idx < LH * LW; idx += NT) {
             const int r = idx / LW, c = idx - r * LW;
             const int gy = y0 + r - LO, gx = x0 + c - LO;
             float v = 0.0f;
@@ -217,25 +218,27 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
     const dim3 grid(static_cast<unsigned>(blocks));
     const bool fast = w_ <= kConvTW && w_ % 4 == 0 && aligned16(in) && (static_cast<int64_t>(h) * w_) % 4 == 0;
-    static const bool pipelined = []() {                 // TA_TIM_PIPELINED=0/1 selects the row schedule (tuning knob)
-        const char* e = getenv("TA_TIM_PIPELINED");
-        return e == nullptr ? kTimPipelinedDefault : e[0] == '1';
+    // TA_TIM_VARIANT (tuning knob): 0 = 16-row tiles, rolled rows; 1 = 16-row tiles, software-pipelined rows;
+    // 2 = 14-row tiles (224 lanes, 32.3 KB LDS -> 5 workgroups per CU), rolled rows
+    static const int variant = []() {
+        const char* e = getenv("TA_TIM_VARIANT");
+        return e == nullptr ? kTimVariantDefault : atoi(e);
     }();
     switch (k) {
-#define TA_CONV(KK)                                                                                                 \
-    case KK:                                                                                                        \
-        if (fast && pipelined)                                                                                      \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, true, true>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,   \
-                               tiles_x, tiles_y);                                                                   \
-        else if (fast)                                                                                              \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, true, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_,  \
-                               tiles_x, tiles_y);                                                                   \
-        else                                                                                                        \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, false, false>), grid, dim3(kBlock), 0, st, in, out, w, h, w_, \
-                               tiles_x, tiles_y);                                                                   \
+#define TA_CONV_LAUNCH(KK, TH, FAST, PIPE)                                                                     \
+    hipLaunchKernelGGL((dwconv_same_kernel<KK, TH, FAST, PIPE>), dim3(static_cast<unsigned>(planes * tiles_x *   \
+                       ceil_div(h, TH))), dim3(TH * kConvXG), 0, st, in, out, w, h, w_, tiles_x,                \
+                       static_cast<int>(ceil_div(h, TH)))
+#define TA_CONV(KK)                                                                                  \
+    case KK:                                                                                         \
+        if (fast && variant == 2) { TA_CONV_LAUNCH(KK, 14, true, false); }                           \
+        else if (fast && variant == 1) { TA_CONV_LAUNCH(KK, 16, true, true); }                       \
+        else if (fast) { TA_CONV_LAUNCH(KK, 16, true, false); }                                      \
+        else { TA_CONV_LAUNCH(KK, 16, false, false); }                                               \
         break;
         TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
 #undef TA_CONV
+#undef TA_CONV_LAUNCH
         default: {
             const int ls = conv_lds_stride(k);
             const size_t smem = sizeof(float) * (static_cast<size_t>(kConvTH + k - 1) * ls + k * k);
