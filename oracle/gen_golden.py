@@ -204,7 +204,7 @@ def gen_loops_more():
     label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
     out = {}
     for name, kw in (("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}), ("gra", dict(num_neighbor=5)),
-                     ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {})):
+                     ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {}), ("smifgrm", dict(num_neighbor=4))):
         atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False), **kw)
         torch.manual_seed(1234)
         out["delta_" + name] = atk(x, label)

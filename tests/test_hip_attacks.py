@@ -141,7 +141,7 @@ def test_end_to_end_gpu_vs_reference(golden, name):
 
 
 @pytest.mark.parametrize("name,kw", [("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}),
-                                     ("gra", dict(num_neighbor=5)), ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {})])
+                                     ("gra", dict(num_neighbor=5)), ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {}), ("smifgrm", dict(num_neighbor=4))])
 def test_more_gradient_attacks_gpu_vs_reference(golden, name, kw):
     """SURVEY 8(f) rank 3 on the GPU: PI / EMI / IE-FGSM, GNP, GRA, PGN end to end against the reference's golden."""
     g, base = golden("loops_more"), golden("loops_toy")

@@ -170,7 +170,7 @@ def test_abi_symbols_exported():
 
 # ------------------------------------------------------------------ wider gradient family
 MORE = [("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}), ("gra", dict(num_neighbor=5)),
-        ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {})]
+        ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {}), ("smifgrm", dict(num_neighbor=4))]
 
 
 @pytest.mark.parametrize("name,kw", MORE)

@@ -26,6 +26,7 @@ attack_zoo = {
     'gifgsm': ('.gradient.gifgsm', 'GIFGSM'),
     'dta': ('.gradient.dta', 'DTA'),
     'pcifgsm': ('.gradient.pcifgsm', 'PCIFGSM'),
+    'smifgrm': ('.gradient.smifgrm', 'SMIFGRM'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
