@@ -209,3 +209,33 @@ def test_per_member_ensemble_attacks_match_reference(golden, monkeypatch, name):
     torch.manual_seed(1234)
     np.random.seed(99)
     assert np.array_equal(atk(x, label).numpy(), g["delta_" + name])
+
+
+def test_adv_dataset_matches_reference_decoding(tmp_path):
+    """AdvDataset (utils.py:108-153): labels.csv + images/*.png -> fp32 CHW in [0,1] (uint8/255, resized to 224),
+    untargeted int label or [label, target]; eval mode reads the PNGs back from the output directory."""
+    import csv
+    from PIL import Image
+    from transferattack_amd.utils import AdvDataset
+    inp, out = tmp_path / "data", tmp_path / "adv"
+    (inp / "images").mkdir(parents=True)
+    out.mkdir()
+    rng = np.random.RandomState(0)
+    imgs = [rng.randint(0, 256, (224, 224, 3), dtype=np.uint8), rng.randint(0, 256, (100, 60, 3), dtype=np.uint8)]
+    with open(inp / "labels.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["filename", "label", "targeted_label"])
+        for i, im in enumerate(imgs):
+            Image.fromarray(im).save(inp / "images" / ("%d.png" % i))
+            Image.fromarray(im).save(out / ("%d.png" % i))
+            w.writerow(["%d.png" % i, 10 + i, 20 + i])
+    ds = AdvDataset(input_dir=str(inp), output_dir=str(out))
+    assert len(ds) == 2
+    x, label, name = ds[0]
+    assert name == "0.png" and label == 10 and x.dtype == torch.float32 and tuple(x.shape) == (3, 224, 224)
+    assert np.array_equal((x.permute(1, 2, 0).numpy() * 255).round().astype(np.uint8), imgs[0])
+    assert tuple(ds[1][0].shape) == (3, 224, 224)                      # non-224 inputs are resized like the reference
+    tds = AdvDataset(input_dir=str(inp), output_dir=str(out), targeted=True)
+    assert tds[1][1] == [11, 21]
+    eds = AdvDataset(input_dir=str(inp), output_dir=str(out), eval=True)
+    assert torch.equal(eds[0][0], x)
