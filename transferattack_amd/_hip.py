@@ -17,7 +17,6 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TA_HIP_LIB", os.path.join(_HERE, "lib", "libta_hip.so"))
 
-_c_f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _int = ctypes.c_int
 _f32 = ctypes.c_float
