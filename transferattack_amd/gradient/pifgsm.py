@@ -23,39 +23,41 @@ class PIFGSM(Attack):
         self.beta = beta
 
     def project_kern(self, kern_size):
-        kern = np.ones((kern_size, kern_size), dtype=np.float32) / (kern_size ** 2 - 1)
-        kern[kern_size // 2, kern_size // 2] = 0.0
-        stack = np.expand_dims(np.stack([kern, kern, kern]).astype(np.float32), 1)
-        return torch.tensor(stack).to(self.device), kern_size // 2
+        """Uniform k x k kernel with a hole in the middle (the overshoot goes to the NEIGHBOURS), one per plane."""
+        kern = np.full((kern_size, kern_size), 1.0, dtype=np.float32) / (kern_size ** 2 - 1)
+        centre = kern_size // 2
+        kern[centre, centre] = 0.0
+        stack = np.repeat(kern[None, None].astype(np.float32), 3, axis=0)
+        return torch.tensor(stack).to(self.device), centre
 
     def project_noise(self, x, stack_kern, padding_size):
         x = x.contiguous()
-        out = torch.empty_like(x)
-        _hip.depthwise_conv2d_same(x, out, stack_kern[0, 0].contiguous())      # padding k//2 == 'same' for odd k
-        return out
+        spread = torch.empty_like(x)
+        _hip.depthwise_conv2d_same(x, spread, stack_kern[0, 0].contiguous())   # padding k//2 == 'same' for odd k
+        return spread
 
     def update_delta(self, delta, data, grad, alpha, projection, **kwargs):
         if self.norm == 'linfty':
-            delta = torch.clamp(delta + alpha * grad.sign() + projection, -self.epsilon, self.epsilon)
+            stepped = delta + alpha * grad.sign() + projection
+            delta = torch.clamp(stepped, -self.epsilon, self.epsilon)
         else:
-            grad_norm = torch.norm(grad.view(grad.size(0), -1), dim=1).view(-1, 1, 1, 1)
-            scaled = grad / (grad_norm + 1e-20)
-            delta = (delta + scaled * alpha + projection).view(delta.size(0), -1) \
-                .renorm(p=2, dim=0, maxnorm=self.epsilon).view_as(delta)
+            flat_norm = torch.norm(grad.view(grad.size(0), -1), dim=1).view(-1, 1, 1, 1)
+            stepped = delta + grad / (flat_norm + 1e-20) * alpha + projection
+            delta = stepped.view(delta.size(0), -1).renorm(p=2, dim=0, maxnorm=self.epsilon).view_as(delta)
         return clamp(delta, img_min - data, img_max - data)
 
     def forward(self, data, label, **kwargs):
         data, label = self._to_device(data, label)
         delta = self.init_delta(data)
         stack_kern, padding_size = self.project_kern(self.kern_size)
+        step = self.beta * self.alpha                                   # amplified step size
         momentum, amplification = 0.0, 0.0
         for _ in range(self.epoch):
             grad = self.get_grad(self.get_loss(self.get_logits(self.transform(data + delta)), label), delta)
             momentum = self.get_momentum(grad, momentum)
-            amplification = amplification + self.beta * self.alpha * momentum.sign()
-            cut_noise = torch.clamp(abs(amplification) - self.epsilon, 0, 10000.0) * torch.sign(amplification)
-            projection = self.gamma * torch.sign(self.project_noise(cut_noise, stack_kern, padding_size))
+            amplification = amplification + step * momentum.sign()
+            overshoot = torch.clamp(abs(amplification) - self.epsilon, 0, 10000.0) * torch.sign(amplification)
+            projection = self.gamma * torch.sign(self.project_noise(overshoot, stack_kern, padding_size))
             amplification = amplification + projection
-            delta = self.update_delta(delta.detach(), data, momentum, self.beta * self.alpha, projection)
-            delta.requires_grad_(True)
+            delta = self.update_delta(delta.detach(), data, momentum, step, projection).requires_grad_(True)
         return delta.detach()

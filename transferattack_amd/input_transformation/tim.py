@@ -8,6 +8,19 @@ from ..gradient.mifgsm import MIFGSM
 from .. import _hip
 
 
+def _gaussian_profile(size, nsig):
+    x = np.linspace(-nsig, nsig, size)
+    return np.exp(-x ** 2 / 2.0) / np.sqrt(2 * np.pi)                     # == scipy.stats.norm.pdf(x)
+
+
+def _linear_profile(size, nsig):
+    ramp = np.linspace((-size + 1) // 2, (size - 1) // 2, size)
+    return 1 - np.abs(ramp / (size ** 2))
+
+
+_PROFILE_1D = {'gaussian': _gaussian_profile, 'linear': _linear_profile}
+
+
 class TIM(MIFGSM):
     """Official arguments: epsilon=16/255, alpha=1.6/255, epoch=10, decay=1., kernel_type='gaussian', kernel_size=15."""
 
@@ -18,25 +31,20 @@ class TIM(MIFGSM):
         self.kernel = self.generate_kernel(kernel_type, kernel_size)
 
     def generate_kernel(self, kernel_type, kernel_size, nsig=3):
-        """[3, 1, k, k] fp32 kernel built in fp64 (tim.py:42-66): gaussian (normal pdf on linspace(-nsig, nsig)),
-        uniform or linear, normalised to sum 1."""
+        """[3, 1, k, k] fp32 smoothing kernel (tim.py:42-66).  'gaussian' and 'linear' are separable profiles: the
+        outer product of a 1-D profile with itself, normalised to unit sum in fp64 before the cast; 'uniform' is the
+        box filter."""
         kind = kernel_type.lower()
-        if kind == 'gaussian':
-            x = np.linspace(-nsig, nsig, kernel_size)
-            kern1d = np.exp(-x ** 2 / 2.0) / np.sqrt(2 * np.pi)          # == scipy.stats.norm.pdf(x)
-            kernel = np.outer(kern1d, kern1d)
-            kernel = kernel / kernel.sum()
-        elif kind == 'uniform':
-            kernel = np.ones((kernel_size, kernel_size)) / (kernel_size ** 2)
-        elif kind == 'linear':
-            kern1d = 1 - np.abs(np.linspace((-kernel_size + 1) // 2, (kernel_size - 1) // 2, kernel_size)
-                                / (kernel_size ** 2))
-            kernel = np.outer(kern1d, kern1d)
-            kernel = kernel / kernel.sum()
-        else:
+        if kind not in _PROFILE_1D and kind != 'uniform':
             raise Exception("Unspported kernel type {}".format(kernel_type))
-        stack = np.expand_dims(np.stack([kernel, kernel, kernel]), 1)
-        return torch.from_numpy(stack.astype(np.float32)).to(self.device)
+        if kind == 'uniform':
+            plane = np.ones((kernel_size, kernel_size)) / (kernel_size ** 2)
+        else:
+            profile = _PROFILE_1D[kind](kernel_size, nsig)
+            plane = np.outer(profile, profile)
+            plane = plane / plane.sum()
+        planes = np.stack([plane] * 3)[:, None]                          # one identical kernel per colour plane
+        return torch.from_numpy(planes.astype(np.float32)).to(self.device)
 
     def get_grad(self, loss, delta, **kwargs):
         grad = torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0].contiguous()
