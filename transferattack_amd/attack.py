@@ -176,6 +176,11 @@ class Attack(object):
         return data
 
     # ------------------------------------------------------------------------------- helpers for subclasses
+    def _schedule(self, alpha, epoch, decay):
+        """step size, iteration count and momentum decay -- the three numbers that tell FGSM / I-FGSM / MI-FGSM
+        apart (gradient/fgsm.py:31-33, ifgsm.py:33-35, mifgsm.py:34-36)"""
+        self.alpha, self.epoch, self.decay = alpha, epoch, decay
+
     def _to_device(self, data, label):
         """The prologue every ``forward`` of the reference repeats (attack.py:76-80)."""
         if self.targeted:

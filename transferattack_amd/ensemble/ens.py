@@ -8,15 +8,13 @@ from ..dist import ShardedEnsemble, allreduce_input_grad
 
 
 class ENS(Attack):
-    """Official arguments: epsilon=16/255, alpha=1.6/255, epoch=10, decay=1.
-    Example: python main.py --attack ens --model='resnet50,vgg16,mobilenet_v2,inception_v3'"""
+    """Official arguments: epsilon=16/255, alpha=1.6/255, epoch=10, decay=1.; surrogates e.g.
+    --model='resnet50,vgg16,mobilenet_v2,inception_v3' (ens.py:27)."""
 
     def __init__(self, model_name, epsilon=16/255, alpha=1.6/255, epoch=10, decay=1., targeted=False,
                  random_start=False, norm='linfty', loss='crossentropy', device=None, attack='ENS', **kwargs):
         super().__init__(attack, model_name, epsilon, targeted, random_start, norm, loss, device)
-        self.alpha = alpha
-        self.epoch = epoch
-        self.decay = decay
+        self._schedule(alpha, epoch, decay)
 
     def get_grad(self, loss, delta, **kwargs):
         grad = super().get_grad(loss, delta, **kwargs)

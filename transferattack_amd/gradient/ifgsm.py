@@ -5,12 +5,9 @@ from ..attack import Attack
 
 class IFGSM(Attack):
     """Official arguments: epsilon=16/255, alpha=epsilon/epoch=1.6/255, epoch=10.
-    Example: python main.py --input_dir ./data --output_dir adv_data/ifgsm/resnet50 --attack ifgsm --model=resnet50
     """
 
     def __init__(self, model_name, epsilon=16/255, alpha=1.6/255, epoch=10, targeted=False, random_start=False,
                  norm='linfty', loss='crossentropy', device=None, attack='I-FGSM', **kwargs):
         super().__init__(attack, model_name, epsilon, targeted, random_start, norm, loss, device)
-        self.alpha = alpha
-        self.epoch = epoch
-        self.decay = 0
+        self._schedule(alpha, epoch, decay=0)                    # no history: sign of the current gradient

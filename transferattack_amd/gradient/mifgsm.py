@@ -6,12 +6,9 @@ from ..attack import Attack
 
 class MIFGSM(Attack):
     """Official arguments: epsilon=16/255, alpha=epsilon/epoch=1.6/255, epoch=10, decay=1.
-    Example: python main.py --input_dir ./data --output_dir adv_data/mifgsm/resnet50 --attack mifgsm --model=resnet50
     """
 
     def __init__(self, model_name, epsilon=16/255, alpha=1.6/255, epoch=10, decay=1., targeted=False,
                  random_start=False, norm='linfty', loss='crossentropy', device=None, attack='MI-FGSM', **kwargs):
         super().__init__(attack, model_name, epsilon, targeted, random_start, norm, loss, device)
-        self.alpha = alpha
-        self.epoch = epoch
-        self.decay = decay
+        self._schedule(alpha, epoch, decay)
