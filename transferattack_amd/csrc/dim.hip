@@ -13,6 +13,7 @@
 // The 1-D tap tables (and, for the backward, the inverse "which outputs touch this source index" ranges)
 // are rebuilt in LDS by every workgroup: <= 250 entries, cheaper than a host round trip per iteration.
 #include <limits.h>
+#include <stdlib.h>
 #include "ta_common.h"
 
 namespace ta {
@@ -37,6 +38,7 @@ constexpr int kDimMaxSide = 1024;       // LDS tables are sized for sides up to 
 
 // ---------------------------------------------------------------------------------------- forward
 constexpr int kDimFwdTile = 32;         // 32 x 32 outputs per workgroup, 4 per lane
+constexpr int kDimFwdVariantDefault = 0;
 constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of the padded image; resize/size <= ~2.4
 
 // Two stages through LDS: (1) the window of the zero-padded, rescaled image that this output tile touches is
@@ -92,6 +94,80 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
         const float b = fmaf(tx.l0, m1[tx.i0], tx.l1 * m1[tx.i1]);
         yp[static_cast<int64_t>(oy) * size + ox] = fmaf(ty.l0, a, ty.l1 * b);
     }
+}
+
+// Separable form of the same forward (bit-identical: ATen's bilinear IS "width first, then height").  Four passes
+// over LDS-resident rectangles, each lane bound to one COLUMN so its horizontal tap pair lives in registers and the
+// vertical tap pair is wave-uniform: ~6 instructions per produced value instead of ~40, no div/mod by runtime sizes.
+//   H1  T[r][c]   = fma(lx0, x[r][i0], lx1 * x[r][i1])          rows of x behind the window, window columns
+//   V1  mid[p][c] = fma(ly0, T[i0][c], ly1 * T[i1][c])  (or 0)   the zero-padded, rescaled window
+//   H2  u[p][ox]  = fma(lx0, mid[p][i0], lx1 * mid[p][i1])       window rows, the tile's 32 output columns
+//   V2  y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
+__global__ __launch_bounds__(kBlock) void dim_fwd_sep_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int size, int resize, int rnd, int top, int left,
+                                                             int tiles_per_side, int ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
+    Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
+    float* T = reinterpret_cast<float*>(t1 + rnd);       // [ws][ws]
+    float* mid = T + ws * ws;                            // [ws][ws]
+    float* u = mid + ws * ws;                            // [ws][32]
+    for (int o = threadIdx.x; o < size; o += kBlock) t2[o] = make_tap(o, resize, size);
+    for (int o = threadIdx.x; o < rnd; o += kBlock) t1[o] = make_tap(o, size, rnd);
+    __syncthreads();
+
+    const int tiles = tiles_per_side * tiles_per_side;
+    const int64_t plane = blockIdx.x / tiles;
+    const int t = blockIdx.x % tiles;
+    const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
+    const int oy1 = min(oy0 + kDimFwdTile, size) - 1, ox1 = min(ox0 + kDimFwdTile, size) - 1;
+    const float* xp = x + plane * static_cast<int64_t>(size) * size;
+    float* yp = y + plane * static_cast<int64_t>(size) * size;
+    const int py_lo = t2[oy0].i0, py_hi = t2[oy1].i1, px_lo = t2[ox0].i0, px_hi = t2[ox1].i1;
+    const int mh = py_hi - py_lo + 1, mw = px_hi - px_lo + 1;                 // <= ws (host-checked)
+    // rows of the rescaled image inside the window, and the rows of x behind them
+    const int ry_a = max(py_lo - top, 0), ry_b = min(py_hi - top, rnd - 1);
+    const bool any_rows = ry_a <= ry_b;
+    const int sr_lo = any_rows ? t1[ry_a].i0 : 0;
+    const int sh = any_rows ? t1[ry_b].i1 - sr_lo + 1 : 0;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rx = px_lo + lane - left;
+    const bool col_ok = lane < mw && rx >= 0 && rx < rnd;
+    Tap tx{0, 0, 0.f, 0.f};
+    if (col_ok) tx = t1[rx];
+
+    if (col_ok)                                                               // H1
+        for (int r = wave; r < sh; r += kBlock / 64) {
+            const float* row = xp + (sr_lo + r) * size;
+            T[r * ws + lane] = fmaf(tx.l0, row[tx.i0], tx.l1 * row[tx.i1]);
+        }
+    __syncthreads();
+    if (lane < mw)                                                            // V1
+        for (int p = wave; p < mh; p += kBlock / 64) {
+            const int ry = py_lo + p - top;
+            float val = 0.0f;                                                 // the zero padding of dim.py:65
+            if (col_ok && ry >= 0 && ry < rnd) {
+                const Tap ty = t1[ry];
+                val = fmaf(ty.l0, T[(ty.i0 - sr_lo) * ws + lane], ty.l1 * T[(ty.i1 - sr_lo) * ws + lane]);
+            }
+            mid[p * ws + lane] = val;
+        }
+    __syncthreads();
+    const int ox = threadIdx.x & 31, grp = threadIdx.x >> 5;                  // 8 row groups x 32 output columns
+    const bool out_col = ox0 + ox <= ox1;
+    if (out_col) {                                                            // H2
+        const Tap tx2 = t2[ox0 + ox];
+        for (int p = grp; p < mh; p += kBlock / 32)
+            u[p * 32 + ox] = fmaf(tx2.l0, mid[p * ws + tx2.i0 - px_lo], tx2.l1 * mid[p * ws + tx2.i1 - px_lo]);
+    }
+    __syncthreads();
+    if (out_col)                                                              // V2
+        for (int ly = grp; oy0 + ly <= oy1; ly += kBlock / 32) {
+            const Tap ty2 = t2[oy0 + ly];
+            yp[(oy0 + ly) * size + ox0 + ox] =
+                fmaf(ty2.l0, u[(ty2.i0 - py_lo) * 32 + ox], ty2.l1 * u[(ty2.i1 - py_lo) * 32 + ox]);
+        }
 }
 
 // --------------------------------------------------------------------------------------- backward
@@ -222,6 +298,18 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     // a 32-pixel output tile reads at most this many padded pixels per axis
     const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimFwdTile) * resize, size)) + 3;
     TA_REQUIRE(mid_side <= kDimFwdMaxMid, "resize ratio %d/%d too large for the fused forward", resize, size);
+    // TA_DIM_FWD_VARIANT (tuning knob): 0 = 16-tap gather per window pixel, 1 = separable four-pass form
+    static const int variant = []() {
+        const char* e = getenv("TA_DIM_FWD_VARIANT");
+        return e == nullptr ? kDimFwdVariantDefault : atoi(e);
+    }();
+    if (variant == 1 && mid_side <= 64 && static_cast<int64_t>(size) * size < (1ll << 31)) {
+        const int ws = mid_side + 1;                     // the x rectangle can be one row taller than the window
+        const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * (2 * ws * ws + ws * 32);
+        hipLaunchKernelGGL(dim_fwd_sep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
+                           static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, ws);
+        return check_launch("dim_fwd_sep");
+    }
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * mid_side * mid_side;
     hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
                        static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps);
