@@ -135,3 +135,67 @@ def philox_uniform(numel, seed, offset, r):
     lib().ta_oracle_philox_uniform(out.ctypes.data_as(_f32p), ctypes.c_int64(numel), ctypes.c_uint64(seed),
                                    ctypes.c_uint64(offset), ctypes.c_float(r))
     return out
+
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def scale_copies_fwd(x, num_scale):
+    x, px = _f(x)
+    out = np.empty((num_scale * x.shape[0],) + x.shape[1:], dtype=np.float32)
+    lib().ta_oracle_scale_copies_fwd(px, out.ctypes.data_as(_f32p), ctypes.c_int64(x.size), num_scale)
+    return out
+
+
+def scale_copies_bwd(gy, num_scale):
+    gy, pg = _f(gy)
+    out = np.empty((gy.shape[0] // num_scale,) + gy.shape[1:], dtype=np.float32)
+    lib().ta_oracle_scale_copies_bwd(pg, out.ctypes.data_as(_f32p), ctypes.c_int64(out.size), num_scale)
+    return out
+
+
+def admix_fwd(x, perm, num_admix, num_scale, strength):
+    x, px = _f(x)
+    perm = np.ascontiguousarray(perm, dtype=np.int64)
+    n, e = x.shape[0], x[0].size
+    out = np.empty((num_scale * num_admix * n,) + x.shape[1:], dtype=np.float32)
+    lib().ta_oracle_admix_fwd(px, perm.ctypes.data_as(_i64p), out.ctypes.data_as(_f32p), ctypes.c_int64(n),
+                              ctypes.c_int64(e), num_admix, num_scale, ctypes.c_float(strength))
+    return out
+
+
+def admix_bwd(gy, num_admix, num_scale):
+    gy, pg = _f(gy)
+    n = gy.shape[0] // (num_admix * num_scale)
+    out = np.empty((n,) + gy.shape[1:], dtype=np.float32)
+    lib().ta_oracle_admix_bwd(pg, out.ctypes.data_as(_f32p), ctypes.c_int64(n), ctypes.c_int64(out[0].size),
+                              num_admix, num_scale)
+    return out
+
+
+def normalize_fwd(x, mean, std):
+    x, px = _f(x)
+    mean, pm = _f(mean)
+    std, ps = _f(std)
+    out = np.empty_like(x)
+    lib().ta_oracle_normalize_fwd(px, out.ctypes.data_as(_f32p), pm, ps, ctypes.c_int64(x.shape[0]), x.shape[1],
+                                  ctypes.c_int64(x[0, 0].size))
+    return out
+
+
+def normalize_bwd(gy, std):
+    gy, pg = _f(gy)
+    std, ps = _f(std)
+    out = np.empty_like(gy)
+    lib().ta_oracle_normalize_bwd(pg, out.ctypes.data_as(_f32p), ps, ctypes.c_int64(gy.shape[0]), gy.shape[1],
+                                  ctypes.c_int64(gy[0, 0].size))
+    return out
+
+
+def variance_finalize(acc, cur, count):
+    acc, pa = _f(acc)
+    cur, pc = _f(cur)
+    out = np.empty_like(acc)
+    lib().ta_oracle_variance_finalize(pa, pc, out.ctypes.data_as(_f32p), ctypes.c_float(count),
+                                      ctypes.c_int64(acc.size))
+    return out

@@ -254,3 +254,82 @@ void ta_oracle_philox_uniform(float* out, int64_t numel, uint64_t seed, uint64_t
             out[q * 4 + j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f) * (2.0f * r) - r;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SIM / Admix copy stacks and their backward (input_transformation/sim.py:36-40, admix.py:40-45).
+ * x / 2^i is an exact power-of-two scaling; the backward adds the slices in the order autograd's input buffer
+ * receives them: last-created node first (i, then j, descending).
+ * ---------------------------------------------------------------------------------------------- */
+void ta_oracle_scale_copies_fwd(const float* x, float* y, int64_t ne, int num_scale) {
+    float s = 1.0f;
+    for (int c = 0; c < num_scale; ++c, s *= 0.5f)
+        for (int64_t i = 0; i < ne; ++i) y[c * ne + i] = x[i] * s;
+}
+
+void ta_oracle_scale_copies_bwd(const float* gy, float* gx, int64_t ne, int num_scale) {
+    for (int64_t i = 0; i < ne; ++i) {
+        float s = ldexpf(1.0f, -(num_scale - 1));
+        float acc = gy[(int64_t)(num_scale - 1) * ne + i] * s;
+        for (int c = num_scale - 2; c >= 0; --c) {
+            s *= 2.0f;
+            acc += gy[(int64_t)c * ne + i] * s;
+        }
+        gx[i] = acc;
+    }
+}
+
+void ta_oracle_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
+                         int num_scale, float strength) {
+    for (int c = 0; c < num_scale; ++c) {
+        const float s = ldexpf(1.0f, -c);
+        for (int j = 0; j < num_admix; ++j)
+            for (int64_t b = 0; b < n; ++b) {
+                const float* xb = x + b * e;
+                const float* xp = x + perm[j * n + b] * e;
+                float* yo = y + (((int64_t)c * num_admix + j) * n + b) * e;
+                for (int64_t i = 0; i < e; ++i) yo[i] = (xb[i] + xp[i] * strength) * s;
+            }
+    }
+}
+
+void ta_oracle_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale) {
+    for (int64_t b = 0; b < n; ++b)
+        for (int64_t i = 0; i < e; ++i) {
+            float total = 0.0f;
+            for (int j = num_admix - 1; j >= 0; --j) {
+                float s = ldexpf(1.0f, -(num_scale - 1));
+                float acc = gy[(((int64_t)(num_scale - 1) * num_admix + j) * n + b) * e + i] * s;
+                for (int c = num_scale - 2; c >= 0; --c) {
+                    s *= 2.0f;
+                    acc += gy[(((int64_t)c * num_admix + j) * n + b) * e + i] * s;
+                }
+                total = (j == num_admix - 1) ? acc : total + acc;
+            }
+            gx[b * e + i] = total;
+        }
+}
+
+/* PreprocessingModel's Normalize and its backward (transferattack/utils.py:72-79): two roundings each way */
+void ta_oracle_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
+                             int64_t hw) {
+    for (int64_t b = 0; b < n; ++b)
+        for (int ch = 0; ch < c; ++ch)
+            for (int64_t i = 0; i < hw; ++i) {
+                const int64_t k = (b * c + ch) * hw + i;
+                y[k] = (x[k] - mean[ch]) / stdv[ch];
+            }
+}
+
+void ta_oracle_normalize_bwd(const float* gy, float* gx, const float* stdv, int64_t n, int c, int64_t hw) {
+    for (int64_t b = 0; b < n; ++b)
+        for (int ch = 0; ch < c; ++ch)
+            for (int64_t i = 0; i < hw; ++i) {
+                const int64_t k = (b * c + ch) * hw + i;
+                gx[k] = gy[k] / stdv[ch];
+            }
+}
+
+/* VMIFGSM.get_variance finalisation (gradient/vmifgsm.py:58): acc / N - cur_grad */
+void ta_oracle_variance_finalize(const float* acc, const float* cur, float* var, float count, int64_t numel) {
+    for (int64_t i = 0; i < numel; ++i) var[i] = acc[i] / count - cur[i];
+}

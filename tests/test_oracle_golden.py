@@ -162,3 +162,25 @@ def test_config1_ifgsm_resnet18(golden):
     model = backbones.create("resnet18", seed=int(g["seed_weights"]), verbose=False)
     delta = O.run_attack("ifgsm", model, x, t(g["label"]))
     assert np.array_equal(O.quantize_u8(x + delta), g["adv_u8"])
+
+
+def test_c_oracle_copies_and_normalize(golden):
+    """plain-C restatements of the SIM / Admix stacks (forward and autograd-ordered backward), the preprocessing
+    Normalize and the VMI variance against the reference's golden tensors / the torch expressions."""
+    g = golden("copies")
+    assert same(C.scale_copies_fwd(g["x"], 5), g["sim_y"])
+    assert same(C.scale_copies_bwd(g["sim_gy"], 5), g["sim_gx"])
+    torch.manual_seed(int(g["admix_seed"]))
+    perm = torch.cat(O.admix_draw(g["x"].shape[0])).numpy()
+    assert same(C.admix_fwd(g["x"], perm, 3, 5, 0.2), g["admix_y"])
+    assert same(C.admix_bwd(g["admix_gy"], 3, 5), g["admix_gx"])
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 17, 19, generator=gen)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    xin = x.clone().requires_grad_(True)
+    y = O.preprocess(xin, 19, mean, std) if False else (xin - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1)
+    gy = torch.randn(y.shape, generator=gen)
+    assert same(C.normalize_fwd(x.numpy(), mean, std), y.detach().numpy())
+    assert same(C.normalize_bwd(gy.numpy(), std), torch.autograd.grad(y, xin, gy)[0].numpy())
+    acc, cur = torch.randn(4, 7, generator=gen), torch.randn(4, 7, generator=gen)
+    assert same(C.variance_finalize(acc.numpy(), cur.numpy(), 20), (acc / 20 - cur).numpy())
