@@ -225,6 +225,32 @@ def gen_loops_more():
     save("loops_more", **out)
 
 
+def gen_loops_ens():
+    """SURVEY.md 8(f) rank 4, continued: AdaEA and SMER by the reference's own classes on three toy members
+    (Gaussian / uniform start from the CPU generator; SMER's member order from the numpy generator).  SMER's member
+    weights persist on the attack object, so a second batch is recorded too."""
+    ref_shim.neutralise_cuda_calls()                       # smer.py:45,58-59,69 use .cuda()
+    n, size = 4, 32
+    x = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    x2 = u8_images(n, size, 22).float() / 255
+    out = dict(x2_u8=u8_images(n, size, 22))
+    ta = ref_shim.import_reference()
+    from transferattack.utils import wrap_model, EnsembleModel
+    for name in ("adaea", "smer"):
+        members = [backbones.create("toy_cnn", seed=s, verbose=False) for s in (3, 4, 5)]
+        base = ta.load_attack_class(name)
+        cls = type("Ref_" + name, (base,), {"load_model": lambda self, mn: EnsembleModel([wrap_model(m.eval()) for m in members])})
+        atk = cls(model_name=["a", "b", "c"])
+        torch.manual_seed(1234)
+        np.random.seed(99)
+        out["delta_" + name] = atk(x, label)
+        out["delta2_" + name] = atk(x2, label)
+        if name == "smer":
+            out["smer_weight"] = atk.weight_selection.weight.detach().clone()
+    save("loops_ens", **out)
+
+
 def gen_config1():
     """BASELINE.json configs[0]: I-FGSM on ResNet-18, 16 images, eps=16/255, K=10, CPU reference path."""
     n = 16
@@ -241,6 +267,6 @@ def gen_config1():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "config1"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "config1"]
     for w in which:
         globals()["gen_" + w]()

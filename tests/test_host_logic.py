@@ -239,3 +239,31 @@ def test_adv_dataset_matches_reference_decoding(tmp_path):
     assert tds[1][1] == [11, 21]
     eds = AdvDataset(input_dir=str(inp), output_dir=str(out), eval=True)
     assert torch.equal(eds[0][0], x)
+
+
+@pytest.mark.parametrize("name", ["adaea", "smer"])
+def test_adaptive_ensemble_attacks_match_reference(golden, monkeypatch, name):
+    """AdaEA (AGM weights + DRF mask, adaea.py:62-87) and SMER (learned member weights with SGD
+    inside the attack, smer.py:62-126) on three members; two batches in a row, because SMER's weights persist."""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_ens"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    x2 = t(g["x2_u8"]).float() / 255
+    models = [backbones.create("toy_cnn", seed=s, verbose=False) for s in (3, 4, 5)]
+    cls = ta.load_attack_class(name)
+
+    def load_model(self, model_name):
+        return EnsembleModel([wrap_model(m.eval()) for m in models])
+
+    atk = type("Cpu" + cls.__name__, (cls,), {"load_model": load_model})(model_name=["a", "b", "c"])
+    if name == "adaea":
+        atk.noise_source = lambda shape, lo, hi: torch.randn(shape)
+    else:
+        atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    torch.manual_seed(1234)
+    np.random.seed(99)
+    assert np.array_equal(atk(x, label).numpy(), g["delta_" + name])
+    assert np.array_equal(atk(x2, label).numpy(), g["delta2_" + name])
+    if name == "smer":
+        assert np.array_equal(atk.weight_selection.weight.detach().numpy(), g["smer_weight"])
+        assert not np.array_equal(g["smer_weight"], np.ones(3, dtype=np.float32))

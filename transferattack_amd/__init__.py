@@ -37,6 +37,8 @@ attack_zoo = {
     'ens': ('.ensemble.ens', 'ENS'),
     'svre': ('.ensemble.svre', 'SVRE'),
     'cwa': ('.ensemble.cwa', 'CWA'),
+    'adaea': ('.ensemble.adaea', 'AdaEA'),
+    'smer': ('.ensemble.smer', 'SMER'),
 }
 
 
