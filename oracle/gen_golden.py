@@ -248,6 +248,12 @@ def gen_loops_ens():
         out["delta2_" + name] = atk(x2, label)
         if name == "smer":
             out["smer_weight"] = atk.weight_selection.weight.detach().clone()
+    # rank 3, last member: FGSRA (DCT-domain neighbours; tensor step).  rand_like draws come from the CPU generator.
+    atk = ref_shim.make_reference_attack("fgsra", backbones.create("toy_cnn", seed=3, verbose=False), max_iter=4)
+    torch.manual_seed(1234)
+    out["delta_fgsra"] = atk(x, label)
+    probe = torch.rand(2, 3, 7, 10, generator=torch.Generator().manual_seed(5))
+    out["dct_probe"], out["dct_2d"], out["idct_2d"] = probe, atk.dct_2d(probe), atk.idct_2d(probe)
     save("loops_ens", **out)
 
 

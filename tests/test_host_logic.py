@@ -267,3 +267,20 @@ def test_adaptive_ensemble_attacks_match_reference(golden, monkeypatch, name):
     if name == "smer":
         assert np.array_equal(atk.weight_selection.weight.detach().numpy(), g["smer_weight"])
         assert not np.array_equal(g["smer_weight"], np.ones(3, dtype=np.float32))
+
+
+def test_fgsra_matches_reference(golden, monkeypatch):
+    """FGSRA -- DCT-domain neighbours (fgsra.py:49-123), relevance-weighted gradients and the
+    per-element step alpha*m through update_delta's tensor operand (fgsra.py:213)."""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_ens"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    atk = make("fgsra", max_iter=4)
+    atk.noise_source = lambda shape, lo, hi: torch.rand(shape)
+    probe = t(g["dct_probe"])
+    assert np.array_equal(atk.dct_2d(probe).numpy(), g["dct_2d"])
+    assert np.array_equal(atk.idct_2d(probe).numpy(), g["idct_2d"])
+    assert torch.allclose(atk.idct_2d(atk.dct_2d(probe)), probe, atol=1e-5)          # inverse pair
+    torch.manual_seed(1234)
+    assert np.array_equal(atk(x, label).numpy(), g["delta_fgsra"])
+    assert "update_delta_linf" in fake_hip.calls

@@ -27,6 +27,7 @@ attack_zoo = {
     'dta': ('.gradient.dta', 'DTA'),
     'pcifgsm': ('.gradient.pcifgsm', 'PCIFGSM'),
     'smifgrm': ('.gradient.smifgrm', 'SMIFGRM'),
+    'fgsra': ('.gradient.fgsra', 'FGSRA'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
