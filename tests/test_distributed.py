@@ -43,7 +43,7 @@ def _setup(rank, world, port):
     return tadist
 
 
-def _make(name, models, **kw):
+def _make(name, models, model_name="injected", **kw):
     import transferattack_amd as ta
     from transferattack_amd.utils import EnsembleModel, wrap_model
     base = ta.load_attack_class(name)
@@ -54,7 +54,7 @@ def _make(name, models, **kw):
         wrapped = [wrap_model(m.eval()) for m in models]
         return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
 
-    return type("T" + base.__name__, (base,), {"load_model": load_model})(model_name="injected", **kw)
+    return type("T" + base.__name__, (base,), {"load_model": load_model})(model_name=model_name, **kw)
 
 
 def _rank_shard(rank, world, port, out):
@@ -100,6 +100,38 @@ def _rank_ensemble(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _rank_members(rank, world, port, out):
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import wrap_model
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    grp, idx, _, _ = tadist.model_groups(world, 2)
+    result = {}
+    for name, kw in _MEMBER_ATTACKS:
+        member = wrap_model(backbones.create("toy_cnn", seed=3 + rank, verbose=False).eval())
+        atk = _make(name, tadist.ShardedMembers(member, idx, grp, [0, 1]), model_name=["a", "b"], **kw)
+        atk.noise_source = _cpu_noise(name)
+        tadist.seed_batch(5, 0)
+        result[name] = atk(x, y).numpy()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, result)
+    if rank == 0:
+        np.savez(out, **{"%s_r%d" % (k, r): v for r, g in enumerate(gathered) for k, v in g.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_MEMBER_ATTACKS = (("svre", dict(epoch=2)), ("cwa", dict(epoch=2)), ("adaea", dict(epoch=2)), ("smer", dict(epoch=2)))
+
+
+def _cpu_noise(name):
+    if name == "adaea":
+        return lambda shape, lo, hi: torch.randn(shape)
+    return lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+
+
 def _run(fn, tmp_path):
     out = str(tmp_path / "out.npz")
     mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
@@ -139,3 +171,24 @@ def test_sharded_ensemble_matches_single_process(tmp_path, monkeypatch):
     ref = _make("ens", models, epoch=4)(x, y).numpy()
     assert float((got["r0"] != ref).mean()) <= 0.002
     assert np.abs(got["r0"] - ref).max() <= 2 * 1.6 / 255 + 1e-7
+
+
+def test_sharded_members_match_single_process(tmp_path, monkeypatch):
+    """SVRE / CWA / AdaEA / SMER with one member per rank (logits broadcast forward, input gradient broadcast backward)
+    == the same attack with both members in one process, bit for bit: the ranks run the same arithmetic, only the
+    surrogates are spread out."""
+    got = _run(_rank_members, tmp_path)
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones, dist as tadist
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    for name, kw in _MEMBER_ATTACKS:
+        models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+        atk = _make(name, models, model_name=["a", "b"], **kw)
+        atk.noise_source = _cpu_noise(name)
+        tadist.seed_batch(5, 0)
+        ref = atk(x, y).numpy()
+        assert np.array_equal(got[name + "_r0"], got[name + "_r1"]), name
+        assert np.array_equal(got[name + "_r0"], ref), name

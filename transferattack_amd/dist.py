@@ -10,9 +10,16 @@ The reference is single-process, single-GPU (main.py:31, 43); nothing here has a
   one RCCL all-reduce ([N,1000] fp32) and ``allreduce_input_grad`` sums the input gradients with another
   ([N,3,224,224] fp32) -- the only two exchange steps the path has.  Ranks of a group see the same images and,
   after the second all-reduce, hold identical gradients, so each runs the identical fused update locally.
+* Attacks that address single members (SVRE, CWA, AdaEA, SMER: ``self.model.models[k](x)``, svre.py:72-83,
+  cwa.py:71-81, adaea.py:65-82, smer.py:80-106) use ``ShardedMembers``: ``models[k]`` is a handle that runs on the rank
+  owning member k and broadcasts its logits forward and its input gradient backward.  Every rank of the group executes
+  the same attack code on the same images with the same host draws (``seed_batch`` seeds torch AND numpy), so the
+  results equal the single-device run bit for bit; what is sharded is the surrogates' weights and activations
+  (one model per 288 GB GPU), not the arithmetic.
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -53,6 +60,7 @@ def seed_batch(base_seed, batch_idx):
     same whichever rank processes it."""
     seed = (int(base_seed) * 1000003 + int(batch_idx) * 7919 + 12345) % (2 ** 63 - 1)
     torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))          # SVRE / SMER draw their member order from numpy (svre.py:75, smer.py:75)
     return seed
 
 
@@ -109,3 +117,90 @@ def allreduce_input_grad(grad, group):
     grad = grad.contiguous()
     dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
+
+
+class _OwnerCall(torch.autograd.Function):
+    """logits = member(x) where the member lives on one rank of the group.  Forward: the owner runs it and broadcasts
+    the logits ([N, classes] fp32).  Backward: the owner back-propagates the (identical on every rank) logit gradient
+    and broadcasts d/dx ([N,3,H,W] fp32).  The owner keeps its graph until the handle's output dies, so a second
+    backward through the same logits (adaea.py:67 then :81) works like retain_graph=True."""
+
+    @staticmethod
+    def forward(ctx, x, handle):
+        ctx.handle, ctx.own, ctx.x_shape = handle, None, tuple(x.shape)
+        if handle.local is not None:
+            if ctx.needs_input_grad[0]:
+                with torch.enable_grad():
+                    leaf = x.detach().requires_grad_(True)
+                    out = handle.local(leaf)
+                ctx.own = (leaf, out)
+            else:
+                out = handle.local(x.detach())
+            logits = out.detach().clone().contiguous()
+            handle.announce(logits)
+        else:
+            logits = x.new_empty((x.shape[0],) + handle.announce(None))
+        dist.broadcast(logits, src=handle.owner, group=handle.group)
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        handle = ctx.handle
+        if ctx.own is not None:
+            leaf, out = ctx.own
+            gx = torch.autograd.grad(out, leaf, grad_logits.contiguous(), retain_graph=True)[0].contiguous()
+        else:
+            gx = torch.empty(ctx.x_shape, dtype=grad_logits.dtype, device=grad_logits.device)
+        dist.broadcast(gx, src=handle.owner, group=handle.group)
+        return gx, None
+
+
+class MemberHandle(nn.Module):
+    """``EnsembleModel.models[k]`` when member k lives on rank ``owner`` (a GLOBAL rank) of ``group``; ``local`` is the
+    wrapped surrogate on the owner and None elsewhere.  Calls are collective: every rank of the group makes them in the
+    same order (they do -- the ranks run the same attack on the same batch with the same seeds)."""
+
+    def __init__(self, local, owner, group):
+        super().__init__()
+        self.local, self.owner, self.group = local, owner, group
+        self._tail = None                        # logits shape after the batch axis, learnt at the first call
+
+    def announce(self, logits):
+        if self._tail is None:
+            box = [tuple(logits.shape[1:])] if logits is not None else [None]
+            dist.broadcast_object_list(box, src=self.owner, group=self.group)
+            self._tail = tuple(box[0])
+        return self._tail
+
+    def forward(self, x):
+        return _OwnerCall.apply(x, self)
+
+
+class ShardedMembers(nn.Module):
+    """Drop-in for ``EnsembleModel`` (utils.py:82-105) with one member per rank of ``group`` and the members
+    individually addressable.  ``forward`` is the same stack-and-mean as the reference class, over the handles."""
+
+    def __init__(self, local_model, index, group, group_ranks, mode='mean'):
+        super().__init__()
+        self.local = local_model
+        self.group = group
+        self.models = [MemberHandle(local_model if k == index else None, r, group) for k, r in enumerate(group_ranks)]
+        self.num_models = len(group_ranks)
+        self.mode = mode
+        self.type_name = 'ensemble'
+        self.device = next(local_model.parameters()).device
+
+    def forward(self, x):
+        outputs = torch.stack([member(x) for member in self.models], dim=0)
+        if self.mode == 'mean':
+            return torch.mean(outputs, dim=0)
+        if self.mode == 'ind':
+            return outputs
+        raise NotImplementedError
+
+    def eval(self):
+        self.local.eval()
+        return super().eval()
+
+    def parameters(self, recurse=True):
+        return self.local.parameters(recurse)
