@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE -- compile a csrc kernel file for the HOST (g++, one OS thread per lane; see hip/hip_runtime.h)
+so its logic can be compared with the oracle where there is no GPU.  Never imported by the package."""
+import ctypes
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "transferattack_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+
+# name and element type of each file's dynamic-LDS array (a block-scope `extern` needs a namespace-scope definition)
+_DYNAMIC_LDS = {"dim.hip": [("char", "smem_raw")], "tim.hip": [("float", "smem")]}
+
+
+def _host_text(text):
+    text = text.replace("extern __shared__", "extern")
+    text = text.replace('#include "../../include/ta_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "ta_hip.h"))
+    # clang's ext_vector_type has no g++ counterpart with .x/.y members
+    text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
+    return text
+
+
+HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip")     # not fused_update.hip
+
+
+def build():
+    """-> path of libta_host.so: the kernel sources of csrc compiled for the host; rebuilt when a source is newer."""
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, "libta_host.so")
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    sources = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = sources + headers + [os.path.join(HERE, "hipcpu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), __file__]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        for h in headers:
+            with open(os.path.join(OUT, os.path.basename(h)), "w") as fh:
+                fh.write(_host_text(open(h).read()))
+        generated = []
+        for src in sources:
+            name = os.path.basename(src)
+            text = _host_text(open(src).read())
+            for ctype, var in _DYNAMIC_LDS.get(name, []):
+                text += "\nnamespace ta { __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (ctype, var, ctype)
+            generated.append(os.path.join(OUT, os.path.splitext(name)[0] + "_host.cpp"))
+            with open(generated[-1], "w") as fh:
+                fh.write(text)
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread",
+               "-Wno-attributes", "-Wno-unknown-pragmas", "-I", HERE, "-I", OUT] + generated + [
+               os.path.join(HERE, "hipcpu.cpp"), "-o", lib]
+        subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return lib
+
+
+def load(tag=None):
+    """ctypes.CDLL of the host build; ``tag`` loads a private copy (own statics, e.g. a variant knob read once)."""
+    lib = build()
+    if tag is not None:
+        import shutil
+        private = lib.replace(".so", "_%s.so" % tag)
+        shutil.copyfile(lib, private)
+        lib = private
+    return ctypes.CDLL(lib)

@@ -1,0 +1,82 @@
+// TEST INFRASTRUCTURE -- a minimal host stand-in for <hip/hip_runtime.h>.
+//
+// Lets a kernel source file of transferattack_amd/csrc be compiled with g++ and executed on the CPU, one OS thread
+// per lane, so that the kernel's LOGIC (indexing, staging through "LDS", barriers, rounding order) can be checked bit
+// for bit against the oracle in a container that has no GPU.  It says nothing about speed and is never part of the
+// product: only tests/ builds it (tests/hipcpu/build.py), the package cannot import it.
+//
+// Model: workgroups run one after another; the lanes of a workgroup are persistent threads meeting at a barrier for
+// __syncthreads(); `__shared__` arrays are plain statics (one workgroup alive at a time); wave shuffles go through a
+// per-wave exchange buffer.  Only what the csrc kernels use is provided.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static                 /* `extern __shared__` is rewritten to `extern` by build.py */
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "host stand-in"; }
+
+namespace hipcpu {
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx thread_idx, block_idx, block_dim, grid_dim;
+void barrier();
+float shfl_xor(float v, int lane_mask, int width);
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+}  // namespace hipcpu
+
+#define threadIdx hipcpu::thread_idx
+#define blockIdx hipcpu::block_idx
+#define blockDim hipcpu::block_dim
+#define gridDim hipcpu::grid_dim
+
+static inline void __syncthreads() { hipcpu::barrier(); }
+static inline float __shfl_xor(float v, int lane_mask, int width = 64) { return hipcpu::shfl_xor(v, lane_mask, width); }
+
+static inline int atomicMin(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+/* streaming hints have no meaning on the host */
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int64_t min(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t max(int64_t a, int64_t b) { return a > b ? a : b; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    hipcpu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

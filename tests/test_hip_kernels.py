@@ -101,7 +101,7 @@ def test_fused_update_random(shape, single):
         gsum = grad + var if use_var else grad
         m_ref = O.momentum_step(gsum, mom, decay)
         d_ref = O.delta_step(delta, x, m_ref, ALPHA, EPS)
-        d, m, xa = delta.to(DEV), mom.to(DEV), torch.empty(shape, device=DEV)
+        d, m, xa = delta.clone().to(DEV), mom.clone().to(DEV), torch.empty(shape, device=DEV)   # updated in place
         _hip.mi_update(grad.to(DEV), m, m, d, x.to(DEV), decay, ALPHA, EPS,
                        variance=var.to(DEV) if use_var else None, x_adv=xa, single_launch=single)
         if single:

@@ -148,6 +148,8 @@ def test_no_cpu_fallback():
     x = torch.rand(1, 3, 8, 8)
     with pytest.raises(_hip.HipExtensionError):
         _hip.momentum(x, None, torch.empty_like(x), 1.0)
+    with pytest.raises(_hip.HipExtensionError):
+        wrap_model(backbones.create("toy_cnn", seed=3, verbose=False).eval())(x)     # Normalize is a HIP kernel too
     if not torch.cuda.is_available():
         with pytest.raises(_hip.HipExtensionError):
             Attack.load_model(object.__new__(Attack), "resnet18")

@@ -1,0 +1,87 @@
+"""Kernel LOGIC on the CPU.  The .hip sources (update, elementwise, TIM, DIM) are compiled for the host under a
+thread-per-lane stand-in for the HIP runtime (tests/hipcpu) and driven through the real ctypes binding
+(tests/host_kernels.py); the assertions are the ones the `-m gpu` tests make on MI355X (tests/test_hip_kernels.py,
+re-used here function by function at sizes the stand-in finishes quickly).
+
+What this proves: indexing, tiling, staging through the shared arrays, barriers, tail handling, rounding order and
+the binding's argument marshalling.  What it does not: anything about the gfx950 build (another compiler, no real
+wave execution, no non-temporal paths, no single-launch exchange) or about speed -- the GPU tests stay the parity
+gate.  Test infrastructure only."""
+import numpy as np
+import pytest
+import torch
+
+import host_kernels
+import test_hip_kernels as G
+
+
+@pytest.fixture(autouse=True)
+def host_backend(monkeypatch):
+    host_kernels.install(monkeypatch)
+    monkeypatch.setattr(G, "DEV", "cpu")
+
+
+# ---- re-used as they are (golden tensors of the reference; small ragged shapes)
+test_update_stack_golden = G.test_update_stack_golden
+test_update_delta_variants_golden = G.test_update_delta_variants_golden
+test_quantiser = G.test_quantiser
+test_tim_golden = G.test_tim_golden
+test_dim_golden = G.test_dim_golden
+test_sim_admix_golden = G.test_sim_admix_golden
+test_sum_copies_bwd = G.test_sum_copies_bwd
+test_sim_admix_ragged = G.test_sim_admix_ragged
+test_vmi_kernels_and_philox = G.test_vmi_kernels_and_philox
+
+
+# ---- re-used with smaller shapes
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (2, 1, 1, 7)])
+def test_fused_update_random(shape):
+    G.test_fused_update_random(shape, False)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 224, 224), (3, 3, 37, 41), (2, 1, 5, 7)])
+def test_normalize_and_producer_side_partials(shape):
+    G.test_normalize_and_producer_side_partials(shape)
+
+
+@pytest.mark.parametrize("shape,k", [((1, 3, 224, 224), 15), ((1, 2, 37, 41), 15), ((1, 2, 64, 64), 7), ((1, 1, 20, 33), 3)])
+def test_tim_random(shape, k):
+    G.test_tim_random(shape, k)
+
+
+@pytest.mark.parametrize("size,rate,geoms", [
+    (224, 1.1, [(245, 0, 1), (237, 3, 5)]),
+    (64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)]),
+    (33, 2.0, [(40, 5, 20), (65, 0, 1)]),
+])
+def test_dim_random(size, rate, geoms):
+    G.test_dim_random(size, rate, geoms)
+
+
+def test_bad_arguments_fail_loudly():
+    """the library's own argument checks (TA_EINVAL + message) and the binding's dtype check; the device check of the
+    binding is the one thing the stand-in replaces, see tests/test_host_logic.py::test_no_cpu_fallback for it"""
+    from transferattack_amd import _hip
+    x = torch.rand(2, 3, 8, 8)
+    with pytest.raises(_hip.HipExtensionError, match="alias"):
+        _hip.depthwise_conv2d_same(x, x, torch.rand(3, 3))
+    with pytest.raises(_hip.HipExtensionError, match="geometry"):
+        _hip.dim_fwd(x, torch.empty_like(x), 8, 9, 0, 0)
+    with pytest.raises(TypeError):
+        _hip.momentum(x.double(), None, torch.empty_like(x), 1.0)
+
+
+# ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_tim_variants(monkeypatch, golden, variant):
+    host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
+    G.test_tim_golden(golden)
+    G.test_tim_random((1, 2, 224, 224), 15)
+    G.test_tim_random((1, 1, 37, 41), 15)
+
+
+def test_dim_separable_forward(monkeypatch, golden):
+    host_kernels.install(monkeypatch, tag="dimsep", env={"TA_DIM_FWD_VARIANT": "1"})
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(237, 3, 5)])
+    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0)])

@@ -85,9 +85,11 @@ class _Normalize(nn.Module):
         self.register_buffer("std", torch.tensor(list(std), dtype=torch.float32).view(1, -1, 1, 1), persistent=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous():
+        if x.dtype == torch.float32 and x.dim() == 4:
+            # the attack path: fp32 NCHW batches.  HIP kernels, whatever device x claims to be on -- a CPU tensor is
+            # refused by the binding like everywhere else (no silent torch fallback on the hot path)
             return _NormalizeFn.apply(x, self.mean.reshape(-1).contiguous(), self.std.reshape(-1).contiguous())
-        return (x - self.mean) / self.std
+        return (x - self.mean) / self.std            # other dtypes / ranks: not the path this package accelerates
 
 
 class PreprocessingModel(nn.Module):
