@@ -15,7 +15,7 @@ _DYNAMIC_LDS = {"dim.hip": [("char", "smem_raw")], "tim.hip": [("float", "smem")
 
 
 def _host_text(text):
-    text = text.replace("extern __shared__", "extern")
+    text = text.replace("extern __shared__", "extern thread_local")
     text = text.replace('#include "../../include/ta_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "ta_hip.h"))
     # clang's ext_vector_type has no g++ counterpart with .x/.y members
     text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
@@ -41,7 +41,7 @@ def build():
             name = os.path.basename(src)
             text = _host_text(open(src).read())
             for ctype, var in _DYNAMIC_LDS.get(name, []):
-                text += "\nnamespace ta { __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (ctype, var, ctype)
+                text += "\nnamespace ta { thread_local __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (ctype, var, ctype)
             generated.append(os.path.join(OUT, os.path.splitext(name)[0] + "_host.cpp"))
             with open(generated[-1], "w") as fh:
                 fh.write(text)

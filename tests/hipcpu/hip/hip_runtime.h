@@ -1,13 +1,14 @@
 // TEST INFRASTRUCTURE -- a minimal host stand-in for <hip/hip_runtime.h>.
 //
-// Lets a kernel source file of transferattack_amd/csrc be compiled with g++ and executed on the CPU, one OS thread
-// per lane, so that the kernel's LOGIC (indexing, staging through "LDS", barriers, rounding order) can be checked bit
-// for bit against the oracle in a container that has no GPU.  It says nothing about speed and is never part of the
-// product: only tests/ builds it (tests/hipcpu/build.py), the package cannot import it.
+// Lets a kernel source file of transferattack_amd/csrc be compiled with g++ and executed on the CPU so that the
+// kernel's LOGIC (indexing, staging through "LDS", barriers, rounding order) can be checked bit for bit against the
+// oracle in a container that has no GPU.  It says nothing about speed and is never part of the product: only tests/
+// builds it (tests/hipcpu/build.py), the package cannot import it.
 //
-// Model: workgroups run one after another; the lanes of a workgroup are persistent threads meeting at a barrier for
-// __syncthreads(); `__shared__` arrays are plain statics (one workgroup alive at a time); wave shuffles go through a
-// per-wave exchange buffer.  Only what the csrc kernels use is provided.
+// Model: every lane of a workgroup is a fiber (ucontext) on one OS thread; __syncthreads() and the wave shuffles park
+// the fiber until its group has arrived.  Workgroups are independent, so a small pool of OS threads runs them side by
+// side; `__shared__` arrays are thread_local statics (one workgroup per OS thread at a time).  Only what the csrc
+// kernels use is provided.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -20,7 +21,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static                 /* `extern __shared__` is rewritten to `extern` by build.py */
+#define __shared__ static thread_local    /* `extern __shared__` is rewritten to `extern thread_local` by build.py */
 
 struct dim3 {
     unsigned x, y, z;
@@ -34,30 +35,26 @@ static inline const char* hipGetErrorString(hipError_t) { return "host stand-in"
 
 namespace hipcpu {
 struct Idx { unsigned x, y, z; };
-extern thread_local Idx thread_idx, block_idx, block_dim, grid_dim;
+const Idx& thread_idx();
+const Idx& block_idx();
+const Idx& block_dim();
+const Idx& grid_dim();
 void barrier();
 float shfl_xor(float v, int lane_mask, int width);
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 }  // namespace hipcpu
 
-#define threadIdx hipcpu::thread_idx
-#define blockIdx hipcpu::block_idx
-#define blockDim hipcpu::block_dim
-#define gridDim hipcpu::grid_dim
+#define threadIdx (hipcpu::thread_idx())
+#define blockIdx (hipcpu::block_idx())
+#define blockDim (hipcpu::block_dim())
+#define gridDim (hipcpu::grid_dim())
 
 static inline void __syncthreads() { hipcpu::barrier(); }
 static inline float __shfl_xor(float v, int lane_mask, int width = 64) { return hipcpu::shfl_xor(v, lane_mask, width); }
 
-static inline int atomicMin(int* p, int v) {
-    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-    return old;
-}
-static inline int atomicMax(int* p, int v) {
-    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-    return old;
-}
+/* one workgroup = one OS thread: LDS atomics need no hardware atomicity here */
+static inline int atomicMin(int* p, int v) { const int old = *p; if (v < old) *p = v; return old; }
+static inline int atomicMax(int* p, int v) { const int old = *p; if (v > old) *p = v; return old; }
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };

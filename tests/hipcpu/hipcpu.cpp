@@ -1,88 +1,166 @@
 // TEST INFRASTRUCTURE -- runtime half of tests/hipcpu/hip/hip_runtime.h (see there).
-#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "hip/hip_runtime.h"
 
 namespace hipcpu {
-
-thread_local Idx thread_idx, block_idx, block_dim, grid_dim;
-
 namespace {
-pthread_barrier_t group_barrier;
-std::vector<pthread_barrier_t> wave_barriers;
-std::vector<float> wave_slots;              // [waves][64]
-thread_local int wave_of_thread;
+
+constexpr size_t kStackBytes = 128 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    Idx tid;
+    bool done;
+};
+
+// one per OS thread of the pool: the lanes of the workgroup it is currently running
+struct Worker {
+    ucontext_t scheduler;
+    std::vector<Fiber> lanes;
+    char* stacks = nullptr;
+    Idx bid, bdim, gdim;
+    unsigned current = 0, alive = 0;
+    unsigned arrived = 0, generation = 0;                 // __syncthreads
+    std::vector<unsigned> wave_arrived, wave_generation, wave_alive;
+    std::vector<float> slots;                             // [waves][64] shuffle exchange
+    const std::function<void()>* body = nullptr;
+};
+
+thread_local Worker* worker = nullptr;
+
+void yield() {
+    Worker* w = worker;
+    swapcontext(&w->lanes[w->current].ctx, &w->scheduler);
+}
+
+void release_if_complete(Worker* w) {
+    if (w->alive != 0 && w->arrived == w->alive) {
+        w->arrived = 0;
+        ++w->generation;
+    }
+}
+
+void release_wave_if_complete(Worker* w, unsigned wave) {
+    if (w->wave_alive[wave] != 0 && w->wave_arrived[wave] == w->wave_alive[wave]) {
+        w->wave_arrived[wave] = 0;
+        ++w->wave_generation[wave];
+    }
+}
+
+void wave_barrier(Worker* w, unsigned wave) {
+    const unsigned gen = w->wave_generation[wave];
+    ++w->wave_arrived[wave];
+    release_wave_if_complete(w, wave);
+    while (gen == w->wave_generation[wave]) yield();
+}
+
+void lane_entry() {
+    Worker* w = worker;
+    (*w->body)();
+    const unsigned lane = w->current;
+    w->lanes[lane].done = true;
+    --w->alive;                                           // a lane that has left no longer holds up the others
+    --w->wave_alive[lane / 64];
+    release_if_complete(w);
+    release_wave_if_complete(w, lane / 64);
+}
+
+void run_workgroup(Worker* w, unsigned lanes) {
+    const unsigned waves = (lanes + 63) / 64;
+    w->alive = lanes;
+    w->arrived = 0;
+    w->wave_arrived.assign(waves, 0);
+    w->wave_generation.assign(waves, 0);
+    w->wave_alive.assign(waves, 0);
+    for (unsigned t = 0; t < lanes; ++t) {
+        Fiber& f = w->lanes[t];
+        f.done = false;
+        f.tid = Idx{t % w->bdim.x, (t / w->bdim.x) % w->bdim.y, t / (w->bdim.x * w->bdim.y)};
+        ++w->wave_alive[t / 64];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = w->stacks + static_cast<size_t>(t) * kStackBytes;
+        f.ctx.uc_stack.ss_size = kStackBytes;
+        f.ctx.uc_link = &w->scheduler;
+        makecontext(&f.ctx, lane_entry, 0);
+    }
+    unsigned remaining = lanes;
+    while (remaining != 0)
+        for (unsigned t = 0; t < lanes; ++t) {
+            if (w->lanes[t].done) continue;
+            w->current = t;
+            swapcontext(&w->scheduler, &w->lanes[t].ctx);
+            if (w->lanes[t].done) --remaining;
+        }
+}
+
 }  // namespace
 
-void barrier() { pthread_barrier_wait(&group_barrier); }
+const Idx& thread_idx() { return worker->lanes[worker->current].tid; }
+const Idx& block_idx() { return worker->bid; }
+const Idx& block_dim() { return worker->bdim; }
+const Idx& grid_dim() { return worker->gdim; }
+
+void barrier() {
+    Worker* w = worker;
+    const unsigned gen = w->generation;
+    ++w->arrived;
+    release_if_complete(w);
+    while (gen == w->generation) yield();
+}
 
 float shfl_xor(float v, int lane_mask, int width) {
-    (void)width;                            // the kernels only use full 64-lane butterflies
-    const int lane = thread_idx.x & 63;
-    float* slots = wave_slots.data() + 64 * wave_of_thread;
-    slots[lane] = v;
-    pthread_barrier_wait(&wave_barriers[wave_of_thread]);
-    const float got = slots[lane ^ lane_mask];
-    pthread_barrier_wait(&wave_barriers[wave_of_thread]);
+    (void)width;                                          // the kernels only use full 64-lane butterflies
+    Worker* w = worker;
+    const unsigned t = w->current, wave = t / 64, lane = t & 63;
+    w->slots[64 * wave + lane] = v;
+    wave_barrier(w, wave);
+    const float got = w->slots[64 * wave + (lane ^ static_cast<unsigned>(lane_mask))];
+    wave_barrier(w, wave);
     return got;
 }
 
-struct Job {
-    dim3 grid, block;
-    const std::function<void()>* body;
-    unsigned lane;
-};
-
-static void* lane_main(void* arg) {
-    const Job* job = static_cast<const Job*>(arg);
-    const unsigned t = job->lane;
-    thread_idx = Idx{t % job->block.x, (t / job->block.x) % job->block.y, t / (job->block.x * job->block.y)};
-    block_dim = Idx{job->block.x, job->block.y, job->block.z};
-    grid_dim = Idx{job->grid.x, job->grid.y, job->grid.z};
-    wave_of_thread = static_cast<int>(t / 64);
-    for (unsigned bz = 0; bz < job->grid.z; ++bz)
-        for (unsigned by = 0; by < job->grid.y; ++by)
-            for (unsigned bx = 0; bx < job->grid.x; ++bx) {
-                block_idx = Idx{bx, by, bz};
-                (*job->body)();
-                pthread_barrier_wait(&group_barrier);       // next workgroup reuses the "LDS"
-            }
-    return nullptr;
-}
-
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
-    (void)smem_bytes;                                       // dynamic LDS is a fixed 160 KiB array (build.py)
+    (void)smem_bytes;                                     // dynamic LDS is a fixed 160 KiB array (build.py)
     const unsigned lanes = block.x * block.y * block.z;
-    const unsigned waves = (lanes + 63) / 64;
-    pthread_barrier_init(&group_barrier, nullptr, lanes);
-    wave_barriers.resize(waves);
-    wave_slots.assign(64 * waves, 0.0f);
-    for (unsigned w = 0; w < waves; ++w) {
-        const unsigned in_wave = (w + 1) * 64 <= lanes ? 64 : lanes - w * 64;
-        pthread_barrier_init(&wave_barriers[w], nullptr, in_wave);
-    }
-    std::vector<Job> jobs(lanes);
-    std::vector<pthread_t> threads(lanes);
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 256 * 1024);
-    for (unsigned t = 0; t < lanes; ++t) {
-        jobs[t] = Job{grid, block, &body, t};
-        pthread_create(&threads[t], &attr, lane_main, &jobs[t]);
-    }
-    for (unsigned t = 0; t < lanes; ++t) pthread_join(threads[t], nullptr);
-    pthread_attr_destroy(&attr);
-    for (unsigned w = 0; w < waves; ++w) pthread_barrier_destroy(&wave_barriers[w]);
-    pthread_barrier_destroy(&group_barrier);
+    const uint64_t groups = static_cast<uint64_t>(grid.x) * grid.y * grid.z;
+    unsigned pool = std::thread::hardware_concurrency();
+    if (pool == 0) pool = 1;
+    if (pool > groups) pool = static_cast<unsigned>(groups);
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() {
+        Worker w;
+        w.lanes.resize(lanes);
+        w.slots.assign(64 * ((lanes + 63) / 64), 0.0f);
+        w.stacks = static_cast<char*>(mmap(nullptr, kStackBytes * lanes, PROT_READ | PROT_WRITE,
+                                           MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+        w.bdim = Idx{block.x, block.y, block.z};
+        w.gdim = Idx{grid.x, grid.y, grid.z};
+        w.body = &body;
+        worker = &w;
+        for (uint64_t g = next.fetch_add(1); g < groups; g = next.fetch_add(1)) {
+            w.bid = Idx{static_cast<unsigned>(g % grid.x), static_cast<unsigned>((g / grid.x) % grid.y),
+                        static_cast<unsigned>(g / (static_cast<uint64_t>(grid.x) * grid.y))};
+            run_workgroup(&w, lanes);
+        }
+        worker = nullptr;
+        munmap(w.stacks, kStackBytes * lanes);
+    };
+    std::vector<std::thread> threads;
+    for (unsigned i = 1; i < pool; ++i) threads.emplace_back(work);
+    work();
+    for (auto& th : threads) th.join();
 }
 
 }  // namespace hipcpu
 
-// entry points of fused_update.hip: the single-launch exchange needs concurrently resident workgroups, which this
-// one-workgroup-at-a-time model cannot provide
-#include <stdint.h>
+// entry points of fused_update.hip: the single-launch exchange needs concurrently resident workgroups that can see
+// each other's progress, which this model (a workgroup runs to completion on its OS thread) does not provide
 namespace ta { void set_error(const char* fmt, ...); }
 extern "C" int64_t ta_fused_sync_bytes(int64_t, int64_t) { return 8; }
 extern "C" int ta_mi_update_fused(const float*, const float*, const float*, float*, float*, const float*, float*, void*,

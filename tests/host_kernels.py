@@ -50,4 +50,8 @@ def install(monkeypatch, tag=None, env=None):
     monkeypatch.setattr(_hip, "_partials", None)
     two_launch = _hip._mi_update                 # the single-launch exchange cannot run here: route it to the two-launch form
     monkeypatch.setattr(_hip, "_mi_update", lambda *a: two_launch(*a[:10], False, *a[11:]))
+    from transferattack_amd import attack as ta_attack, utils as ta_utils
+    cpu = lambda: torch.device("cpu")            # noqa: E731  -- "the device this process drives" is the host here
+    monkeypatch.setattr(ta_utils, "default_device", cpu)
+    monkeypatch.setattr(ta_attack, "default_device", cpu)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: types.SimpleNamespace(cuda_stream=0))

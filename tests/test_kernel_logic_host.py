@@ -33,29 +33,30 @@ test_sim_admix_ragged = G.test_sim_admix_ragged
 test_vmi_kernels_and_philox = G.test_vmi_kernels_and_philox
 
 
-# ---- re-used with smaller shapes
-@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (2, 1, 1, 7)])
+test_normalize_and_producer_side_partials = G.test_normalize_and_producer_side_partials
+test_tim_random = G.test_tim_random
+test_dim_random = G.test_dim_random
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (3, 3, 299, 299), (2, 1, 1, 7)])
 def test_fused_update_random(shape):
-    G.test_fused_update_random(shape, False)
+    G.test_fused_update_random(shape, False)          # the single-launch form cannot run here (see tests/hipcpu)
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 224, 224), (3, 3, 37, 41), (2, 1, 5, 7)])
-def test_normalize_and_producer_side_partials(shape):
-    G.test_normalize_and_producer_side_partials(shape)
+# ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_tim_variants(monkeypatch, golden, variant):
+    host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
+    G.test_tim_golden(golden)
+    G.test_tim_random((4, 3, 224, 224), 15)
+    G.test_tim_random((2, 3, 37, 41), 15)
 
 
-@pytest.mark.parametrize("shape,k", [((1, 3, 224, 224), 15), ((1, 2, 37, 41), 15), ((1, 2, 64, 64), 7), ((1, 1, 20, 33), 3)])
-def test_tim_random(shape, k):
-    G.test_tim_random(shape, k)
-
-
-@pytest.mark.parametrize("size,rate,geoms", [
-    (224, 1.1, [(245, 0, 1), (237, 3, 5)]),
-    (64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)]),
-    (33, 2.0, [(40, 5, 20), (65, 0, 1)]),
-])
-def test_dim_random(size, rate, geoms):
-    G.test_dim_random(size, rate, geoms)
+def test_dim_separable_forward(monkeypatch, golden):
+    host_kernels.install(monkeypatch, tag="dimsep", env={"TA_DIM_FWD_VARIANT": "1"})
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
+    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
 
 
 def test_bad_arguments_fail_loudly():
