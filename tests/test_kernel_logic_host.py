@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import c_oracle as C
 import host_kernels
 import test_hip_kernels as G
 
@@ -86,3 +87,67 @@ def test_dim_separable_forward(monkeypatch, golden):
     G.test_dim_golden(golden)
     G.test_dim_random(224, 1.1, [(237, 3, 5)])
     G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0)])
+
+
+def test_dim_lane_per_column_forward(monkeypatch, golden):
+    host_kernels.install(monkeypatch, tag="dimlanes", env={"TA_DIM_FWD_VARIANT": "2"})
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
+    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
+    G.test_dim_random(33, 2.0, [(40, 5, 20), (65, 0, 1)])
+
+
+# ---- out-of-bounds reads: inputs placed flush against inaccessible pages (a stray load faults instead of passing)
+def _guarded(array, at_end):
+    """copy of ``array`` inside an anonymous mapping, its last (or first) byte adjacent to a PROT_NONE page"""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    nbytes = array.nbytes
+    body = (nbytes + page - 1) // page * page
+    m = mmap.mmap(-1, body + 2 * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(base, page, 0) == 0 and libc.mprotect(base + page + body, page, 0) == 0
+    start = page + (body - nbytes if at_end else 0)
+    view = np.frombuffer(m, dtype=array.dtype, count=array.size, offset=start).reshape(array.shape)
+    view[...] = array
+    return view, m
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_dim_reads_stay_in_bounds(monkeypatch, variant):
+    from transferattack_amd import _hip
+    host_kernels.install(monkeypatch, tag="dimoob" + variant, env={"TA_DIM_FWD_VARIANT": variant})
+    gen = torch.Generator().manual_seed(1)
+    for size, resize, geoms in ((224, 246, [(245, 0, 1), (224, 22, 0), (230, 0, 16)]), (33, 66, [(40, 5, 20), (65, 0, 1)])):
+        x = torch.rand(1, 1, size, size, generator=gen).numpy()
+        for at_end in (True, False):
+            xg, keep = _guarded(x, at_end)
+            xt = torch.from_numpy(xg)
+            for rnd, top, left in geoms:
+                y, gx = torch.empty(x.shape), torch.empty(x.shape)
+                _hip.dim_fwd(xt, y, resize, rnd, top, left)
+                _hip.dim_bwd(xt, gx, resize, rnd, top, left)
+                assert np.array_equal(y.numpy(), C.dim_fwd(x, (True, rnd, top, left), resize))
+            del xt, xg
+            keep = None
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_tim_reads_stay_in_bounds(monkeypatch, variant):
+    from transferattack_amd import _hip
+    host_kernels.install(monkeypatch, tag="timoob" + variant, env={"TA_TIM_VARIANT": variant})
+    gen = torch.Generator().manual_seed(2)
+    for shape, k in (((1, 1, 224, 224), 15), ((1, 1, 37, 41), 15), ((1, 1, 64, 64), 7), ((1, 1, 33, 33), 4)):
+        grad = torch.randn(shape, generator=gen).numpy()
+        w = torch.rand(k, k, generator=gen)
+        w = (w / w.sum()).contiguous()
+        for at_end in (True, False):
+            gg, keep = _guarded(grad, at_end)
+            out = torch.empty(shape)
+            _hip.depthwise_conv2d_same(torch.from_numpy(gg), out, w)
+            assert np.array_equal(out.numpy(), C.depthwise_conv2d_same(grad, w.numpy()))
+            del gg
+            keep = None

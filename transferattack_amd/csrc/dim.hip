@@ -13,6 +13,7 @@
 // The 1-D tap tables (and, for the backward, the inverse "which outputs touch this source index" ranges)
 // are rebuilt in LDS by every workgroup: <= 250 entries, cheaper than a host round trip per iteration.
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include "ta_common.h"
 
@@ -170,6 +171,140 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_sep_kernel(const float* __rest
         }
 }
 
+// Lane-per-column form of the separable forward (TA_DIM_FWD_VARIANT=2), written for instruction count: the shipped
+// gather spends ~190 instructions per output pixel (per-workgroup rebuild of all 460 taps, div/mod by the runtime window
+// width, 64-bit addressing), and its measured time is what instruction issue alone predicts.  Here
+//   * a tile is THO=32 output rows x `tw` (<= 64) output columns, `tw` chosen on the host so that the window of the
+//     padded image behind it is at most 64 columns wide: one LANE per window column, all four passes run over rows;
+//   * every lane builds only its own two column taps (registers) and at most one row tap (LDS); the two divisions
+//     in/out are done once on the host (same IEEE single division);
+//   * the x rows behind the window are fetched with all loads of a lane issued back to back (RPW rows per wave).
+// Arithmetic and rounding order are those of dim_fwd_sep_kernel / ATen (width first, then height) -> bit-identical.
+constexpr int kDimLaneRows = 32;        // THO
+
+__device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) {
+    float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    int i0 = static_cast<int>(src);
+    i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+    const int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    const float l1 = fminf(fmaxf(src - static_cast<float>(i0), 0.0f), 1.0f);
+    return Tap{i0, i1, 1.0f - l1, l1};
+}
+
+template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
+__global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               int size, int resize, int rnd, int top, int left,
+                                                               float scale1, float scale2, int tw, int tiles_x,
+                                                               int tiles_y) {
+    constexpr int ROWS = 4 * RPW;
+    __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
+    __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
+    __shared__ int corner[2];                                          // px_lo, px_hi
+    __shared__ __attribute__((aligned(16))) float T[ROWS * 64];        // H1 result; re-used as `u` by H2 / V2
+    __shared__ __attribute__((aligned(16))) float mid[ROWS * 64];      // the zero-padded, rescaled window
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
+    const int tiles = tiles_x * tiles_y;
+    const int plane = blockIdx.x / tiles;                              // grid < 2^31 (host-checked)
+    const int t = blockIdx.x - plane * tiles;
+    const int tyi = t / tiles_x;
+    const int oy0 = tyi * kDimLaneRows, ox0 = (t - tyi * tiles_x) * tw;
+    const int th = min(kDimLaneRows, size - oy0), twc = min(tw, size - ox0);    // rows / columns of this tile
+    const float* xp = x + static_cast<int64_t>(plane) * size * size;
+    float* yp = y + static_cast<int64_t>(plane) * size * size;
+
+    // -- taps that do not depend on the window origin
+    Tap tx2{0, 0, 0.f, 0.f};
+    if (lane < twc) tx2 = make_tap_scaled(ox0 + lane, resize, scale2);
+    if (threadIdx.x < th) ty2[threadIdx.x] = make_tap_scaled(oy0 + threadIdx.x, resize, scale2);
+    if (threadIdx.x == 64) corner[0] = tx2.i0;                         // lane 0 of wave 1
+    if (threadIdx.x == 64 + twc - 1) corner[1] = tx2.i1;
+    __syncthreads();
+    const int py_lo = ty2[0].i0, py_hi = ty2[th - 1].i1, px_lo = corner[0], px_hi = corner[1];
+    const int mh = py_hi - py_lo + 1, mw = px_hi - px_lo + 1;          // <= ROWS - 1, <= 64 (host-checked)
+    const int p_a = max(top - py_lo, 0), p_b = min(top + rnd - 1 - py_lo, mh - 1);   // window rows inside the image
+    // -- taps of the first resample for this lane's window column and for the valid window rows
+    const int rx = px_lo + lane - left;
+    const bool col_ok = lane < mw && rx >= 0 && rx < rnd;
+    Tap tx1{0, 0, 0.f, 0.f};
+    if (col_ok) tx1 = make_tap_scaled(rx, size, scale1);
+    {
+        const int p = static_cast<int>(threadIdx.x) - 64;              // waves 1.. build the row table
+        if (p >= p_a && p <= p_b) ty1[p] = make_tap_scaled(py_lo + p - top, size, scale1);
+    }
+    __syncthreads();
+    const bool any_rows = p_a <= p_b;
+    const int sr_lo = any_rows ? ty1[p_a].i0 : 0;
+    const int sh = any_rows ? ty1[p_b].i1 - sr_lo + 1 : 0;             // <= ROWS
+
+    // -- H1: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1]); all loads of the lane first, 32-bit element offsets
+    {
+        float a[RPW], b[RPW];
+        // 32-bit BYTE offsets from the wave-uniform plane pointer (4 * size * size < 2^32, host-checked): the loads
+        // take the scalar-base + 32-bit-offset form, no 64-bit address arithmetic per access
+        const char* base = reinterpret_cast<const char*>(xp);
+        const int w0 = min(wave, max(sh - 1, 0));                      // this wave's first row, inside the rectangle
+        const unsigned row0 = static_cast<unsigned>((sr_lo + w0) * size), bstep = 16u * static_cast<unsigned>(size);
+        const unsigned b0 = (row0 + static_cast<unsigned>(tx1.i0)) * 4u, b1 = (row0 + static_cast<unsigned>(tx1.i1)) * 4u;
+        // rows past the rectangle are clamped to its last row (scalar min) and lanes outside the image read column 0:
+        // every load is in bounds and unpredicated; what they produce is never read by V1
+        const int last = max(sh - 1 - w0, 0);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const unsigned off = static_cast<unsigned>(min(4 * i, last & ~3)) * (bstep / 4u);
+            a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
+            b[i] = *reinterpret_cast<const float*>(base + (b1 + off));
+        }
+        float* out = T + wave * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) out[i * 256] = fmaf(tx1.l0, a[i], tx1.l1 * b[i]);
+    }
+    __syncthreads();
+    // -- V1: mid[p][c] = fma(ly0, T[i0][c], ly1 * T[i1][c]) inside the rescaled image, 0 in the padding (dim.py:65)
+    {
+        const float* Tc = T + lane - sr_lo * 64;
+        float* out = mid + wave * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int p = wave + 4 * i;
+            float val = 0.0f;
+            if (col_ok && p >= p_a && p <= p_b) {
+                const Tap ty = ty1[p];
+                val = fmaf(ty.l0, Tc[ty.i0 * 64], ty.l1 * Tc[ty.i1 * 64]);
+            }
+            out[i * 256] = val;
+        }
+    }
+    __syncthreads();
+    // -- H2: u[p][ox] = fma(lx0, mid[p][i0], lx1 * mid[p][i1])      (u overwrites T: every lane is past V1)
+    float* u = T;
+    if (lane < twc) {
+        const float* m0 = mid + wave * 64 + (tx2.i0 - px_lo);
+        const float* m1 = mid + wave * 64 + (tx2.i1 - px_lo);
+        float* out = u + wave * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+            if (wave + 4 * i < mh) out[i * 256] = fmaf(tx2.l0, m0[i * 256], tx2.l1 * m1[i * 256]);
+    }
+    __syncthreads();
+    // -- V2: y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
+    if (lane < twc) {
+        const float* uc = u + lane - py_lo * 64;
+        char* base = reinterpret_cast<char*>(yp);
+        const unsigned first = static_cast<unsigned>((oy0 + wave) * size + ox0 + lane) * 4u, bstep = 16u * static_cast<unsigned>(size);
+#pragma unroll
+        for (int i = 0; i < kDimLaneRows / 4; ++i) {
+            const int r = wave + 4 * i;
+            if (r < th) {
+                const Tap ty = ty2[r];
+                *reinterpret_cast<float*>(base + (first + i * bstep)) = fmaf(ty.l0, uc[ty.i0 * 64], ty.l1 * uc[ty.i1 * 64]);
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------- backward
 constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
 constexpr int kDimBwdMaxMid = 80;       // side of the LDS-resident window of d(rescaled); rate <= ~2.4
@@ -298,11 +433,32 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     // a 32-pixel output tile reads at most this many padded pixels per axis
     const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimFwdTile) * resize, size)) + 3;
     TA_REQUIRE(mid_side <= kDimFwdMaxMid, "resize ratio %d/%d too large for the fused forward", resize, size);
-    // TA_DIM_FWD_VARIANT (tuning knob): 0 = 16-tap gather per window pixel, 1 = separable four-pass form
+    // TA_DIM_FWD_VARIANT (tuning knob): 0 = 16-tap gather per window pixel, 1 = separable four-pass form,
+    // 2 = separable, one lane per window column (falls back to 0 for resize ratios above ~2)
     static const int variant = []() {
         const char* e = getenv("TA_DIM_FWD_VARIANT");
         return e == nullptr ? kDimFwdVariantDefault : atoi(e);
     }();
+    if (variant == 2 && static_cast<int64_t>(size) * size < (1ll << 30)) {
+        const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
+        const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+        const double ratio = static_cast<double>(resize) / size;
+        const int tw = static_cast<int>(fmin(64.0, floor(61.0 / ratio) + 1.0));        // window <= (tw-1)*ratio + 3 <= 64
+        const int rows = static_cast<int>(ceil((kDimLaneRows - 1) * ratio)) + 4;       // window rows + 1 row of x
+        if (tw >= 8 && rows <= 68) {
+            const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
+            const int64_t lane_blocks = planes * tiles_x * tiles_y;
+            TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
+            const dim3 grid(static_cast<unsigned>(lane_blocks));
+            if (rows <= 40)
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+            return check_launch("dim_fwd_lanes");
+        }
+    }
     if (variant == 1 && mid_side <= 64 && static_cast<int64_t>(size) * size < (1ll << 31)) {
         const int ws = mid_side + 1;                     // the x rectangle can be one row taller than the window
         const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * (2 * ws * ws + ws * 32);
