@@ -68,6 +68,8 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only used on wave-uniform values */
 #define __builtin_assume(cond) ((void)0)
+namespace hipcpu { int wave_any(int pred); }
+static inline int __any(int pred) { return hipcpu::wave_any(pred); }
 /* streaming hints have no meaning on the host */
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

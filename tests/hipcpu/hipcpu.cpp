@@ -125,6 +125,20 @@ float shfl_xor(float v, int lane_mask, int width) {
     return got;
 }
 
+int wave_any(int pred) {                                  // every lane of the wave must call it (as on the device)
+    Worker* w = worker;
+    const unsigned t = w->current, wave = t / 64, lane = t & 63;
+    w->slots[64 * wave + lane] = pred ? 1.0f : 0.0f;
+    wave_barrier(w, wave);
+    int any = 0;
+    for (unsigned l = 0; l < 64; ++l) {
+        const unsigned other = 64 * wave + l;
+        if (other < w->lanes.size() && !w->lanes[other].done && w->slots[other] != 0.0f) any = 1;
+    }
+    wave_barrier(w, wave);
+    return any;
+}
+
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
     (void)smem_bytes;                                     // dynamic LDS is a fixed 160 KiB array (build.py)
     const unsigned lanes = block.x * block.y * block.z;

@@ -151,3 +151,11 @@ def test_tim_reads_stay_in_bounds(monkeypatch, variant):
             assert np.array_equal(out.numpy(), C.depthwise_conv2d_same(grad, w.numpy()))
             del gg
             keep = None
+
+
+def test_dim_lane_per_column_backward(monkeypatch, golden):
+    host_kernels.install(monkeypatch, tag="dimbwdlanes", env={"TA_DIM_BWD_VARIANT": "1", "TA_DIM_FWD_VARIANT": "2"})
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
+    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
+    G.test_dim_random(33, 2.0, [(40, 5, 20), (65, 0, 1)])                  # ratio 2: falls back to the table-driven form

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
 
 // --------------------------------------------------------------------------------------- backward
 constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
+constexpr int kDimBwdVariantDefault = 0;
 constexpr int kDimBwdMaxMid = 80;       // side of the LDS-resident window of d(rescaled); rate <= ~2.4
 
 struct Range {
@@ -412,6 +413,227 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
     }
 }
 
+
+// Lane-per-column form of the backward (TA_DIM_BWD_VARIANT=1), the counterpart of dim_fwd_lanes_kernel.  The adjoint
+// cannot be made separable without changing the rounding (ATen accumulates fma(ly*lx, g, acc) over the output pixels in
+// row-major order), so both stages stay 2-D gathers in that order -- but the bookkeeping changes:
+//   * the outputs that touch one source index form a contiguous run o = first .. first+n-1 (taps are monotone), n <= 3
+//     when downsampling (scale >= 1) and <= 4 when upsampling by at most 1.5: a `Hit` holds first, n and the weight each
+//     of them contributes (the tap that equals the index; both taps only at the clamped border);
+//   * a lane owns one COLUMN of the stage's target (its Hit lives in registers), waves stride over rows whose Hit is
+//     wave-uniform (scalar loop bounds), so the inner loops are n_y x K predicated fma's with no searching, no div/mod;
+//   * tile = 32 rows x tw <= 64 columns of gx, tw chosen on the host so the window of d(rescaled) is <= 64 columns.
+constexpr int kHitSlots = 4;
+struct Hit {
+    int first, n;
+    unsigned both;                 // bit k: output first+k hits the index with BOTH taps (clamped border): w then w2
+    float w[kHitSlots], w2[kHitSlots];
+    int pad;
+};
+
+// outputs o of a 1-D resample (in_size -> out_size, scale = in/out) whose taps touch source index t
+__device__ __forceinline__ Hit find_hits(int t, int in_size, int out_size, float scale) {
+    Hit h;
+    h.first = 0; h.n = 0; h.both = 0u; h.pad = 0;
+#pragma unroll
+    for (int k = 0; k < kHitSlots; ++k) { h.w[k] = 0.0f; h.w2[k] = 0.0f; }
+    // src(o) >= t-1  <=>  o >= (t-0.5)/scale - 0.5 ; start two below the estimate, the taps themselves decide
+    const float est = (static_cast<float>(t) - 0.5f) / scale - 0.5f;
+    int c = static_cast<int>(floorf(est)) - 1;
+    c = c < 0 ? 0 : c;
+    int first = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int o = c + j;
+        if (o < out_size && first < 0) {
+            const Tap tp = make_tap_scaled(o, in_size, scale);
+            if (tp.i0 == t || tp.i1 == t) first = o;
+        }
+    }
+    if (first < 0) return h;
+    h.first = first;
+    bool open = true;
+#pragma unroll
+    for (int k = 0; k < kHitSlots; ++k) {
+        const int o = first + k;
+        if (open && o < out_size) {
+            const Tap tp = make_tap_scaled(o, in_size, scale);
+            const bool h0 = tp.i0 == t, h1 = tp.i1 == t;
+            if (h0 || h1) {
+                h.w[k] = h0 ? tp.l0 : tp.l1;
+                h.w2[k] = tp.l1;
+                if (h0 && h1) h.both |= 1u << k;
+                h.n = k + 1;
+            } else {
+                open = false;
+            }
+        } else {
+            open = false;
+        }
+    }
+    return h;
+}
+
+// One source value g reached through a row slot (weight wy; wy2 if the row hits with both taps) and column slot k of
+// hx, accumulated in ATen's order (a = 0, 1 outer; b = 0, 1 inner).  Branch-free: a slot that does not apply gets
+// weight 0 and g = 0, and fma(0, 0, acc) == acc bit for bit (acc starts at +0 and a sum never produces -0; the masked
+// g keeps a non-finite neighbour out).  FAST = no lane of the wave and not this row has a double hit (everywhere
+// except the clamped last row / column): one multiply and one fma per slot.
+template <bool FAST>
+__device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, float wy2, bool both_y, const Hit& hx, int k) {
+    const bool on = k < hx.n;
+    const float gm = on ? g : 0.0f;
+    const float wx = hx.w[k];                                  // 0 beyond n (find_hits)
+    acc = fmaf(wy * wx, gm, acc);
+    if (!FAST) {
+        const bool bx = on && ((hx.both >> k) & 1u);
+        const float g2 = bx ? g : 0.0f;
+        const float wx2 = bx ? hx.w2[k] : 0.0f;
+        acc = fmaf(wy * wx2, g2, acc);
+        if (both_y) {
+            acc = fmaf(wy2 * wx, gm, acc);
+            acc = fmaf(wy2 * wx2, g2, acc);
+        }
+    }
+    return acc;
+}
+
+template <int RPW>
+__global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                               int size, int resize, int rnd, int top, int left,
+                                                               float scale1, float scale2, int tw, int tiles_x,
+                                                               int tiles_y) {
+    constexpr int ROWS = 4 * RPW;
+    __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
+    __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
+    __shared__ __attribute__((aligned(16))) Hit colA[64];               // window column px -> output columns
+    __shared__ __attribute__((aligned(16))) Hit rowA[ROWS];             // window row py    -> output rows
+    __shared__ __attribute__((aligned(16))) float mid[ROWS * 64];       // d(rescaled) window
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = tiles_x * tiles_y;
+    const int plane = blockIdx.x / tiles;
+    const int t = blockIdx.x - plane * tiles;
+    const int tyi = t / tiles_x;
+    const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
+    const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
+    const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
+    char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
+
+    // -- stage-B tables: which rescaled pixels feed this tile of x
+    if (wave == 0 && lane < twc) colB[lane] = find_hits(ix0 + lane, size, rnd, scale1);
+    if (wave == 1 && lane < th) rowB[lane] = find_hits(iy0 + lane, size, rnd, scale1);
+    __syncthreads();
+    const int rx_lo = colB[0].first, rx_hi = colB[twc - 1].first + colB[twc - 1].n - 1;
+    const int ry_lo = rowB[0].first, ry_hi = rowB[th - 1].first + rowB[th - 1].n - 1;
+    const int mw = rx_hi - rx_lo + 1, mh = ry_hi - ry_lo + 1;           // <= 64, <= ROWS (host-checked)
+    // -- stage-A tables: which output pixels feed that window (through the zero padding: px = rx + left, py = ry + top)
+    if (wave == 0 && lane < mw) colA[lane] = find_hits(rx_lo + lane + left, resize, size, scale2);
+    {
+        const int p = static_cast<int>(threadIdx.x) - 64;
+        if (p >= 0 && p < mh) rowA[p] = find_hits(ry_lo + p + top, resize, size, scale2);
+    }
+    __syncthreads();
+
+    // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c]
+    {
+        Hit hx = colA[lane < mw ? lane : 0];
+        if (lane >= mw) hx.n = 0;
+        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
+        unsigned col[kHitSlots - 1];                                    // byte offsets of the lane's output columns
+#pragma unroll
+        for (int k = 0; k < kHitSlots - 1; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        // software pipeline over the wave's rows: the 9 loads of row p + 4 are in flight while row p is accumulated
+        auto fetch = [&](int p, float (&g)[kHitSlots - 1][kHitSlots - 1]) {
+            const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
+#pragma unroll
+            for (int ky = 0; ky < kHitSlots - 1; ++ky) {
+                const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
+#pragma unroll
+                for (int kx = 0; kx < kHitSlots - 1; ++kx) g[ky][kx] = *reinterpret_cast<const float*>(gyp + (row + col[kx]));
+            }
+        };
+        auto reduce = [&](int p, const float (&g)[kHitSlots - 1][kHitSlots - 1]) {
+            const Hit* hy = &rowA[p];
+            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);                    // <= 3: scale2 >= 1
+            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+            float acc = 0.0f;
+            if (!any_both_x && both_y == 0u) {
+#pragma unroll
+                for (int ky = 0; ky < kHitSlots - 1; ++ky)
+                    if (ky < n_y)
+#pragma unroll
+                        for (int kx = 0; kx < kHitSlots - 1; ++kx)
+                            acc = hit_accumulate<true>(acc, g[ky][kx], hy->w[ky], 0.0f, false, hx, kx);
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < kHitSlots - 1; ++ky)
+                    if (ky < n_y)
+#pragma unroll
+                        for (int kx = 0; kx < kHitSlots - 1; ++kx)
+                            acc = hit_accumulate<false>(acc, g[ky][kx], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+            }
+            mid[p * 64 + lane] = acc;
+        };
+        float ga[kHitSlots - 1][kHitSlots - 1], gb[kHitSlots - 1][kHitSlots - 1];
+        // the prefetch is unconditional (row index clamped to the window) so that the compiler's wait counters know,
+        // on every path, that the nine newest loads are not the ones being consumed
+        int p = wave;
+        if (p < mh) fetch(p, ga);
+#pragma unroll 1
+        while (p < mh) {
+            fetch(min(p + 4, mh - 1), gb);
+            reduce(p, ga);
+            p += 4;
+            if (p >= mh) break;
+            fetch(min(p + 4, mh - 1), ga);
+            reduce(p, gb);
+            p += 4;
+        }
+    }
+    __syncthreads();
+    // -- stage B: gx[iy][ix]
+    if (lane < twc) {
+        const Hit hx = colB[lane];
+        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
+        int col[kHitSlots];
+#pragma unroll
+        for (int k = 0; k < kHitSlots; ++k) col[k] = min(hx.first - rx_lo + k, 63);
+        unsigned out = static_cast<unsigned>((iy0 + wave) * size + ix0 + lane) * 4u;
+        const unsigned bstep = 16u * static_cast<unsigned>(size);
+#pragma unroll 1
+        for (int r = wave; r < th; r += 4, out += bstep) {
+            const Hit* hy = &rowB[r];
+            const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
+            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
+            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+            float acc = 0.0f;
+            if (!any_both_x && both_y == 0u) {
+#pragma unroll
+                for (int ky = 0; ky < kHitSlots; ++ky)
+                    if (ky < n_y) {
+                        const float* mrow = mid + (first_y + ky) * 64;
+#pragma unroll
+                        for (int kx = 0; kx < kHitSlots; ++kx)
+                            acc = hit_accumulate<true>(acc, mrow[col[kx]], hy->w[ky], 0.0f, false, hx, kx);
+                    }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < kHitSlots; ++ky)
+                    if (ky < n_y) {
+                        const float* mrow = mid + (first_y + ky) * 64;
+#pragma unroll
+                        for (int kx = 0; kx < kHitSlots; ++kx)
+                            acc = hit_accumulate<false>(acc, mrow[col[kx]], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+                    }
+            }
+            *reinterpret_cast<float*>(gxp + out) = acc;
+        }
+    }
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -479,6 +701,32 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, 
     // a 32-pixel tile of x (plus one neighbour each side) is fed by at most this many rescaled pixels per axis
     const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimBwdTile + 2) * rnd, size)) + 3;
     TA_REQUIRE(mid_side <= kDimBwdMaxMid, "resize ratio %d/%d too large for the fused backward", rnd, size);
+    // TA_DIM_BWD_VARIANT (tuning knob): 0 = table-driven gather, 1 = lane-per-column gather (needs resize > size,
+    // resize <= 1.5 * size and < 2^28 elements per plane; otherwise 0 runs)
+    static const int bwd_variant = []() {
+        const char* e = getenv("TA_DIM_BWD_VARIANT");
+        return e == nullptr ? kDimBwdVariantDefault : atoi(e);
+    }();
+    if (bwd_variant == 1 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+        const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
+        const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+        const double up = static_cast<double>(resize) / size;                          // bound for rnd / size
+        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));           // window <= (tw + 1) * up + 1 <= 64
+        const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
+        if (tw >= 8 && rows <= 68) {
+            const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
+            const int64_t lane_blocks = planes * tiles_x * tiles_y;
+            TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
+            const dim3 grid(static_cast<unsigned>(lane_blocks));
+            if (rows <= 40)
+                hipLaunchKernelGGL(dim_bwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(dim_bwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+            return check_launch("dim_bwd_lanes");
+        }
+    }
     const int tps = static_cast<int>(ceil_div(size, kDimBwdTile));
     const int64_t blocks = planes * tps * tps;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
