@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, probes, rocprof.  Everything lands in gpurun_out/<tag>/.
-# usage: tools/gpu_check.sh <tag> [steps...]   steps: tests smoke bench probe rocprof pmc
+# usage: tools/gpu_check.sh <tag> [steps...]   steps: tests smoke bench probe rocprof pmc dimvariants widened ...
 TAG=${1:-r1}; shift
 STEPS=${@:-tests smoke bench rocprof}
 OUT=gpurun_out/$TAG
@@ -25,6 +25,12 @@ kernels)
 timvariants)
   for v in 0 1 2; do TA_TIM_VARIANT=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('variant=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
   TA_TIM_VARIANT=2 timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2 ;;
+dimvariants)
+  # first thing to run next round: parity of the lane-per-column DIM kernels on the device, then their timing
+  TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 300 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -k "dim or dts" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/dim_variants_pytest.txt
+  for v in "0 0" "2 0" "0 1" "2 1"; do set -- $v; TA_DIM_FWD_VARIANT=$1 TA_DIM_BWD_VARIANT=$2 timeout 120 python tools/dim_time.py; done 2>&1 | tee $OUT/dim_variants.txt ;;
+widened)
+  timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider 2>&1 | tail -12 | tee $OUT/widened_pytest.txt ;;
 k2sweep)
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
 fast)
