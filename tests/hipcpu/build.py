@@ -19,6 +19,7 @@ def _host_text(text):
     text = text.replace('#include "../../include/ta_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "ta_hip.h"))
     # clang's ext_vector_type has no g++ counterpart with .x/.y members
     text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
+    text = text.replace("typedef float v2f __attribute__((ext_vector_type(2)));", "struct alignas(8) v2f { float x, y; };")
     return text
 
 

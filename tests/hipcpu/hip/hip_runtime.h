@@ -70,6 +70,9 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* on
 #define __builtin_assume(cond) ((void)0)
 namespace hipcpu { int wave_any(int pred); }
 static inline int __any(int pred) { return hipcpu::wave_any(pred); }
+template <class V> static inline V __builtin_elementwise_fma(V a, V b, V c) {     /* clang's vector fma, per element */
+    return V{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
+}
 /* streaming hints have no meaning on the host */
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

@@ -45,7 +45,7 @@ def test_fused_update_random(shape):
 
 
 # ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_tim_variants(monkeypatch, golden, variant):
     host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
     G.test_tim_golden(golden)
@@ -74,7 +74,7 @@ def test_bad_arguments_fail_loudly():
 
 
 # ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_tim_variants(monkeypatch, golden, variant):
     host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
     G.test_tim_golden(golden)
@@ -135,7 +135,7 @@ def test_dim_reads_stay_in_bounds(monkeypatch, variant):
             keep = None
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_tim_reads_stay_in_bounds(monkeypatch, variant):
     from transferattack_amd import _hip
     host_kernels.install(monkeypatch, tag="timoob" + variant, env={"TA_TIM_VARIANT": variant})

@@ -23,8 +23,8 @@ batches)
 kernels)
   timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
 timvariants)
-  for v in 0 1 2; do TA_TIM_VARIANT=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('variant=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
-  TA_TIM_VARIANT=2 timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2 ;;
+  for v in 0 1 2 3; do TA_TIM_VARIANT=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('variant=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
+  for v in 2 3; do TA_TIM_VARIANT=$v timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2; done ;;
 dimvariants)
   # first thing to run next round: parity of the lane-per-column DIM kernels on the device, then their timing
   TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 300 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -k "dim or dts" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/dim_variants_pytest.txt

@@ -30,7 +30,9 @@ constexpr int conv_lds_stride(int k) {
     return s;
 }
 
-template <int K, int TH, bool FAST_LOAD, bool PIPELINED>
+typedef float v2f __attribute__((ext_vector_type(2)));     // one v_pk_fma_f32 operand: an even-aligned register pair
+
+template <int K, int TH, bool FAST_LOAD, bool PIPELINED, bool PAIRS = false>
 __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* __restrict__ in,
                                                              float* __restrict__ out,
                                                              const float* __restrict__ w, int h, int wd,
@@ -93,6 +95,61 @@ __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* 
     const int xg = threadIdx.x % kConvXG;
     const int row = threadIdx.x / kConvXG;
     float acc[kConvPT];
+    if constexpr (PAIRS) {
+        // Explicit register pairs (TA_TIM_VARIANT=3).  The packed FMA reads EVEN-aligned register pairs, so with the
+        // outputs paired (2c, 2c+1) the window pair (win[2c+kx], win[2c+kx+1]) is aligned for even kx only; left to
+        // itself the compiler re-pairs with ~35 v_mov per kernel row and falls back to scalar v_fmac for the last row.
+        // Here the window is held twice -- winE[j] = (win[2j], win[2j+1]) straight from the 8-byte LDS reads, and
+        // winO[j] = (win[2j+1], win[2j+2]) built once per kernel row with one v_pk_mov_b32 per pair and shared by all
+        // odd kx -- and every FMA of every row is a packed one: 105 + 13 VALU per kernel row instead of ~141 (+ ~98
+        // for the unpacked last row).  Each accumulator still sees its taps in (ky, kx) order: bit-identical.
+        static_assert(K % 2 == 1 && kConvPT % 2 == 0, "pair layout assumes an odd kernel and an even strip");
+        constexpr int NE = (kConvPT + K) / 2;               // pairs covering win[0 .. PT + K - 2]
+        constexpr int NC = kConvPT / 2;                     // accumulator pairs
+        v2f acc2[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc2[c] = v2f{0.0f, 0.0f};
+        auto load_pairs = [&](v2f (&win)[NE], int ky) {
+            const v2f* lp = reinterpret_cast<const v2f*>(&tile[(row + ky) * LS + xg * kConvPT]);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) win[j] = lp[j];
+        };
+        auto load_row_weights = [&](float (&wk)[K], int ky) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) wk[kx] = w[ky * K + kx];
+        };
+        auto fma_pairs = [&](const v2f (&winE)[NE], const float (&wk)[K]) {
+            v2f winO[NE - 1];
+#pragma unroll
+            for (int j = 0; j < NE - 1; ++j) winO[j] = v2f{winE[j].y, winE[j + 1].x};
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const v2f wv = v2f{wk[kx], wk[kx]};
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    acc2[c] = __builtin_elementwise_fma(wv, (kx & 1) ? winO[c + kx / 2] : winE[c + kx / 2], acc2[c]);
+            }
+        };
+        v2f win_a[NE], win_b[NE];
+        float wk_a[K], wk_b[K];
+        load_pairs(win_a, 0);
+        load_row_weights(wk_a, 0);
+#pragma unroll 1
+        for (int ky = 0; ky + 1 < K; ky += 2) {
+            load_pairs(win_b, ky + 1);
+            load_row_weights(wk_b, ky + 1);
+            fma_pairs(win_a, wk_a);
+            load_pairs(win_a, ky + 2);                      // K odd: row ky + 2 <= K - 1 always exists
+            load_row_weights(wk_a, ky + 2);
+            fma_pairs(win_b, wk_b);
+        }
+        fma_pairs(win_a, wk_a);                             // the last row, packed like the others
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[2 * c] = acc2[c].x;
+            acc[2 * c + 1] = acc2[c].y;
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < kConvPT; ++r) acc[r] = 0.0f;
 
@@ -144,6 +201,7 @@ __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* 
             fma_row(win, wk);
         }
     }
+    }   // !PAIRS
 
     const int oy = y0 + row;
     if (oy < h) {
@@ -219,22 +277,24 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
     const dim3 grid(static_cast<unsigned>(blocks));
     const bool fast = w_ <= kConvTW && w_ % 4 == 0 && aligned16(in) && (static_cast<int64_t>(h) * w_) % 4 == 0;
     // TA_TIM_VARIANT (tuning knob): 0 = 16-row tiles, rolled rows; 1 = 16-row tiles, software-pipelined rows;
-    // 2 = 14-row tiles (224 lanes, 32.3 KB LDS -> 5 workgroups per CU), rolled rows
+    // 2 = 14-row tiles (224 lanes, 32.3 KB LDS -> 5 workgroups per CU), rolled rows; 3 = variant 1 with explicit
+    // register pairs (every FMA packed, one v_pk_mov per shifted window pair)
     static const int variant = []() {
         const char* e = getenv("TA_TIM_VARIANT");
         return e == nullptr ? kTimVariantDefault : atoi(e);
     }();
     switch (k) {
-#define TA_CONV_LAUNCH(KK, TH, FAST, PIPE)                                                                     \
-    hipLaunchKernelGGL((dwconv_same_kernel<KK, TH, FAST, PIPE>), dim3(static_cast<unsigned>(planes * tiles_x *   \
-                       ceil_div(h, TH))), dim3(TH * kConvXG), 0, st, in, out, w, h, w_, tiles_x,                \
+#define TA_CONV_LAUNCH(KK, TH, FAST, PIPE, PAIRS)                                                              \
+    hipLaunchKernelGGL((dwconv_same_kernel<KK, TH, FAST, PIPE, PAIRS>), dim3(static_cast<unsigned>(planes *      \
+                       tiles_x * ceil_div(h, TH))), dim3(TH * kConvXG), 0, st, in, out, w, h, w_, tiles_x,      \
                        static_cast<int>(ceil_div(h, TH)))
 #define TA_CONV(KK)                                                                                  \
     case KK:                                                                                         \
-        if (fast && variant == 2) { TA_CONV_LAUNCH(KK, 14, true, false); }                           \
-        else if (fast && variant == 1) { TA_CONV_LAUNCH(KK, 16, true, true); }                       \
-        else if (fast) { TA_CONV_LAUNCH(KK, 16, true, false); }                                      \
-        else { TA_CONV_LAUNCH(KK, 16, false, false); }                                               \
+        if (fast && variant == 3) { TA_CONV_LAUNCH(KK, 16, true, true, true); }                      \
+        else if (fast && variant == 2) { TA_CONV_LAUNCH(KK, 14, true, false, false); }               \
+        else if (fast && variant == 1) { TA_CONV_LAUNCH(KK, 16, true, true, false); }                \
+        else if (fast) { TA_CONV_LAUNCH(KK, 16, true, false, false); }                               \
+        else { TA_CONV_LAUNCH(KK, 16, false, false, false); }                                        \
         break;
         TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
 #undef TA_CONV
