@@ -3,7 +3,7 @@
 // Lets a kernel source file of transferattack_amd/csrc be compiled with g++ and executed on the CPU so that the
 // kernel's LOGIC (indexing, staging through "LDS", barriers, rounding order) can be checked bit for bit against the
 // oracle in a container that has no GPU.  It says nothing about speed and is never part of the product: only tests/
-// builds it (tests/hipcpu/build.py), the package cannot import it.
+// builds it (tests/hipcpu/hipcpu_build.py), the package cannot import it.
 //
 // Model: every lane of a workgroup is a fiber (ucontext) on one OS thread; __syncthreads() and the wave shuffles park
 // the fiber until its group has arrived.  Workgroups are independent, so a small pool of OS threads runs them side by
@@ -21,7 +21,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static thread_local    /* `extern __shared__` is rewritten to `extern thread_local` by build.py */
+#define __shared__ static thread_local    /* `extern __shared__` is rewritten to `extern thread_local` by hipcpu_build.py */
 
 struct dim3 {
     unsigned x, y, z;

@@ -140,7 +140,7 @@ int wave_any(int pred) {                                  // every lane of the w
 }
 
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
-    (void)smem_bytes;                                     // dynamic LDS is a fixed 160 KiB array (build.py)
+    (void)smem_bytes;                                     // dynamic LDS is a fixed 160 KiB array (hipcpu_build.py)
     const unsigned lanes = block.x * block.y * block.z;
     const uint64_t groups = static_cast<uint64_t>(grid.x) * grid.y * grid.z;
     unsigned pool = std::thread::hardware_concurrency();

@@ -10,7 +10,7 @@ import types
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipcpu"))
-import build as hipcpu_build            # noqa: E402
+import hipcpu_build                    # noqa: E402
 from transferattack_amd import _hip     # noqa: E402
 
 _libs = {}
