@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 2
+#define TA_ABI_VERSION 3
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -115,6 +115,21 @@ int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64
                  int num_scale, float strength, void* stream);
 int ta_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale,
                  void* stream);
+
+/* ---- SIA block transform: SIA.blocktransform / transform  input_transformation/sia.py:41-100 -------------
+ * Every copy of the batch is cut into nb x nb rectangles; each gets one operation: 0 roll rows, 1 roll columns,
+ * 2 flip rows, 3 flip columns, 4 rotate 180, 5 multiply by a scalar, 6 add U(-noise_radius, noise_radius) and clip to
+ * [0, 1].  `plan` (device int32) holds, per copy: rows[nb+1], cols[nb+1] (cut positions incl. 0 and h / w), then per
+ * rectangle (rows outer) op, roll step, scale factor (float bits) -- drawn on the host in the reference's order.
+ * `planes` = N*C; y / gy are [copies][planes][h][w].  `noise` (nullable, same shape as y; only the op-6 rectangles
+ * are read) replaces the in-kernel Philox (seed, offset) stream.
+ * fwd: y[k] = blockwise op(x).   bwd: gx = sum_k (k descending = autograd's order) of the gradient routed back
+ * through copy k's permutation / scale / clip mask (0 <= x + noise <= 1); needs x and the same noise as the forward. */
+int ta_sia_fwd(const float* x, const int32_t* plan, const float* noise, float* y, int64_t planes, int h, int w,
+               int copies, int nb, float noise_radius, uint64_t seed, uint64_t offset, void* stream);
+int ta_sia_bwd(const float* gy, const int32_t* plan, const float* x, const float* noise, float* gx,
+               int64_t planes, int h, int w, int copies, int nb, float noise_radius, uint64_t seed,
+               uint64_t offset, void* stream);
 
 /* ---- VMI-FGSM: VMIFGSM.get_variance  gradient/vmifgsm.py:42-58 --------------------------------------
  * neighbour: out = x + d + U(-radius, radius)   (Philox (seed, offset) or caller `noise`)

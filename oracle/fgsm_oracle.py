@@ -161,6 +161,77 @@ def admix_copies(x, perms, admix_strength=0.2, num_scale=5):
     return torch.cat([mixed / (2 ** i) for i in range(num_scale)])
 
 
+SIA_OPS = ("vertical_shift", "horizontal_shift", "vertical_flip", "horizontal_flip", "rotate180", "scale", "add_noise")
+SIA_NOISE = 16 / 255            # sia.py:67: the noise radius is a constant of the method, not the attack's epsilon
+
+
+def sia_draw(shape, num_block=3, num_copies=20, noise_source=None):
+    """The random choices of ``num_copies`` calls of SIA.blocktransform on a tensor of ``shape`` (N,C,H,W), drawn in
+    the reference's order from the reference's generators (sia.py:86-100): numpy -- column cuts, row cuts, then per
+    block (rows outer, columns inner) the operation index and, for the two shifts, the roll step; torch -- the scale
+    factor ``torch.rand(1)[0]`` and the block-shaped uniform noise.  Returns one dict per copy:
+    rows / cols (cut positions incl. 0 and the size) and blocks = [(op, step, scale, noise)] in visiting order."""
+    import numpy as np
+    n, c, height, width = shape
+    plans = []
+    for _ in range(num_copies):
+        cols = [0] + np.random.choice(list(range(1, width)), num_block - 1, replace=False).tolist() + [width]
+        rows = [0] + np.random.choice(list(range(1, height)), num_block - 1, replace=False).tolist() + [height]
+        cols.sort()
+        rows.sort()
+        blocks = []
+        for i in range(num_block):
+            for j in range(num_block):
+                bh, bw = rows[i + 1] - rows[i], cols[j + 1] - cols[j]
+                op = int(np.random.randint(0, high=len(SIA_OPS), dtype=np.int32))
+                step, scale, noise = 0, None, None
+                if op == 0:
+                    step = int(np.random.randint(low=0, high=bh, dtype=np.int32))
+                elif op == 1:
+                    step = int(np.random.randint(low=0, high=bw, dtype=np.int32))
+                elif op == 5:
+                    scale = torch.rand(1)[0]
+                elif op == 6:
+                    noise = (noise_source((n, c, bh, bw), -SIA_NOISE, SIA_NOISE) if noise_source is not None
+                             else torch.zeros(n, c, bh, bw).uniform_(-SIA_NOISE, SIA_NOISE))
+                blocks.append((op, step, scale, noise))
+        plans.append(dict(rows=rows, cols=cols, blocks=blocks))
+    return plans
+
+
+def sia_apply(x, plans):
+    """cat over the copies of the block-wise transformed clone of x (sia.py:86-100) -- the ATen ops the reference's
+    seven operations run (roll / flip / rot90 / mul / add+clip), applied to the same slices in the same order, so
+    both the values and the autograd accumulation order are the reference's."""
+    outs = []
+    for plan in plans:
+        rows, cols = plan["rows"], plan["cols"]
+        nb = len(rows) - 1
+        y = x.clone()
+        for i in range(nb):
+            for j in range(nb):
+                op, step, scale, noise = plan["blocks"][i * nb + j]
+                region = (slice(None), slice(None), slice(rows[i], rows[i + 1]), slice(cols[j], cols[j + 1]))
+                block = y[region]
+                if op == 0:
+                    block = block.roll(step, dims=2)
+                elif op == 1:
+                    block = block.roll(step, dims=3)
+                elif op == 2:
+                    block = block.flip(dims=(2,))
+                elif op == 3:
+                    block = block.flip(dims=(3,))
+                elif op == 4:
+                    block = block.rot90(k=2, dims=(2, 3))
+                elif op == 5:
+                    block = scale * block
+                else:
+                    block = torch.clip(block + noise, 0, 1)
+                y[region] = block
+        outs.append(y)
+    return torch.cat(outs)
+
+
 # ------------------------------------------------------------------------------------------------
 # surrogate wrapper (utils.py:37-60, 72-79) and ensemble (utils.py:82-105)
 # ------------------------------------------------------------------------------------------------

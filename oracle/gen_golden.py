@@ -257,6 +257,30 @@ def gen_loops_ens():
     save("loops_ens", **out)
 
 
+def gen_sia():
+    """SIA's block transform (input_transformation/sia.py:86-100) by the reference's own class --
+    the 20-copy stack of one seeded batch, the gradient autograd sends back through it, and a whole K=10 loop."""
+    ref_shim.neutralise_cuda_calls()
+    gen = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 32, 40, generator=gen)
+    atk = ref_shim.make_reference_attack("sia", backbones.create("toy_cnn", seed=3, verbose=False))
+    np.random.seed(7)
+    torch.manual_seed(8)
+    xin = x.clone().requires_grad_(True)
+    y = atk.transform(xin)
+    gy = torch.randn(y.shape, generator=gen)
+    gx = torch.autograd.grad(y, xin, gy)[0]
+    out = dict(x=x, y=y.detach(), gy=gy, gx=gx, np_seed=7, torch_seed=8)
+    n, size = 4, 32
+    xl = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    atk = ref_shim.make_reference_attack("sia", backbones.create("toy_cnn", seed=3, verbose=False), num_scale=4)
+    np.random.seed(99)
+    torch.manual_seed(1234)
+    out["delta_sia"] = atk(xl, label)
+    save("sia", **out)
+
+
 def gen_config1():
     """BASELINE.json configs[0]: I-FGSM on ResNet-18, 16 images, eps=16/255, K=10, CPU reference path."""
     n = 16
@@ -273,6 +297,6 @@ def gen_config1():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "config1"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1"]
     for w in which:
         globals()["gen_" + w]()

@@ -151,7 +151,41 @@ def quantize_u8_nhwc(data, delta, out):
     out.copy_(_t(O.quantize_u8(data + delta)))
 
 
-_NAMES = ["momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+def _sia_plans(plan, num_block, n, noise):
+    """decode the int32 plan table of transforms.sia_draw back into the oracle's per-copy dictionaries"""
+    import struct
+    plans = []
+    for k, row in enumerate(plan.cpu().numpy()):
+        rows, cols = row[:num_block + 1].tolist(), row[num_block + 1:2 * (num_block + 1)].tolist()
+        blocks, cell = [], 2 * (num_block + 1)
+        for i in range(num_block):
+            for j in range(num_block):
+                op, step, bits = (int(v) for v in row[cell:cell + 3])
+                cell += 3
+                scale = torch.tensor(struct.unpack("<f", struct.pack("<i", bits))[0], dtype=torch.float32)
+                nz = None
+                if op == 6:
+                    nz = noise[k * n:(k + 1) * n, :, rows[i]:rows[i + 1], cols[j]:cols[j + 1]]
+                blocks.append((op, step, scale, nz))
+        plans.append(dict(rows=rows, cols=cols, blocks=blocks))
+    return plans
+
+
+def sia_fwd(x, plan, y, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
+    calls.append("sia_fwd")
+    assert noise is not None, "the fake has no Philox stream for SIA: inject the noise"
+    y.copy_(O.sia_apply(x, _sia_plans(plan, num_block, x.shape[0], noise)))
+
+
+def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
+    calls.append("sia_bwd")
+    with torch.enable_grad():
+        xin = x.detach().clone().requires_grad_(True)
+        y = O.sia_apply(xin, _sia_plans(plan, num_block, x.shape[0], noise))
+        gx.copy_(torch.autograd.grad(y, xin, gy)[0])
+
+
+_NAMES = ["sia_fwd", "sia_bwd", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd"]

@@ -66,6 +66,7 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only used on wave-uniform values */
 #define __builtin_assume(cond) ((void)0)
 namespace hipcpu { int wave_any(int pred); }

@@ -159,3 +159,23 @@ def test_dim_lane_per_column_backward(monkeypatch, golden):
     G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
     G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
     G.test_dim_random(33, 2.0, [(40, 5, 20), (65, 0, 1)])                  # ratio 2: falls back to the table-driven form
+
+
+# ---- SIA: the (not yet run) GPU tests of tests/test_zz_hip_widened.py, on the host stand-in
+import test_zz_hip_widened as W          # noqa: E402
+
+
+@pytest.fixture
+def widened_on_host(monkeypatch):
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0)
+
+
+def test_sia_kernels_golden(golden, widened_on_host):
+    W.test_sia_kernels_golden(golden)
+
+
+@pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 5), ((1, 3, 37, 41), 3, 4), ((3, 1, 16, 100), 2, 3),
+                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2)])
+def test_sia_kernels_random(widened_on_host, shape, nb, copies):
+    W.test_sia_kernels_random(shape, nb, copies)

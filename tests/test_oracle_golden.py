@@ -184,3 +184,19 @@ def test_c_oracle_copies_and_normalize(golden):
     assert same(C.normalize_bwd(gy.numpy(), std), torch.autograd.grad(y, xin, gy)[0].numpy())
     acc, cur = torch.randn(4, 7, generator=gen), torch.randn(4, 7, generator=gen)
     assert same(C.variance_finalize(acc.numpy(), cur.numpy(), 20), (acc / 20 - cur).numpy())
+
+
+def test_sia_block_transform(golden):
+    """SIA (sia.py:86-100): the oracle's draw order (numpy cuts / ops / steps, torch scale factors and noise) and its
+    restatement of the seven block operations reproduce the reference's 20-copy stack and the gradient autograd
+    returns through it (copy accumulation order included), bit for bit."""
+    g = golden("sia")
+    x, gy = t(g["x"]), t(g["gy"])
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    plans = O.sia_draw(x.shape, 3, 20)
+    assert sorted({b[0] for p in plans for b in p["blocks"]}) == list(range(7))      # every operation occurs
+    xin = x.clone().requires_grad_(True)
+    y = O.sia_apply(xin, plans)
+    assert same(y.detach().numpy(), g["y"])
+    assert same(torch.autograd.grad(y, xin, gy)[0].numpy(), g["gx"])

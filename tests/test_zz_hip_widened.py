@@ -78,3 +78,102 @@ def test_fgsra(golden):
     rate = mismatch(x, delta, g["delta_fgsra"])
     print("fgsra: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
     assert rate <= BOUND
+
+
+# ------------------------------------------------------------------------------------------------- SIA
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV).contiguous()
+
+
+def test_sia_kernels_golden(golden):
+    """ta_sia_fwd / ta_sia_bwd against the reference's own 20-copy stack and the gradient autograd returns through it
+    (tests/golden/sia.npz): data movement, one multiply, one add + clip -> bit-exact."""
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import SIA_NOISE, sia_draw
+    g = golden("sia")
+    x = t(g["x"])
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    plan, noise = sia_draw(tuple(x.shape), 3, 20, lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi))
+    plan_d, noise_d, x_d = _dev(plan), _dev(noise.numpy()), _dev(g["x"])
+    y = torch.empty(g["y"].shape, device=DEV)
+    _hip.sia_fwd(x_d, plan_d, y, 20, 3, SIA_NOISE, noise=noise_d)
+    assert np.array_equal(y.cpu().numpy(), g["y"])
+    gx = torch.empty_like(x_d)
+    _hip.sia_bwd(_dev(g["gy"]), plan_d, x_d, gx, 20, 3, SIA_NOISE, noise=noise_d)
+    assert np.array_equal(gx.cpu().numpy(), g["gx"])
+
+
+@pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 5), ((1, 3, 37, 41), 3, 4), ((3, 1, 16, 100), 2, 3),
+                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2)])
+def test_sia_kernels_random(shape, nb, copies):
+    """ragged shapes, other block counts, widths beyond one 64-lane pass -- against the oracle's restatement -- and the
+    in-kernel Philox noise: the values of the oracle's stream, the same in forward and backward."""
+    import c_oracle as C
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import SIA_NOISE, sia_draw
+    gen = torch.Generator().manual_seed(sum(shape) + nb)
+    x = torch.rand(shape, generator=gen)
+    np.random.seed(sum(shape))
+    torch.manual_seed(nb)
+    state = (np.random.get_state(), torch.get_rng_state())
+    plan, noise = sia_draw(shape, nb, copies, lambda s, lo, hi: torch.zeros(s).uniform_(lo, hi))
+    np.random.set_state(state[0])
+    torch.set_rng_state(state[1])
+    plans = O.sia_draw(shape, nb, copies)                      # same generators, same order -> the same choices
+    xin = x.clone().requires_grad_(True)
+    y_ref = O.sia_apply(xin, plans)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    gx_ref = torch.autograd.grad(y_ref, xin, gy)[0]
+    plan_d, noise_d, x_d = _dev(plan), noise.to(DEV), x.to(DEV)
+    y = torch.empty(y_ref.shape, device=DEV)
+    _hip.sia_fwd(x_d, plan_d, y, copies, nb, SIA_NOISE, noise=noise_d)
+    assert np.array_equal(y.cpu().numpy(), y_ref.detach().numpy())
+    gx = torch.empty_like(x_d)
+    _hip.sia_bwd(gy.to(DEV), plan_d, x_d, gx, copies, nb, SIA_NOISE, noise=noise_d)
+    assert np.array_equal(gx.cpu().numpy(), gx_ref.numpy())
+    # in-kernel noise: element o of the output stack gets value o of the Philox (seed, offset) stream
+    y2 = torch.empty_like(y)
+    _hip.sia_fwd(x_d, plan_d, y2, copies, nb, SIA_NOISE, seed=11, offset=3)
+    stream = torch.from_numpy(C.philox_uniform(y2.numel(), 11, 3, SIA_NOISE)).view(y2.shape)
+    y2_ref = O.sia_apply(x, _with_noise(plans, stream, shape[0]))
+    assert np.array_equal(y2.cpu().numpy(), y2_ref.numpy())
+    gx2 = torch.empty_like(x_d)
+    _hip.sia_bwd(gy.to(DEV), plan_d, x_d, gx2, copies, nb, SIA_NOISE, seed=11, offset=3)
+    xin2 = x.clone().requires_grad_(True)
+    gx2_ref = torch.autograd.grad(O.sia_apply(xin2, _with_noise(plans, stream, shape[0])), xin2, gy)[0]
+    assert np.array_equal(gx2.cpu().numpy(), gx2_ref.numpy())
+
+
+def _with_noise(plans, stream, n):
+    """the oracle's plans with the noise blocks cut out of a full-size noise stack"""
+    out = []
+    for k, plan in enumerate(plans):
+        rows, cols = plan["rows"], plan["cols"]
+        nb = len(rows) - 1
+        blocks = []
+        for idx, (op, step, scale, nz) in enumerate(plan["blocks"]):
+            i, j = divmod(idx, nb)
+            if op == 6:
+                nz = stream[k * n:(k + 1) * n, :, rows[i]:rows[i + 1], cols[j]:cols[j + 1]]
+            blocks.append((op, step, scale, nz))
+        out.append(dict(rows=rows, cols=cols, blocks=blocks))
+    return out
+
+
+def test_sia_attack(golden):
+    """the whole SIA loop on the device against the reference's golden loop (4 copies, toy surrogate)"""
+    g, base = golden("sia"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    cls = ta.load_attack_class("sia")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("DevSIA", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})(
+        model_name="injected", num_scale=4)
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    np.random.seed(99)
+    torch.manual_seed(1234)
+    delta = atk(x, label).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    rate = mismatch(x, delta, g["delta_sia"])
+    print("sia: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
+    assert rate <= BOUND

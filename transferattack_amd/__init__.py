@@ -33,6 +33,7 @@ attack_zoo = {
     'tim': ('.input_transformation.tim', 'TIM'),
     'sim': ('.input_transformation.sim', 'SIM'),
     'admix': ('.input_transformation.admix', 'Admix'),
+    'sia': ('.input_transformation.sia', 'SIA'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
     # ensemble
     'ens': ('.ensemble.ens', 'ENS'),

@@ -47,6 +47,8 @@ SIGNATURES = {
     "ta_sum_copies_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_admix_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _f32, _vp]),
     "ta_admix_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "ta_sia_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
+    "ta_sia_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
     "ta_vmi_neighbor": (_int, [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_grad_accumulate": (_int, [_vp, _vp, _int, _i64, _vp]),
     "ta_variance_finalize": (_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
@@ -54,7 +56,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipExtensionError(RuntimeError):
@@ -314,6 +316,20 @@ def admix_bwd(gy, gx, num_admix, num_scale):
     n, e = _batch(gx)
     _check(load().ta_admix_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, num_admix, num_scale, _stream()),
            "ta_admix_bwd")
+
+
+def sia_fwd(x, plan, y, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
+    h, w = x.shape[-2:]
+    _check(load().ta_sia_fwd(_ptr(x, name="x"), _ptr(plan, torch.int32, "plan"), _ptr(noise, name="noise"), _ptr(y, name="y"),
+                             x.numel() // (h * w), h, w, copies, num_block, float(noise_radius), seed, offset, _stream()),
+           "ta_sia_fwd")
+
+
+def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
+    h, w = x.shape[-2:]
+    _check(load().ta_sia_bwd(_ptr(gy, name="gy"), _ptr(plan, torch.int32, "plan"), _ptr(x, name="x"), _ptr(noise, name="noise"),
+                             _ptr(gx, name="gx"), x.numel() // (h * w), h, w, copies, num_block, float(noise_radius), seed,
+                             offset, _stream()), "ta_sia_bwd")
 
 
 # ---------------------------------------------------------------------------------------------- VMI / NI

@@ -5,39 +5,9 @@
 //   random-start init                                     (attack.py:130-143)
 //   output quantiser  NCHW fp32 -> NHWC uint8             (utils.py:63-66)
 // All use 16-byte lane accesses, three in flight per operand, one 3072-element tile per workgroup.
-#include "ta_common.h"
+#include "philox.h"
 
 namespace ta {
-
-// ---- Philox4x32-10 (Salmon et al. 2011), counter = (lo32(i), hi32(i), lo32(offset), hi32(offset)) ---
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += W0;
-        k.y += W1;
-    }
-    return c;
-}
-
-// four U[-r, r) draws for the float4 group `quad` (element index / 4)
-__device__ __forceinline__ float4 uniform4(uint64_t quad, uint64_t seed, uint64_t offset, float r) {
-    const uint4 bits = philox4x32_10(
-        make_uint4(static_cast<uint32_t>(quad), static_cast<uint32_t>(quad >> 32),
-                   static_cast<uint32_t>(offset), static_cast<uint32_t>(offset >> 32)),
-        make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)));
-    constexpr float k24 = 1.0f / 16777216.0f;
-    const float two_r = 2.0f * r;
-    float4 o;
-    o.x = static_cast<float>(bits.x >> 8) * k24 * two_r - r;
-    o.y = static_cast<float>(bits.y >> 8) * k24 * two_r - r;
-    o.z = static_cast<float>(bits.z >> 8) * k24 * two_r - r;
-    o.w = static_cast<float>(bits.w >> 8) * k24 * two_r - r;
-    return o;
-}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -10,6 +10,9 @@ backward are single HIP kernels (the reference builds them from 3-20 ATen ops in
 The random draws stay on the host, on torch's CPU default generator, in the reference's order, so a seeded
 run makes the same choices as the reference on any device.
 """
+import struct
+
+import numpy as np
 import torch
 
 from . import _hip
@@ -110,3 +113,67 @@ class Neighbor(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ SIA
+SIA_OPS = 7                 # roll rows, roll columns, flip rows, flip columns, rotate 180, scale, noise + clip
+SIA_NOISE = 16 / 255        # sia.py:67: a constant of the method, not the attack's epsilon
+
+
+def sia_draw(shape, num_block, num_copies, noise_source=None):
+    """The random choices of ``num_copies`` block transforms of a batch of ``shape`` (sia.py:86-100), drawn in the
+    reference's order from the reference's host generators: numpy -- column cuts, row cuts, then per rectangle (rows
+    outer) the operation and, for the two rolls, the step; torch (CPU) -- the scale factor.  Returns the int32 plan
+    table ``ta_sia_fwd`` reads ([copies, 2*(nb+1) + 3*nb*nb]) and, if ``noise_source`` is given (tests: the
+    reference's CPU draws, in the reference's order), the noise as a tensor shaped like the output stack; otherwise
+    None and the kernel draws from its Philox stream."""
+    n, c, height, width = shape
+    stride = 2 * (num_block + 1) + 3 * num_block * num_block
+    plan = np.zeros((num_copies, stride), dtype=np.int32)
+    noise = torch.zeros((num_copies * n, c, height, width)) if noise_source is not None else None
+    for k in range(num_copies):
+        cols = [0] + np.random.choice(list(range(1, width)), num_block - 1, replace=False).tolist() + [width]
+        rows = [0] + np.random.choice(list(range(1, height)), num_block - 1, replace=False).tolist() + [height]
+        cols.sort()
+        rows.sort()
+        plan[k, :num_block + 1] = rows
+        plan[k, num_block + 1:2 * (num_block + 1)] = cols
+        cell = 2 * (num_block + 1)
+        for i in range(num_block):
+            for j in range(num_block):
+                bh, bw = rows[i + 1] - rows[i], cols[j + 1] - cols[j]
+                op = int(np.random.randint(0, high=SIA_OPS, dtype=np.int32))
+                step, scale_bits = 0, 0
+                if op == 0:
+                    step = int(np.random.randint(low=0, high=bh, dtype=np.int32))
+                elif op == 1:
+                    step = int(np.random.randint(low=0, high=bw, dtype=np.int32))
+                elif op == 5:
+                    scale_bits = struct.unpack("<i", struct.pack("<f", float(torch.rand(1)[0])))[0]
+                elif op == 6 and noise is not None:
+                    noise[k * n:(k + 1) * n, :, rows[i]:rows[i + 1], cols[j]:cols[j + 1]] = noise_source(
+                        (n, c, bh, bw), -SIA_NOISE, SIA_NOISE)
+                plan[k, cell:cell + 3] = (op, step, scale_bits)
+                cell += 3
+    return plan, noise
+
+
+class SiaBlocks(torch.autograd.Function):
+    """cat of ``copies`` block-transformed clones of x: one gather kernel each way (``ta_sia_fwd/bwd``)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, copies, num_block, seed, offset, noise):
+        x = x.contiguous()
+        y = torch.empty((copies * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _hip.sia_fwd(x, plan, y, copies, num_block, SIA_NOISE, seed, offset, noise)
+        ctx.save_for_backward(x, plan, noise)
+        ctx.cfg = (copies, num_block, seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, plan, noise = ctx.saved_tensors
+        copies, num_block, seed, offset = ctx.cfg
+        gx = torch.empty_like(x)
+        _hip.sia_bwd(gy.contiguous(), plan, x, gx, copies, num_block, SIA_NOISE, seed, offset, noise)
+        return gx, None, None, None, None, None, None
