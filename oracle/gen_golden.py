@@ -278,6 +278,11 @@ def gen_sia():
     np.random.seed(99)
     torch.manual_seed(1234)
     out["delta_sia"] = atk(xl, label)
+    # SSM (ssm.py:40-99): the Gaussian is hard-coded 3 x 224 x 224, so the loop runs on 224-pixel inputs
+    x224 = u8_images(1, 224, 23).float() / 255
+    atk = ref_shim.make_reference_attack("ssm", backbones.create("toy_cnn", seed=3, verbose=False), num_spectrum=3, epoch=3)
+    torch.manual_seed(4321)
+    out["delta_ssm"] = atk(x224, label[:1])
     save("sia", **out)
 
 

@@ -307,3 +307,17 @@ def test_sia_matches_reference(golden, monkeypatch):
     np.random.seed(99)
     torch.manual_seed(1234)
     assert np.array_equal(make("sia", num_scale=4)(xl, label).numpy(), g["delta_sia"])
+
+
+def test_ssm_matches_reference(golden, monkeypatch):
+    """SSM (ssm.py:40-99): spectrum-perturbed views through the shared DCT pair, gradient taken at the view, averaged
+    over the views -- the reference's loop on a 224-pixel input (its Gaussian is hard-coded to that size)."""
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g, base = golden("sia"), golden("loops_toy")
+    x224 = u8_images(1, 224, 23).float() / 255
+    atk = make("ssm", num_spectrum=3, epoch=3)
+    atk.noise_source = lambda shape, lo, hi: torch.randn(shape) if lo is None else torch.rand(shape)
+    torch.manual_seed(4321)
+    assert np.array_equal(atk(x224, t(base["label"])[:1]).numpy(), g["delta_ssm"])
+    assert "grad_accumulate" in fake_hip.calls

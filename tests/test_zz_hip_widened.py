@@ -177,3 +177,21 @@ def test_sia_attack(golden):
     rate = mismatch(x, delta, g["delta_sia"])
     print("sia: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
     assert rate <= BOUND
+
+
+def test_ssm_attack(golden):
+    """SSM on the device (rocFFT DCT pair, HIP accumulation / update) against the reference's golden loop"""
+    from conftest import u8_images
+    g, base = golden("sia"), golden("loops_toy")
+    x224 = u8_images(1, 224, 23).float() / 255
+    cls = ta.load_attack_class("ssm")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("DevSSM", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})(
+        model_name="injected", num_spectrum=3, epoch=3)
+    atk.noise_source = lambda shape, lo, hi: torch.randn(shape) if lo is None else torch.rand(shape)
+    torch.manual_seed(4321)
+    delta = atk(x224, t(base["label"])[:1]).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    rate = mismatch(x224, delta, g["delta_ssm"])
+    print("ssm: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
+    assert rate <= BOUND

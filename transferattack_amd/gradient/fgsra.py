@@ -6,26 +6,10 @@ gradient's -- so ``update_delta`` receives a TENSOR step.
 Mirror of transferattack/gradient/fgsra.py:36-46 (constructor), :49-123 (DCT-II / inverse by Makhoul's FFT
 factorisation, unnormalised), :163-215 (loop).  HIP: momentum, ``ta_update_delta_linf`` with the per-element step;
 the FFTs are rocFFT through torch.fft, differentiable, as in the reference."""
-import math
-
 import torch
 
 from ..attack import Attack
-
-
-class _Twiddles:
-    """cos/sin of k*pi/(2N) for the last-axis length N (fgsra.py:62-64, 90-92), kept per (N, device)"""
-
-    def __init__(self):
-        self._cache = {}
-
-    def __call__(self, n, like, sign):
-        key = (n, like.device, like.dtype, sign)
-        if key not in self._cache:
-            ramp = torch.arange(n, dtype=like.dtype, device=like.device)[None, :]
-            angle = (-ramp if sign < 0 else ramp) * math.pi / (2 * n)
-            self._cache[key] = (torch.cos(angle), torch.sin(angle))
-        return self._cache[key]
+from ..spectrum import MakhoulDct
 
 
 class FGSRA(Attack):
@@ -38,39 +22,20 @@ class FGSRA(Attack):
         self._schedule(alpha, epoch, decay)
         self.rho, self.beta, self.max_iter = rho, beta, max_iter
         self.targeted = False                       # fgsra.py:46: the reference runs this attack untargeted only
-        self._twiddles = _Twiddles()
+        self._dct = MakhoulDct()
 
-    # ------------------------------------------------------------------ DCT-II along the last axis and its inverse
+    # DCT-II / inverse over the last axis and the last two axes (fgsra.py:49-123): shared with SSM
     def dct(self, x, norm=None):
-        if norm is not None:
-            raise Exception("Unsupported DCT normalisation {}".format(norm))
-        shape, n = x.shape, x.shape[-1]
-        rows = x.contiguous().view(-1, n)
-        folded = torch.cat([rows[:, ::2], rows[:, 1::2].flip([1])], dim=1)       # even samples, then odd reversed
-        spectrum = torch.fft.fft(folded)
-        cos_k, sin_k = self._twiddles(n, rows, -1)
-        out = spectrum.real * cos_k - spectrum.imag * sin_k
-        return 2 * out.view(*shape)
+        return self._dct.dct(x, norm)
 
     def idct(self, X, norm=None):
-        if norm is not None:
-            raise Exception("Unsupported DCT normalisation {}".format(norm))
-        shape, n = X.shape, X.shape[-1]
-        re = X.contiguous().view(-1, n) / 2
-        im = torch.cat([re[:, :1] * 0, -re.flip([1])[:, :-1]], dim=1)
-        cos_k, sin_k = self._twiddles(n, re, +1)
-        rotated = torch.complex(re * cos_k - im * sin_k, re * sin_k + im * cos_k)
-        folded = torch.fft.ifft(rotated)
-        rows = folded.new_zeros(folded.shape)
-        rows[:, ::2] += folded[:, :n - (n // 2)]
-        rows[:, 1::2] += folded.flip([1])[:, :n // 2]
-        return rows.view(*shape).real
+        return self._dct.idct(X, norm)
 
     def dct_2d(self, x, norm=None):
-        return self.dct(self.dct(x, norm=norm).transpose(-1, -2), norm=norm).transpose(-1, -2)
+        return self._dct.dct_2d(x, norm)
 
     def idct_2d(self, x, norm=None):
-        return self.idct(self.idct(x, norm=norm).transpose(-1, -2), norm=norm).transpose(-1, -2)
+        return self._dct.idct_2d(x, norm)
 
     # ----------------------------------------------------------------------------------------------------- loop
     def _unit_uniform(self, x):

@@ -1,0 +1,50 @@
+"""SSM / SSA (Long et al., ECCV 2022) -- spectrum simulation: each iteration averages the gradients of
+``num_spectrum`` spectrum-perturbed views idct2(dct2(x + N(0, eps^2)) * U(1 - rho, 1 + rho)), taken with respect to
+the VIEW itself (not back through the transform), then runs the MI-FGSM update.
+Mirror of transferattack/input_transformation/ssm.py:34-99.  HIP: gradient accumulation, momentum + projected step;
+the DCT pair is torch.fft = rocFFT (``spectrum.MakhoulDct``).  The reference hard-codes a 3 x 224 x 224 Gaussian
+(ssm.py:48); so does the shape check here."""
+import torch
+
+from .. import _hip
+from ..gradient.mifgsm import MIFGSM
+from ..spectrum import MakhoulDct
+
+
+class SSM(MIFGSM):
+    """Official arguments: epsilon=16/255, alpha=1.6/255, epoch=10, decay=1., num_spectrum=20, rho=0.5."""
+
+    def __init__(self, model_name, epsilon=16/255, alpha=1.6/255, epoch=10, decay=1., num_spectrum=20, rho=0.5,
+                 targeted=False, random_start=False, norm='linfty', loss='crossentropy', device=None, **kwargs):
+        super().__init__(model_name, epsilon, alpha, epoch, decay, targeted, random_start, norm, loss, device)
+        self.num_spectrum, self.rho = num_spectrum, rho
+        self._dct = MakhoulDct()
+
+    def _draw(self, shape, normal):
+        """host draws of the reference (ssm.py:48, 51): N(0, 1) from the CPU generator, U[0, 1) shaped like x"""
+        if self.noise_source is not None:
+            return self.noise_source(shape, None, None) if normal else self.noise_source(shape, 0.0, 1.0)
+        return torch.randn(shape) if normal else torch.rand(shape, device=self.device)
+
+    def transform(self, x, **kwargs):
+        gauss = (self._draw((x.size()[0], 3, 224, 224), True) * self.epsilon).to(self.device)
+        spectrum = self._dct.dct_2d(x + gauss)
+        mask = (self._draw(tuple(x.shape), False) * 2 * self.rho + 1 - self.rho).to(self.device)
+        return self._dct.idct_2d(spectrum * mask)
+
+    def forward(self, data, label, **kwargs):
+        data, label = self._to_device(data, label)
+        delta = self.init_delta(data)
+        momentum = 0
+        for _ in range(self.epoch):
+            grads = None
+            for s in range(self.num_spectrum):
+                view = self.transform(data + delta)
+                grad = self.get_grad(self.get_loss(self.get_logits(view), label), view).contiguous()
+                if grads is None:
+                    grads = torch.empty_like(grad)
+                _hip.grad_accumulate(grads, grad, first=(s == 0))
+            grads = grads / self.num_spectrum
+            momentum = self.get_momentum(grads, momentum)
+            delta = self.update_delta(delta, data, momentum, self.alpha)
+        return delta.detach()
