@@ -74,3 +74,17 @@ def test_fgsra_through_kernels(golden, monkeypatch):
     monkeypatch.setattr(W, "DEV", "cpu")
     monkeypatch.setattr(W, "BOUND", 0.0)
     W.test_fgsra(golden)
+
+
+def test_sia_through_kernels(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0)
+    W.test_sia_attack(golden)
+
+
+def test_ssm_through_kernels(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0)
+    W.test_ssm_attack(golden)
