@@ -88,3 +88,8 @@ def test_ssm_through_kernels(golden, monkeypatch):
     monkeypatch.setattr(W, "DEV", "cpu")
     monkeypatch.setattr(W, "BOUND", 0.0)
     W.test_ssm_attack(golden)
+
+
+def test_main_cli_roundtrip(tmp_path, monkeypatch):
+    """main.py end to end (decode -> attack -> quantise -> PNG -> --eval) with the kernels' own code on the host"""
+    A.test_main_cli_roundtrip(tmp_path, monkeypatch)
