@@ -14,6 +14,16 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def same_thread_count_as_the_ranks():
+    """the single-process side of every comparison runs with the ranks' thread count: ATen's CPU bilinear resize (the
+    32 -> 224 resize in front of the toy surrogate) can round differently for different work partitions"""
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    yield
+    torch.set_num_threads(threads)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -27,6 +37,9 @@ class _Patch:
 
     def setattr(self, obj, name, value):
         setattr(obj, name, value)
+
+    def setenv(self, name, value):
+        os.environ[name] = value
 
 
 def _setup(rank, world, port):
@@ -132,6 +145,47 @@ def _cpu_noise(name):
     return lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
 
 
+_CLI_CASES = (("dim", "toy_cnn"), ("ens", "toy_cnn,toy_cnn"), ("cwa", "toy_cnn,toy_cnn"))
+
+
+def _write_dataset(root, count):
+    import csv
+    from PIL import Image
+    from conftest import u8_images
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    pixels = u8_images(count, 32, 11).permute(0, 2, 3, 1).numpy()
+    with open(os.path.join(root, "labels.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["filename", "label", "targeted_label"])
+        for i in range(count):
+            Image.fromarray(pixels[i]).save(os.path.join(root, "images", "%d.png" % i))
+            w.writerow(["%d.png" % i, i % 10, (i + 1) % 10])
+
+
+def _cli(inp, out, attack, model):
+    import main as cli
+    sys.argv = ["main.py", "--input_dir", inp, "--output_dir", out, "--attack", attack, "--model", model,
+                "--batchsize", "2", "--seed", "5"]
+    cli.main()
+
+
+def _rank_cli(rank, world, port, out):
+    """main.py under torch.distributed (gloo), the kernels' own code on the host (tests/host_kernels.py) in every rank"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import host_kernels
+    host_kernels.install(_Patch())
+    base = os.path.dirname(out)
+    for attack, model in _CLI_CASES:
+        _cli(os.path.join(base, "data"), os.path.join(base, "adv2_" + attack), attack, model)
+        dist.barrier()
+    dist.destroy_process_group()
+
+
 def _run(fn, tmp_path):
     out = str(tmp_path / "out.npz")
     mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
@@ -192,3 +246,24 @@ def test_sharded_members_match_single_process(tmp_path, monkeypatch):
         ref = atk(x, y).numpy()
         assert np.array_equal(got[name + "_r0"], got[name + "_r1"]), name
         assert np.array_equal(got[name + "_r0"], ref), name
+
+
+def test_main_cli_sharded_equals_single_process(tmp_path, monkeypatch):
+    """main.py on 2 ranks writes the same PNG bytes as on 1: image sharding by whole batches with per-batch seeding
+    (dim), one surrogate per rank with the two all-reduces (ens), per-member broadcast (cwa).  Runs the kernel
+    sources on the host stand-in in every rank, gloo instead of RCCL."""
+    from PIL import Image
+    _write_dataset(str(tmp_path / "data"), 5)                      # 5 images, batches of 2 -> 3 batches over 2 ranks
+    # (ens / cwa: the 2 ranks form ONE model group, so there the batches are not sharded but the surrogates are)
+    mp.spawn(_rank_cli, args=(2, _free_port(), str(tmp_path / "out.npz")), nprocs=2, join=True)
+    import host_kernels
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    for attack, model in _CLI_CASES:
+        _cli(str(tmp_path / "data"), str(tmp_path / ("adv1_" + attack)), attack, model)
+        for i in range(5):
+            one = np.array(Image.open(tmp_path / ("adv1_" + attack) / ("%d.png" % i)))
+            two = np.array(Image.open(tmp_path / ("adv2_" + attack) / ("%d.png" % i)))
+            assert np.array_equal(one, two), (attack, i)
+        assert not np.array_equal(one, np.array(Image.open(tmp_path / "data" / "images" / "4.png")))   # it did attack
