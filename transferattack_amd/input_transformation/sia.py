@@ -5,6 +5,8 @@ Mirror of transferattack/input_transformation/sia.py:35-106.  The draws stay on 
 (``transforms.sia_draw``); the whole stack and its backward are one HIP gather kernel each (``ta_sia_fwd/bwd``) instead
 of ~10 ATen launches per rectangle.  (The reference also builds a 3x3 blur kernel, sia.py:69-80, that none of its
 seven operations uses; it is not reproduced.)"""
+import torch
+
 from ..gradient.mifgsm import MIFGSM
 from ..transforms import SiaBlocks, sia_draw
 
@@ -20,7 +22,6 @@ class SIA(MIFGSM):
 
     def transform(self, x, **kwargs):
         plan, noise = sia_draw(tuple(x.shape), self.num_block, self.num_scale, self.noise_source)
-        import torch
         plan = torch.from_numpy(plan).to(x.device)
         if noise is not None:
             noise = noise.to(x.device).contiguous()
