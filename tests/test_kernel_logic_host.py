@@ -179,3 +179,19 @@ def test_sia_kernels_golden(golden, widened_on_host):
                                              ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2)])
 def test_sia_kernels_random(widened_on_host, shape, nb, copies):
     W.test_sia_kernels_random(shape, nb, copies)
+
+
+def test_xcd_major_tile_order(monkeypatch, golden):
+    """TA_XCD_MAJOR_TILES=1 only changes WHICH workgroup computes which tile (a bijection on the tile ids): every
+    TIM / DIM kernel, shipped and variant, must give the same bytes"""
+    host_kernels.install(monkeypatch, tag="xcd", env={"TA_XCD_MAJOR_TILES": "1", "TA_DIM_FWD_VARIANT": "2",
+                                                       "TA_DIM_BWD_VARIANT": "1", "TA_TIM_VARIANT": "3"})
+    G.test_tim_golden(golden)
+    G.test_tim_random((4, 3, 224, 224), 15)
+    G.test_tim_random((2, 3, 50, 70), 9)                       # generic kernel
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
+    G.test_dim_random(33, 2.0, [(40, 5, 20)])                  # falls back to the table-driven kernels
+    host_kernels.install(monkeypatch, tag="xcd0", env={"TA_XCD_MAJOR_TILES": "1"})
+    G.test_tim_random((4, 3, 224, 224), 15)
+    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])

@@ -28,7 +28,8 @@ timvariants)
 dimvariants)
   # first thing to run next round: parity of the lane-per-column DIM kernels on the device, then their timing
   TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 300 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -k "dim or dts" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/dim_variants_pytest.txt
-  for v in "0 0" "2 0" "0 1" "2 1"; do set -- $v; TA_DIM_FWD_VARIANT=$1 TA_DIM_BWD_VARIANT=$2 timeout 120 python tools/dim_time.py; done 2>&1 | tee $OUT/dim_variants.txt ;;
+  for v in "0 0" "2 0" "0 1" "2 1"; do set -- $v; TA_DIM_FWD_VARIANT=$1 TA_DIM_BWD_VARIANT=$2 timeout 120 python tools/dim_time.py; done 2>&1 | tee $OUT/dim_variants.txt
+  TA_XCD_MAJOR_TILES=1 TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 120 python tools/dim_time.py 2>&1 | sed "s/^/xcd-major /" | tee -a $OUT/dim_variants.txt ;;
 widened)
   timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider 2>&1 | tail -12 | tee $OUT/widened_pytest.txt ;;
 k2sweep)

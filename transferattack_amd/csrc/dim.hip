@@ -47,7 +47,7 @@ constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of th
 // is evaluated once per tile instead of up to 4 times, and no intermediate ever reaches HBM.
 __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          int size, int resize, int rnd, int top, int left,
-                                                         int tiles_per_side) {
+                                                         int tiles_per_side, int xcd_major) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
     Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
@@ -57,8 +57,9 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
     __syncthreads();
 
     const int tiles = tiles_per_side * tiles_per_side;
-    const int64_t plane = blockIdx.x / tiles;
-    const int t = blockIdx.x % tiles;
+    const unsigned tid = tile_id(xcd_major);
+    const int64_t plane = tid / tiles;
+    const int t = tid % tiles;
     const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
     const int oy1 = min(oy0 + kDimFwdTile, size) - 1, ox1 = min(ox0 + kDimFwdTile, size) - 1;
     const float* xp = x + plane * static_cast<int64_t>(size) * size;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
 //   V2  y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
 __global__ __launch_bounds__(kBlock) void dim_fwd_sep_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int size, int resize, int rnd, int top, int left,
-                                                             int tiles_per_side, int ws) {
+                                                             int tiles_per_side, int ws, int xcd_major) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
     Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
@@ -118,8 +119,9 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_sep_kernel(const float* __rest
     __syncthreads();
 
     const int tiles = tiles_per_side * tiles_per_side;
-    const int64_t plane = blockIdx.x / tiles;
-    const int t = blockIdx.x % tiles;
+    const unsigned tid = tile_id(xcd_major);
+    const int64_t plane = tid / tiles;
+    const int t = tid % tiles;
     const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
     const int oy1 = min(oy0 + kDimFwdTile, size) - 1, ox1 = min(ox0 + kDimFwdTile, size) - 1;
     const float* xp = x + plane * static_cast<int64_t>(size) * size;
@@ -196,7 +198,7 @@ template <int RPW>                      // rows per wave of the LDS rectangles: 
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y) {
+                                                               int tiles_y, int xcd_major) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
     __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
@@ -207,8 +209,9 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
     const int tiles = tiles_x * tiles_y;
-    const int plane = blockIdx.x / tiles;                              // grid < 2^31 (host-checked)
-    const int t = blockIdx.x - plane * tiles;
+    const int tid = static_cast<int>(tile_id(xcd_major));
+    const int plane = tid / tiles;                                     // grid < 2^31 (host-checked)
+    const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
     const int oy0 = tyi * kDimLaneRows, ox0 = (t - tyi * tiles_x) * tw;
     const int th = min(kDimLaneRows, size - oy0), twc = min(tw, size - ox0);    // rows / columns of this tile
@@ -316,7 +319,7 @@ struct Range {
 
 __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                          int size, int resize, int rnd, int top, int left,
-                                                         int tiles_per_side) {
+                                                         int tiles_per_side, int xcd_major) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);                  // [size]    out pixel  -> padded index
     Tap* t1 = t2 + size;                                         // [rnd]     rescaled   -> x index
@@ -346,8 +349,9 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
     __syncthreads();
 
     const int tiles = tiles_per_side * tiles_per_side;
-    const int64_t plane = blockIdx.x / tiles;
-    const int t = blockIdx.x % tiles;
+    const unsigned tid = tile_id(xcd_major);
+    const int64_t plane = tid / tiles;
+    const int t = tid % tiles;
     const int iy0 = (t / tiles_per_side) * kDimBwdTile, ix0 = (t % tiles_per_side) * kDimBwdTile;
     const int iy1 = min(iy0 + kDimBwdTile, size) - 1, ix1 = min(ix0 + kDimBwdTile, size) - 1;
     const float* gyp = gy + plane * static_cast<int64_t>(size) * size;
@@ -502,7 +506,7 @@ template <int RPW>
 __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y) {
+                                                               int tiles_y, int xcd_major) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
     __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
@@ -513,8 +517,9 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = tiles_x * tiles_y;
-    const int plane = blockIdx.x / tiles;
-    const int t = blockIdx.x - plane * tiles;
+    const int tid = static_cast<int>(tile_id(xcd_major));
+    const int plane = tid / tiles;
+    const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
     const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
     const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
@@ -674,10 +679,10 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
             else
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -685,12 +690,12 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
         const int ws = mid_side + 1;                     // the x rectangle can be one row taller than the window
         const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * (2 * ws * ws + ws * 32);
         hipLaunchKernelGGL(dim_fwd_sep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                           static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, ws);
+                           static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, ws, xcd_major_tiles());
         return check_launch("dim_fwd_sep");
     }
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * mid_side * mid_side;
     hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                       static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps);
+                       static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, xcd_major_tiles());
     return check_launch("dim_fwd");
 }
 
@@ -720,10 +725,10 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, 
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_bwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
             else
                 hipLaunchKernelGGL(dim_bwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);
+                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
             return check_launch("dim_bwd_lanes");
         }
     }
@@ -734,6 +739,6 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, 
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(Range) * (static_cast<size_t>(resize) + size) +
                         sizeof(float) * mid_side * mid_side;
     hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                       static_cast<hipStream_t>(stream), gy, gx, size, resize, rnd, top, left, tps);
+                       static_cast<hipStream_t>(stream), gy, gx, size, resize, rnd, top, left, tps, xcd_major_tiles());
     return check_launch("dim_bwd");
 }

@@ -1,5 +1,6 @@
 // Error reporting and ABI bookkeeping for libta_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "ta_common.h"
 
 namespace ta {
@@ -20,6 +21,14 @@ int check_launch(const char* what) {
         return static_cast<int>(err);
     }
     return 0;
+}
+
+int xcd_major_tiles() {
+    static const int on = []() {
+        const char* e = getenv("TA_XCD_MAJOR_TILES");
+        return e != nullptr && atoi(e) != 0 ? 1 : 0;
+    }();
+    return on;
 }
 
 }  // namespace ta

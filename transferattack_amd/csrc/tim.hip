@@ -36,7 +36,7 @@ template <int K, int TH, bool FAST_LOAD, bool PIPELINED, bool PAIRS = false>
 __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* __restrict__ in,
                                                              float* __restrict__ out,
                                                              const float* __restrict__ w, int h, int wd,
-                                                             int tiles_x, int tiles_y) {
+                                                             int tiles_x, int tiles_y, int xcd_major) {
     constexpr int LO = (K - 1) / 2;
     constexpr int LW = kConvTW + K - 1;
     constexpr int LH = TH + K - 1;
@@ -45,8 +45,9 @@ __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float tile[LH * LS];
 
     const int tiles = tiles_x * tiles_y;
-    const int64_t plane = blockIdx.x / tiles;
-    const int t = blockIdx.x % tiles;
+    const unsigned tid = tile_id(xcd_major);
+    const int64_t plane = tid / tiles;
+    const int t = tid % tiles;
     const int y0 = (t / tiles_x) * TH;
     const int x0 = (t % tiles_x) * kConvTW;
     const float* ip = in + plane * static_cast<int64_t>(h) * wd;
@@ -217,15 +218,17 @@ __global__ __launch_bounds__(TH * kConvXG) void dwconv_same_kernel(const float* 
 __global__ __launch_bounds__(kBlock) void dwconv_same_generic_kernel(const float* __restrict__ in,
                                                                      float* __restrict__ out,
                                                                      const float* __restrict__ w, int k, int h,
-                                                                     int wd, int tiles_x, int tiles_y, int ls) {
+                                                                     int wd, int tiles_x, int tiles_y, int ls,
+                                                                     int xcd_major) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lo = (k - 1) / 2;
     const int lw = kConvTW + k - 1, lh = kConvTH + k - 1;
     float* tile = smem;
     float* wl = smem + lh * ls;
     const int tiles = tiles_x * tiles_y;
-    const int64_t plane = blockIdx.x / tiles;
-    const int t = blockIdx.x % tiles;
+    const unsigned tid = tile_id(xcd_major);
+    const int64_t plane = tid / tiles;
+    const int t = tid % tiles;
     const int y0 = (t / tiles_x) * kConvTH;
     const int x0 = (t % tiles_x) * kConvTW;
     const float* ip = in + plane * static_cast<int64_t>(h) * wd;
@@ -287,7 +290,7 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
 #define TA_CONV_LAUNCH(KK, TH, FAST, PIPE, PAIRS)                                                              \
     hipLaunchKernelGGL((dwconv_same_kernel<KK, TH, FAST, PIPE, PAIRS>), dim3(static_cast<unsigned>(planes *      \
                        tiles_x * ceil_div(h, TH))), dim3(TH * kConvXG), 0, st, in, out, w, h, w_, tiles_x,      \
-                       static_cast<int>(ceil_div(h, TH)))
+                       static_cast<int>(ceil_div(h, TH)), xcd_major_tiles())
 #define TA_CONV(KK)                                                                                  \
     case KK:                                                                                         \
         if (fast && variant == 3) { TA_CONV_LAUNCH(KK, 16, true, true, true); }                      \
@@ -303,7 +306,7 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
             const int ls = conv_lds_stride(k);
             const size_t smem = sizeof(float) * (static_cast<size_t>(kConvTH + k - 1) * ls + k * k);
             hipLaunchKernelGGL(dwconv_same_generic_kernel, grid, dim3(kBlock), smem, st, in, out, w, k, h, w_, tiles_x,
-                               tiles_y, ls);
+                               tiles_y, ls, xcd_major_tiles());
         }
     }
     return check_launch("depthwise_conv2d_same");
