@@ -195,3 +195,11 @@ def test_xcd_major_tile_order(monkeypatch, golden):
     host_kernels.install(monkeypatch, tag="xcd0", env={"TA_XCD_MAJOR_TILES": "1"})
     G.test_tim_random((4, 3, 224, 224), 15)
     G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
+
+
+def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
+    """the BASELINE-size property tests of the GPU tier, with the sizes cut to what the stand-in finishes quickly"""
+    monkeypatch.setattr(W, "FULL_N", 12)
+    monkeypatch.setattr(W, "SHARD_N", 5)
+    W.test_update_full_size_properties()
+    W.test_quantiser_full_size()

@@ -195,3 +195,76 @@ def test_ssm_attack(golden):
     rate = mismatch(x224, delta, g["delta_ssm"])
     print("ssm: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
     assert rate <= BOUND
+
+
+# ------------------------------------------------------------------- BASELINE sizes: size-independent properties
+FULL_N, SHARD_N = 1000, 125          # BASELINE.json configs[1]: the 1000-image set, 125 images per GPU on an 8-GPU node
+
+
+def test_update_full_size_properties():
+    """The fused update at the full job size (1000 x 3 x 224 x 224: 602 MB per operand, streaming loads / stores) through
+    properties that need no second implementation:
+      * images are independent: the whole batch in one call == the same images in shards of 125 (also: the
+        non-temporal path used above 256 MiB per launch == the cached path used below it, shards of 32), bit for bit;
+      * invariants of the projection: |delta| <= eps and 0 <= x + delta <= 1;
+      * a zero step leaves a feasible delta untouched;
+      * g / mean|g| is invariant under a power-of-two rescaling of g, bit for bit;
+      * eight images picked across the batch equal the CPU oracle."""
+    from conftest import assert_momentum_close
+    from transferattack_amd import _hip
+    alpha = 1.6 / 255
+    gen = torch.Generator().manual_seed(123)
+    shape = (FULL_N, 3, 224, 224)
+    x = (torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8).float() / 255).to(DEV)
+    grad = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+    mom = torch.randn(shape, generator=gen).to(DEV)
+    delta = (torch.randint(-10, 11, shape, generator=gen).float() * alpha).to(DEV).clamp_(-EPS, EPS)
+    delta = torch.min(torch.max(delta, 0 - x), 1 - x)
+    d_all, m_all = delta.clone(), torch.empty_like(mom)
+    _hip.mi_update(grad, mom, m_all, d_all, x, 1.0, alpha, EPS)
+    for lo in range(0, FULL_N, SHARD_N):
+        sl = slice(lo, min(lo + SHARD_N, FULL_N))
+        d, m = delta[sl].clone(), torch.empty_like(mom[sl])
+        _hip.mi_update(grad[sl].contiguous(), mom[sl].contiguous(), m, d, x[sl].contiguous(), 1.0, alpha, EPS)
+        assert torch.equal(d, d_all[sl]) and torch.equal(m, m_all[sl]), "shard starting at image %d" % lo
+    for lo in (0, 32, FULL_N - 32):                                  # 32 images = 116 MB per launch: the cached path
+        sl = slice(max(lo, 0), max(lo, 0) + min(32, FULL_N))
+        d, m = delta[sl].clone(), torch.empty_like(mom[sl])
+        _hip.mi_update(grad[sl].contiguous(), mom[sl].contiguous(), m, d, x[sl].contiguous(), 1.0, alpha, EPS)
+        assert torch.equal(d, d_all[sl]) and torch.equal(m, m_all[sl]), "32-image shard at %d" % lo
+    assert float(d_all.abs().max()) <= EPS + 1e-7                   # eps is applied as an fp32 number
+    adv = x + d_all
+    assert float(adv.min()) >= 0.0 and float(adv.max()) <= 1.0 + 1e-7
+    d0, m0 = delta.clone(), torch.empty_like(mom)
+    _hip.mi_update(grad, mom, m0, d0, x, 1.0, 0.0, EPS)
+    assert torch.equal(d0, delta) and torch.equal(m0, m_all)
+    m4 = torch.empty_like(mom)
+    _hip.momentum(grad * 4.0, mom, m4, 1.0)
+    m1 = torch.empty_like(mom)
+    _hip.momentum(grad, mom, m1, 1.0)
+    assert torch.equal(m4, m1)
+    picks = sorted({0, 1, FULL_N // 3, FULL_N // 2, FULL_N - 2, FULL_N - 1, 124 % FULL_N, 125 % FULL_N})
+    g_c, m_c, x_c, d_c = (v[picks].cpu() for v in (grad, mom, x, delta))
+    m_ref = O.momentum_step(g_c, m_c, 1.0)
+    assert_momentum_close(m_all[picks].cpu().numpy(), m_ref.numpy(), g_c.numpy(), m_c.numpy(), 1.0)
+    d_ref = O.delta_step(d_c, x_c, m_ref, alpha, EPS)
+    bad = (d_all[picks].cpu() != d_ref)
+    assert int(bad.sum()) == 0 or float(m_ref[bad].abs().max()) < 1e-5
+
+
+def test_quantiser_full_size():
+    """the 1000-image uint8 artefact against numpy's truncation on the host, and its round trip: images that came from
+    uint8 files and get a zero perturbation come back as the same bytes the reference's save_images would write"""
+    from transferattack_amd import _hip
+    gen = torch.Generator().manual_seed(7)
+    u8 = torch.randint(0, 256, (FULL_N, 3, 224, 224), generator=gen, dtype=torch.uint8)
+    x = (u8.float() / 255).to(DEV)
+    d = ((torch.rand(x.shape, generator=gen) - 0.5) * 2 * EPS).to(DEV)
+    d = torch.min(torch.max(d, 0 - x), 1 - x)
+    out = torch.empty((FULL_N, 224, 224, 3), dtype=torch.uint8, device=DEV)
+    _hip.quantize_u8_nhwc(x, d, out)
+    want = ((x + d).permute(0, 2, 3, 1).cpu().numpy() * 255).astype(np.uint8)             # utils.py:64
+    assert np.array_equal(out.cpu().numpy(), want)
+    _hip.quantize_u8_nhwc(x, torch.zeros_like(x), out)
+    want0 = ((u8.float() / 255).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)
+    assert np.array_equal(out.cpu().numpy(), want0)
