@@ -227,8 +227,9 @@ def test_update_full_size_properties():
         d, m = delta[sl].clone(), torch.empty_like(mom[sl])
         _hip.mi_update(grad[sl].contiguous(), mom[sl].contiguous(), m, d, x[sl].contiguous(), 1.0, alpha, EPS)
         assert torch.equal(d, d_all[sl]) and torch.equal(m, m_all[sl]), "shard starting at image %d" % lo
-    for lo in (0, 32, FULL_N - 32):                                  # 32 images = 116 MB per launch: the cached path
-        sl = slice(max(lo, 0), max(lo, 0) + min(32, FULL_N))
+    small = min(32, FULL_N)                                          # 32 images = 116 MB per launch: the cached path
+    for lo in sorted({0, min(small, FULL_N - small), FULL_N - small}):
+        sl = slice(lo, lo + small)
         d, m = delta[sl].clone(), torch.empty_like(mom[sl])
         _hip.mi_update(grad[sl].contiguous(), mom[sl].contiguous(), m, d, x[sl].contiguous(), 1.0, alpha, EPS)
         assert torch.equal(d, d_all[sl]) and torch.equal(m, m_all[sl]), "32-image shard at %d" % lo
