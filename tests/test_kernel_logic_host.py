@@ -203,3 +203,4 @@ def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
     monkeypatch.setattr(W, "SHARD_N", 5)
     W.test_update_full_size_properties()
     W.test_quantiser_full_size()
+    W.test_transform_properties_at_shard_size()

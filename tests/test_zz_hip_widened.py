@@ -269,3 +269,46 @@ def test_quantiser_full_size():
     _hip.quantize_u8_nhwc(x, torch.zeros_like(x), out)
     want0 = ((u8.float() / 255).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)
     assert np.array_equal(out.cpu().numpy(), want0)
+
+
+def test_transform_properties_at_shard_size():
+    """TIM / DIM / SIM at the per-GPU batch of configs[1] (125 images), again through properties only:
+      * images (planes) are independent: one call == calls on sub-batches, bit for bit;
+      * the depthwise convolution commutes with a power-of-two rescaling, bit for bit;
+      * DIM's and SIM's backward kernels are the adjoints of their forwards: <fwd(x), g> == <x, bwd(g)> to fp32 rounding."""
+    from transferattack_amd import _hip
+    n = SHARD_N
+    gen = torch.Generator().manual_seed(99)
+    x = torch.rand(n, 3, 224, 224, generator=gen).to(DEV)
+    g = torch.randn(n, 3, 224, 224, generator=gen).to(DEV)
+    cut = max(1, n // 3)
+    # TIM
+    w = torch.rand(15, 15, generator=gen)
+    w = (w / w.sum()).to(DEV)
+    out = torch.empty_like(g)
+    _hip.depthwise_conv2d_same(g, out, w)
+    part = torch.empty_like(g[:cut])
+    _hip.depthwise_conv2d_same(g[:cut].contiguous(), part, w)
+    assert torch.equal(part, out[:cut])
+    out4 = torch.empty_like(g)
+    _hip.depthwise_conv2d_same(g * 4.0, out4, w)
+    assert torch.equal(out4, out * 4.0)
+    # DIM
+    geom = (246, 237, 3, 5)
+    y, gx = torch.empty_like(x), torch.empty_like(x)
+    _hip.dim_fwd(x, y, *geom)
+    _hip.dim_bwd(g, gx, *geom)
+    yp, gp = torch.empty_like(x[:cut]), torch.empty_like(x[:cut])
+    _hip.dim_fwd(x[:cut].contiguous(), yp, *geom)
+    _hip.dim_bwd(g[:cut].contiguous(), gp, *geom)
+    assert torch.equal(yp, y[:cut]) and torch.equal(gp, gx[:cut])
+    lhs, rhs = float((y.double() * g.double()).sum()), float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (y.double() * g.double()).abs().sum().item()
+    # SIM
+    ys = torch.empty((5 * n, 3, 224, 224), device=DEV)
+    _hip.scale_copies_fwd(x, ys, 5)
+    gs = torch.randn(ys.shape, generator=gen).to(DEV)
+    gxs = torch.empty_like(x)
+    _hip.scale_copies_bwd(gs, gxs, 5)
+    lhs, rhs = float((ys.double() * gs.double()).sum()), float((x.double() * gxs.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (ys.double() * gs.double()).abs().sum().item()
