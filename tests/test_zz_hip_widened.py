@@ -1,8 +1,10 @@
-"""GPU (-m gpu), collected last: AdaEA / SMER / FGSRA on MI355X against the reference's golden loops.
+"""GPU (-m gpu), collected last: what was written after the GPU minutes of its round were spent and has therefore
+not run on MI355X yet -- AdaEA / SMER / FGSRA / SIA / SSM against the reference's golden loops, the SIA kernels against
+the reference's stack and the oracle, and the BASELINE-size property tests.
 
-These three attacks were added after the GPU minutes of their round were spent; until this file has run on a GPU box
-their evidence is the CPU tiers (tests/test_host_logic.py bit for bit; tests/test_attack_loops_host.py, which runs
-these very functions on the host stand-in).  The file sorts last so that a surprise here cannot mask the other tiers."""
+Until this file has run on a GPU box the evidence for its contents is the CPU tiers: tests/test_host_logic.py (bit for
+bit against the reference) and tests/test_kernel_logic_host.py / tests/test_attack_loops_host.py, which run these very
+functions on the host stand-in.  The file sorts last so that a surprise here cannot mask the other tiers."""
 import numpy as np
 import pytest
 import torch
