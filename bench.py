@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--single-launch", type=int, default=int(os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0")))
     p.add_argument("--cpu-images", type=int, default=8, help="images of the CPU-baseline sample (0 = skip)")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
+    p.add_argument("--kernel-times", type=int, default=0,
+                   help="time every HIP kernel call of the loop with events (config.kernels); for the transform attacks")
     return p.parse_args()
 
 
@@ -90,6 +92,65 @@ def kernel_sweep(single_flags=(0, 1), sizes=(32, 125, 250), reps=30):
             out["n%d_%s" % (n, "single" if single else "two")] = {
                 "us": round(us, 2), "GBps": round(BYTES_PER_ELEM * e * n / us / 1e3, 1)}
         del sets
+    return out
+
+
+# algorithmic bytes of one call of a binding function, from its arguments
+_NB = lambda t: 4 * t.numel()                                                   # noqa: E731
+KERNEL_BYTES = {
+    "normalize_fwd": lambda x, y, *a: _NB(x) + _NB(y),
+    "normalize_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "momentum": lambda g, m_in, m_out, *a, **k: _NB(g) * (2 if m_in is None else 3),
+    "update_delta_linf": lambda d, x, m, *a, **k: 4 * _NB(d),
+    "depthwise_conv2d_same": lambda inp, out, w: _NB(inp) + _NB(out),
+    "dim_fwd": lambda x, y, *a: _NB(x) + _NB(y),
+    "dim_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "scale_copies_fwd": lambda x, y, *a: _NB(x) + _NB(y),
+    "scale_copies_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "sum_copies_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "admix_fwd": lambda x, perm, y, num_admix, *a: _NB(x) * (1 + num_admix) + _NB(y),
+    "admix_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "sia_fwd": lambda x, plan, y, *a, **k: _NB(x) + _NB(y),
+    "sia_bwd": lambda gy, plan, x, gx, *a, **k: _NB(gy) + 2 * _NB(x),
+    "vmi_neighbor": lambda data, delta, out, *a, **k: 3 * _NB(data),
+    "grad_accumulate": lambda acc, grad, first: _NB(acc) * (2 if first else 3),
+    "variance_finalize": lambda acc, cur, out, *a: 3 * _NB(acc),
+    "axpy": lambda x, m, coeff, out: 3 * _NB(x),
+}
+
+
+def instrument_kernels(module, make_event):
+    """Wrap the binding functions named in KERNEL_BYTES with event timing (bench-local: the product is not touched).
+    Returns (records, restore): records[name] = [(start, end, bytes)], restore() puts the originals back."""
+    records, originals = {}, {}
+
+    def wrap(name, fn):
+        def timed(*args, **kwargs):
+            start, end = make_event(), make_event()
+            start.record()
+            out = fn(*args, **kwargs)
+            end.record()
+            records.setdefault(name, []).append((start, end, KERNEL_BYTES[name](*args, **kwargs)))
+            return out
+        return timed
+
+    for name in KERNEL_BYTES:
+        originals[name] = getattr(module, name)
+        setattr(module, name, wrap(name, originals[name]))
+
+    def restore():
+        for name, fn in originals.items():
+            setattr(module, name, fn)
+    return records, restore
+
+
+def summarise_kernels(records):
+    out = {}
+    for name, rows in sorted(records.items()):
+        us = [s.elapsed_time(e) * 1e3 for s, e, _ in rows]
+        mean_us, nbytes = sum(us) / len(us), sum(b for _, _, b in rows) / len(rows)
+        out[name] = {"launches": len(rows), "mean_us": round(mean_us, 2), "algorithmic_bytes": int(nbytes),
+                     "GBps": round(nbytes / mean_us / 1e3, 1)}
     return out
 
 
@@ -179,6 +240,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _hip.profile_sink = []
+    kernel_records, restore_kernels = (instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
+                                       if args.kernel_times else ({}, lambda: None))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -188,6 +251,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sink, _hip.profile_sink = _hip.profile_sink, None
+    restore_kernels()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -240,6 +304,8 @@ def main():
                          "k1_pass_skipped_launches": _hip.stats["partials_reused"],
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
         }
+        if kernel_records:
+            result["config"]["kernels"] = summarise_kernels(kernel_records)
         if args.kernel_sweep and world == 1:
             try:
                 result["config"]["update_kernel_sweep"] = kernel_sweep()

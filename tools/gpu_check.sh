@@ -38,7 +38,8 @@ fast)
   TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 4 --warmup 2 --batch 125 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast125.json
   TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast32.json ;;
 configs)
-  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json
+  timeout 600 python bench.py --attack sia --batch 16 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_sia_b16.json
+  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json
   timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32.json
   timeout 600 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32.json ;;
 probe)
