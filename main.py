@@ -6,7 +6,7 @@
 
 Same behaviour as the reference: the hyper-parameter flags --epoch/--eps/--alpha/--momentum/--random_start are
 parsed but, as in the reference (main.py:41), not forwarded -- every attack runs with its class defaults.
-Added flags: --seed (per-batch seeding so results do not depend on the GPU count).  With several processes the
+Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches).  With several processes the
 dataset is sharded by whole batches (transferattack_amd.dist.shard_batches); for ``--attack ens`` every group of
 len(models) ranks holds one surrogate each and exchanges logits / input-gradients over RCCL.
 """
@@ -43,6 +43,9 @@ def get_parser():
     parser.add_argument('--GPU_ID', default='0', type=str)
     parser.add_argument('--seed', default=0, type=int, help='base seed of the per-batch host RNG (DIM / Admix draws)')
     parser.add_argument('--io_threads', default=4, type=int, help='host threads decoding / encoding PNGs')
+    parser.add_argument('--resume', action='store_true',
+                        help='skip the batches whose output files all exist already (an interrupted run picks up where it '
+                             'stopped; the per-batch seeding makes the remaining batches come out the same)')
     return parser.parse_args()
 
 
@@ -99,6 +102,13 @@ def main():
         # three-stage software pipeline: batch i+1 is decoded and batch i-1 is quantised / PNG-encoded on host
         # threads while batch i runs on the GPU (the reference decodes in DataLoader workers and writes inline)
         mine = tadist.shard_batches(num_batches, shard_rank, shard_world)
+        if args.resume:
+            def done(idx):
+                lo, hi = idx * args.batchsize, min((idx + 1) * args.batchsize, len(dataset))
+                return all(os.path.isfile(os.path.join(args.output_dir, dataset.filenames[i])) for i in range(lo, hi))
+            mine = [idx for idx in mine if not done(idx)]
+            if world > 1:                      # every rank decides from the same directory listing before anyone writes
+                torch.distributed.barrier()
         io = ThreadPoolExecutor(max_workers=2)
         pending_write, next_batch = None, io.submit(batch, mine[0]) if mine else None
         for pos, batch_idx in enumerate(tqdm.tqdm(mine, disable=rank != 0)):
