@@ -127,7 +127,18 @@ def _rank_members(rank, world, port, out):
         atk = _make(name, tadist.ShardedMembers(member, idx, grp, [0, 1]), model_name=["a", "b"], **kw)
         atk.noise_source = _cpu_noise(name)
         tadist.seed_batch(5, 0)
+        calls = [0]
+        plain = tadist.MemberHandle.forward
+
+        def counted(self, v, _calls=calls, _plain=plain):
+            _calls[0] += 1
+            return _plain(self, v)
+
+        tadist.MemberHandle.forward = counted
         result[name] = atk(x, y).numpy()
+        tadist.MemberHandle.forward = plain
+        # AdaEA evaluates all members side by side (all-gather / all-reduce rounds), the others address single members
+        assert (calls[0] == 0) == (name == "adaea"), (name, calls[0])
     gathered = [None] * world
     dist.all_gather_object(gathered, result)
     if rank == 0:

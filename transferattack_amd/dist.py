@@ -15,7 +15,9 @@ The reference is single-process, single-GPU (main.py:31, 43); nothing here has a
   owning member k and broadcasts its logits forward and its input gradient backward.  Every rank of the group executes
   the same attack code on the same images with the same host draws (``seed_batch`` seeds torch AND numpy), so the
   results equal the single-device run bit for bit; what is sharded is the surrogates' weights and activations
-  (one model per 288 GB GPU), not the arithmetic.
+  (one model per 288 GB GPU), not the arithmetic.  AdaEA, which evaluates ALL members at the same point, additionally
+  gets one-round forms (``member_logits`` / ``member_input_grads`` / ``member_losses``: one all-gather, or all-gather +
+  all-reduce, per round) so that M GPUs do the M evaluations side by side.
 """
 import os
 
@@ -176,6 +178,31 @@ class MemberHandle(nn.Module):
         return _OwnerCall.apply(x, self)
 
 
+class _GatherLogits(torch.autograd.Function):
+    """All members at the same input in ONE round: every rank runs its own member, the logits are all-gathered
+    ([M, N, classes]); backward: every rank back-propagates its own slice of the cotangent and the input gradients
+    are summed by one all-reduce (the members' contributions to d/dx add up)."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        with torch.enable_grad():
+            leaf = x.detach().requires_grad_(True)
+            out = owner.local(leaf)
+        ctx.own, ctx.owner = (leaf, out), owner
+        mine = out.detach().contiguous()
+        parts = [torch.empty_like(mine) for _ in range(owner.num_models)]
+        dist.all_gather(parts, mine, group=owner.group)
+        return torch.stack(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        leaf, out = ctx.own
+        owner = ctx.owner
+        gx = torch.autograd.grad(out, leaf, grad[owner.index].contiguous(), retain_graph=True)[0].contiguous()
+        dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=owner.group)
+        return gx, None
+
+
 class ShardedMembers(nn.Module):
     """Drop-in for ``EnsembleModel`` (utils.py:82-105) with one member per rank of ``group`` and the members
     individually addressable.  ``forward`` is the same stack-and-mean as the reference class, over the handles."""
@@ -184,6 +211,7 @@ class ShardedMembers(nn.Module):
         super().__init__()
         self.local = local_model
         self.group = group
+        self.index = index
         self.models = [MemberHandle(local_model if k == index else None, r, group) for k, r in enumerate(group_ranks)]
         self.num_models = len(group_ranks)
         self.mode = mode
@@ -197,6 +225,32 @@ class ShardedMembers(nn.Module):
         if self.mode == 'ind':
             return outputs
         raise NotImplementedError
+
+    # ---- one-round forms for algorithms that evaluate ALL members at the same point (AdaEA, adaea.py:65-82): M GPUs do
+    # the M evaluations side by side instead of M owner broadcasts one after the other
+    def member_logits(self, x):
+        """[M, N, classes]: every member's logits at x, differentiable with respect to x"""
+        return _GatherLogits.apply(x, self)
+
+    def member_input_grads(self, x, loss_of_logits):
+        """(logits [M, N, classes], [d loss_of_logits(logits_m) / dx for m < M]) with ONE backward per rank: each rank
+        differentiates its own member's loss, the M input gradients are all-gathered.  Each gradient is exactly what a
+        single device computes for that member."""
+        with torch.enable_grad():
+            leaf = x.detach().requires_grad_(True)
+            mine = torch.autograd.grad(loss_of_logits(self.local(leaf)), leaf)[0].contiguous()
+        parts = [torch.empty_like(mine) for _ in range(self.num_models)]
+        dist.all_gather(parts, mine, group=self.group)
+        return parts
+
+    def member_losses(self, inputs, loss_of_logits):
+        """[M, len(inputs)] matrix L[m][j] = loss_of_logits(member_m(inputs[j])), no gradient: every rank evaluates its
+        member on all inputs, one all-gather of the rows"""
+        with torch.no_grad():
+            row = torch.stack([loss_of_logits(self.local(v)) for v in inputs]).contiguous()
+        rows = [torch.empty_like(row) for _ in range(self.num_models)]
+        dist.all_gather(rows, row, group=self.group)
+        return torch.stack(rows, dim=0)
 
     def eval(self):
         self.local.eval()

@@ -34,9 +34,14 @@ class AdaEA(Attack):
         members = self.model.models
         momentum = 0.
         delta = self._start(data)
+        side_by_side = hasattr(self.model, "member_input_grads")      # dist.ShardedMembers: one member per GPU
         for _ in range(self.epoch):
-            logits = [member(delta + data) for member in members]
-            grads = [torch.autograd.grad(F.cross_entropy(out, label), delta, retain_graph=True)[0] for out in logits]
+            if side_by_side:
+                grads = self.model.member_input_grads(delta + data, lambda z: F.cross_entropy(z, label))
+                logits = list(self.model.member_logits(delta + data).unbind(0))
+            else:
+                logits = [member(delta + data) for member in members]
+                grads = [torch.autograd.grad(F.cross_entropy(out, label), delta, retain_graph=True)[0] for out in logits]
             weights = self.agm(ori_data=data, cur_adv=data + delta, grad=grads, label=label)
             keep = self.drf(grads, data_size=tuple(data.shape))
             keep = torch.where(keep >= self.threshold, torch.ones_like(keep), torch.zeros_like(keep))
@@ -52,12 +57,16 @@ class AdaEA(Attack):
         draws from every OTHER member, relative to that member's loss on its own example; softmax over members."""
         members = self.model.models
         probes = [self.get_adv_example(ori_data=ori_data, adv_data=cur_adv, grad=g) for g in grad]
-        own = [F.cross_entropy(members[k](probes[k]), label) for k in range(self.num_model)]
+        if hasattr(self.model, "member_losses"):                      # every GPU scores its member on all M probes
+            cross = self.model.member_losses(probes, lambda z: F.cross_entropy(z, label))       # cross[i][j]
+        else:
+            cross = torch.stack([torch.stack([F.cross_entropy(members[i](probes[j]), label) for j in range(self.num_model)])
+                                 for i in range(self.num_model)])
         score = torch.zeros(self.num_model, device=self.device)
         for j in range(self.num_model):
             for i in range(self.num_model):
                 if i != j:
-                    score[j] += F.cross_entropy(members[i](probes[j]), label) / own[i] * self.beta
+                    score[j] += cross[i][j] / cross[i][i] * self.beta
         return torch.softmax(score, dim=0)
 
     @torch.no_grad()
