@@ -176,7 +176,8 @@ def test_sia_kernels_golden(golden, widened_on_host):
 
 
 @pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 5), ((1, 3, 37, 41), 3, 4), ((3, 1, 16, 100), 2, 3),
-                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2)])
+                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2),
+                                             ((1, 1, 5, 700), 4, 3)])
 def test_sia_kernels_random(widened_on_host, shape, nb, copies):
     W.test_sia_kernels_random(shape, nb, copies)
 

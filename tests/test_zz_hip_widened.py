@@ -107,7 +107,8 @@ def test_sia_kernels_golden(golden):
 
 
 @pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 5), ((1, 3, 37, 41), 3, 4), ((3, 1, 16, 100), 2, 3),
-                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2)])
+                                             ((1, 2, 9, 9), 1, 2), ((1, 3, 64, 64), 5, 6), ((2, 3, 299, 299), 3, 2),
+                                             ((1, 1, 5, 700), 4, 3)])
 def test_sia_kernels_random(shape, nb, copies):
     """ragged shapes, other block counts, widths beyond one 64-lane pass -- against the oracle's restatement -- and the
     in-kernel Philox noise: the values of the oracle's stream, the same in forward and backward."""
