@@ -1,0 +1,1 @@
+"""Input-transformation attacks: HIP transforms behind the reference's ``transform`` hook (registry: attack_zoo)."""
