@@ -205,3 +205,16 @@ def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
     W.test_update_full_size_properties()
     W.test_quantiser_full_size()
     W.test_transform_properties_at_shard_size()
+
+
+@pytest.mark.parametrize("size,rate,geoms", [
+    (224, 1.05, [(224, 0, 0), (234, 0, 0), (230, 3, 2)]),
+    (224, 1.2, [(268, 0, 0), (240, 14, 28), (225, 43, 0)]),
+    (100, 1.1, [(100, 5, 5), (109, 0, 1)]),
+    (299, 1.1, [(300, 10, 20), (327, 0, 0)]),
+    (40, 1.45, [(57, 0, 0), (41, 8, 16)]),
+])
+def test_dim_lane_kernels_other_geometries(monkeypatch, size, rate, geoms):
+    """tile widths, row counts (RPW 10 and 17) and hit-run lengths the default 224 / 1.1 setting does not reach"""
+    host_kernels.install(monkeypatch, tag="dimlanes_all", env={"TA_DIM_FWD_VARIANT": "2", "TA_DIM_BWD_VARIANT": "1"})
+    G.test_dim_random(size, rate, geoms)
