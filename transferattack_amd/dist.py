@@ -189,6 +189,7 @@ class _GatherLogits(torch.autograd.Function):
             leaf = x.detach().requires_grad_(True)
             out = owner.local(leaf)
         ctx.own, ctx.owner = (leaf, out), owner
+        owner._last_graph = (leaf, out)                 # member_input_grads differentiates this same forward
         mine = out.detach().contiguous()
         parts = [torch.empty_like(mine) for _ in range(owner.num_models)]
         dist.all_gather(parts, mine, group=owner.group)
@@ -212,6 +213,7 @@ class ShardedMembers(nn.Module):
         self.local = local_model
         self.group = group
         self.index = index
+        self._last_graph = None
         self.models = [MemberHandle(local_model if k == index else None, r, group) for k, r in enumerate(group_ranks)]
         self.num_models = len(group_ranks)
         self.mode = mode
@@ -232,13 +234,13 @@ class ShardedMembers(nn.Module):
         """[M, N, classes]: every member's logits at x, differentiable with respect to x"""
         return _GatherLogits.apply(x, self)
 
-    def member_input_grads(self, x, loss_of_logits):
-        """(logits [M, N, classes], [d loss_of_logits(logits_m) / dx for m < M]) with ONE backward per rank: each rank
-        differentiates its own member's loss, the M input gradients are all-gathered.  Each gradient is exactly what a
-        single device computes for that member."""
+    def member_input_grads(self, loss_of_logits):
+        """[d loss_of_logits(logits_m) / dx for m < M] at the x of the latest ``member_logits`` call, with ONE backward per
+        rank through the forward that call already did: each rank differentiates its own member's loss, the M input
+        gradients are all-gathered.  Each gradient is exactly what a single device computes for that member."""
+        leaf, out = self._last_graph
         with torch.enable_grad():
-            leaf = x.detach().requires_grad_(True)
-            mine = torch.autograd.grad(loss_of_logits(self.local(leaf)), leaf)[0].contiguous()
+            mine = torch.autograd.grad(loss_of_logits(out), leaf, retain_graph=True)[0].contiguous()
         parts = [torch.empty_like(mine) for _ in range(self.num_models)]
         dist.all_gather(parts, mine, group=self.group)
         return parts

@@ -37,8 +37,8 @@ class AdaEA(Attack):
         side_by_side = hasattr(self.model, "member_input_grads")      # dist.ShardedMembers: one member per GPU
         for _ in range(self.epoch):
             if side_by_side:
-                grads = self.model.member_input_grads(delta + data, lambda z: F.cross_entropy(z, label))
-                logits = list(self.model.member_logits(delta + data).unbind(0))
+                logits = list(self.model.member_logits(delta + data).unbind(0))       # one forward per member ...
+                grads = self.model.member_input_grads(lambda z: F.cross_entropy(z, label))   # ... differentiated twice
             else:
                 logits = [member(delta + data) for member in members]
                 grads = [torch.autograd.grad(F.cross_entropy(out, label), delta, retain_graph=True)[0] for out in logits]
