@@ -197,9 +197,30 @@ def _rank_cli(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _run(fn, tmp_path):
+def _rank_adaea3(rank, world, port, out):
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import wrap_model
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    grp, idx, _, _ = tadist.model_groups(world, 3)
+    member = wrap_model(backbones.create("toy_cnn", seed=3 + rank, verbose=False).eval())
+    atk = _make("adaea", tadist.ShardedMembers(member, idx, grp, [0, 1, 2]), model_name=["a", "b", "c"], epoch=3)
+    atk.noise_source = _cpu_noise("adaea")
+    tadist.seed_batch(5, 0)
+    delta = atk(x, y).numpy()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, delta)
+    if rank == 0:
+        np.savez(out, r0=gathered[0], r1=gathered[1], r2=gathered[2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(fn, tmp_path, world=2):
     out = str(tmp_path / "out.npz")
-    mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(fn, args=(world, _free_port(), out), nprocs=world, join=True)
     return np.load(out)
 
 
@@ -278,3 +299,24 @@ def test_main_cli_sharded_equals_single_process(tmp_path, monkeypatch):
             two = np.array(Image.open(tmp_path / ("adv2_" + attack) / ("%d.png" % i)))
             assert np.array_equal(one, two), (attack, i)
         assert not np.array_equal(one, np.array(Image.open(tmp_path / "data" / "images" / "4.png")))   # it did attack
+
+
+def test_adaea_three_members_side_by_side(tmp_path, monkeypatch):
+    """AdaEA with one member on each of 3 ranks (all-gather of logits / per-member gradients, all-reduce of the fused
+    input gradient): every rank ends with the same delta; against the single-process run the fused gradient is a sum
+    of three terms in a different order, so it agrees to rounding and the perturbation to the few pixels that can flip."""
+    got = _run(_rank_adaea3, tmp_path, world=3)
+    assert np.array_equal(got["r0"], got["r1"]) and np.array_equal(got["r0"], got["r2"])
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones, dist as tadist
+    from conftest import u8_images
+    x = u8_images(4, 32, 5).float() / 255
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    models = [backbones.create("toy_cnn", seed=3 + k, verbose=False) for k in range(3)]
+    atk = _make("adaea", models, model_name=["a", "b", "c"], epoch=3)
+    atk.noise_source = _cpu_noise("adaea")
+    tadist.seed_batch(5, 0)
+    ref = atk(x, y).numpy()
+    assert float((got["r0"] != ref).mean()) <= 0.002
+    assert np.abs(got["r0"] - ref).max() <= 2 * 1.6 / 255 + 1e-7
