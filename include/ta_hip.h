@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 3
+#define TA_ABI_VERSION 4
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -90,6 +90,12 @@ int ta_init_delta_uniform(float* delta, const float* x, const float* noise, floa
  */
 int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, int k, int64_t planes,
                              int h, int w_, void* stream);
+/* Opt-in, NOT the reference's arithmetic: the same smoothing for a kernel that is an outer product wy (x) wx (all of
+ * tim.py:42-66's kernel types are), evaluated as two 1-D ascending FMA chains -- t = sum_kx wx[kx]*in[y][x+kx-lo], then
+ * out = sum_ky wy[ky]*t[y+ky-lo][x] -- 2k taps instead of k*k.  Differs from ta_depthwise_conv2d_same by rounding only
+ * (~1e-7 relative); k in {3, 5, 7, 15}; wy, wx: device fp32 [k]. */
+int ta_depthwise_conv2d_same_separable(const float* in, float* out, const float* wy, const float* wx, int k,
+                                       int64_t planes, int h, int w, void* stream);
 
 /* ---- DIM: DIM.transform  input_transformation/dim.py:42-68 ----------------------------------------
  * y = bilinear(pad0(bilinear(x, rnd), resize, top, left), size); one geometry for the whole call.

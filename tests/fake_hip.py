@@ -151,6 +151,11 @@ def quantize_u8_nhwc(data, delta, out):
     out.copy_(_t(O.quantize_u8(data + delta)))
 
 
+def depthwise_conv2d_same_separable(inp, out, wy, wx):
+    calls.append("depthwise_conv2d_same_separable")
+    out.copy_(_t(C.depthwise_conv2d_same_separable(inp.numpy(), wy.numpy(), wx.numpy())))
+
+
 def _sia_plans(plan, num_block, n, noise):
     """decode the int32 plan table of transforms.sia_draw back into the oracle's per-copy dictionaries"""
     import struct
@@ -185,7 +190,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
         gx.copy_(torch.autograd.grad(y, xin, gy)[0])
 
 
-_NAMES = ["sia_fwd", "sia_bwd", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+_NAMES = ["sia_fwd", "sia_bwd", "depthwise_conv2d_same_separable", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd"]

@@ -116,3 +116,10 @@ def test_main_cli_resume(tmp_path, monkeypatch):
         assert np.array_equal(np.array(Image.open(tmp_path / "adv" / ("%d.png" % i))), full[i])
     after = {i: (tmp_path / "adv" / ("%d.png" % i)).stat().st_mtime_ns for i in range(5)}
     assert [i for i in range(5) if after[i] != stamp[i]] == [2, 3]          # only the incomplete batch was redone
+
+
+def test_tim_loop_with_separable_smoothing(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0)
+    W.test_tim_loop_with_separable_smoothing(golden, monkeypatch)

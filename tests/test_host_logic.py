@@ -165,7 +165,7 @@ def test_abi_symbols_exported():
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ta_abi_version() == _hip.ABI_VERSION == 3
+    assert lib.ta_abi_version() == _hip.ABI_VERSION == 4
     assert lib.ta_l1_workspace_floats(32, 150528) == 2 * 32 * 49
     assert lib.ta_fused_sync_bytes(32, 150528) >= 32 * 49 * 8
 

@@ -218,3 +218,9 @@ def test_dim_lane_kernels_other_geometries(monkeypatch, size, rate, geoms):
     """tile widths, row counts (RPW 10 and 17) and hit-run lengths the default 224 / 1.1 setting does not reach"""
     host_kernels.install(monkeypatch, tag="dimlanes_all", env={"TA_DIM_FWD_VARIANT": "2", "TA_DIM_BWD_VARIANT": "1"})
     G.test_dim_random(size, rate, geoms)
+
+
+@pytest.mark.parametrize("shape,k", [((4, 3, 224, 224), 15), ((2, 3, 299, 299), 15), ((2, 3, 37, 41), 15), ((2, 3, 64, 64), 3),
+                                     ((2, 3, 64, 64), 5), ((1, 3, 50, 70), 7), ((1, 1, 5, 9), 15)])
+def test_separable_smoothing(widened_on_host, shape, k):
+    W.test_separable_smoothing(shape, k)

@@ -31,6 +31,7 @@ dimvariants)
   for v in "0 0" "2 0" "0 1" "2 1"; do set -- $v; TA_DIM_FWD_VARIANT=$1 TA_DIM_BWD_VARIANT=$2 timeout 120 python tools/dim_time.py; done 2>&1 | tee $OUT/dim_variants.txt
   TA_XCD_MAJOR_TILES=1 TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 120 python tools/dim_time.py 2>&1 | sed "s/^/xcd-major /" | tee -a $OUT/dim_variants.txt ;;
 widened)
+  timeout 300 python tools/tim_microbench.py 2>&1 | tail -5 | tee $OUT/tim_separable.txt
   timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider 2>&1 | tail -12 | tee $OUT/widened_pytest.txt ;;
 k2sweep)
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ta_fused_sync_error": (_int, [_vp, _i64, _i64, _vp]),
     "ta_init_delta_uniform": (_int, [_vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
+    "ta_depthwise_conv2d_same_separable": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_dim_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipExtensionError(RuntimeError):
@@ -274,6 +275,14 @@ def depthwise_conv2d_same(inp, out, weight2d):
     h, w = inp.shape[-2:]
     _check(load().ta_depthwise_conv2d_same(_ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(weight2d, name="kernel"),
                                            k, inp.numel() // (h * w), h, w, _stream()), "ta_depthwise_conv2d_same")
+
+
+def depthwise_conv2d_same_separable(inp, out, wy, wx):
+    """opt-in two-pass form for outer-product kernels (rounding differs from the reference's direct convolution)"""
+    h, w = inp.shape[-2:]
+    _check(load().ta_depthwise_conv2d_same_separable(_ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(wy, name="wy"),
+                                                     _ptr(wx, name="wx"), wy.numel(), inp.numel() // (h * w), h, w,
+                                                     _stream()), "ta_depthwise_conv2d_same_separable")
 
 
 def dim_fwd(x, y, resize, rnd, top, left):
