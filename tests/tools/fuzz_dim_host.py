@@ -1,6 +1,6 @@
-"""Fuzz the lane-per-column DIM kernels (host stand-in, tests/hipcpu) against the C oracle: random sizes, rates, geometries.\n    python tools/fuzz_dim_host.py <seed> <cases>"""
+"""Fuzz the lane-per-column DIM kernels (host stand-in, tests/hipcpu) against the C oracle: random sizes, rates, geometries.\n    python tests/tools/fuzz_dim_host.py <seed> <cases>"""
 import os, sys, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT+'/oracle', ROOT+'/tests'): sys.path.insert(0,p)
 os.environ['TA_DIM_FWD_VARIANT']='2'; os.environ['TA_DIM_BWD_VARIANT']='1'
 import host_kernels, c_oracle as C

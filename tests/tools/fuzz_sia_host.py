@@ -1,6 +1,6 @@
-"""Fuzz the SIA kernels (host stand-in, tests/hipcpu) against the oracle: random shapes, block counts, copy counts.\n    python tools/fuzz_sia_host.py <seed> <cases>"""
+"""Fuzz the SIA kernels (host stand-in, tests/hipcpu) against the oracle: random shapes, block counts, copy counts.\n    python tests/tools/fuzz_sia_host.py <seed> <cases>"""
 import os, sys, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT+'/oracle', ROOT+'/tests'): sys.path.insert(0,p)
 import host_kernels, c_oracle as C, fgsm_oracle as O
 class P:

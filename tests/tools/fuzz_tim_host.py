@@ -1,12 +1,12 @@
 """Fuzz the depthwise-convolution kernels (host stand-in, tests/hipcpu) against the C oracle for one TA_TIM_VARIANT.
-    TA_TIM_VARIANT=3 python tools/fuzz_tim_host.py <seed> <cases>"""
+    TA_TIM_VARIANT=3 python tests/tools/fuzz_tim_host.py <seed> <cases>"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT + '/oracle', ROOT + '/tests'):
     sys.path.insert(0, p)
 import c_oracle as C          # noqa: E402
@@ -39,4 +39,11 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     if not np.array_equal(out.numpy(), C.depthwise_conv2d_same(g.numpy(), wt.numpy())):
         bad += 1
         print('MISMATCH', k, planes, h, w)
+    if k in (3, 5, 7, 15):                                  # the opt-in separable form against its own restatement
+        fy, fx = torch.rand(k), torch.rand(k)
+        fy, fx = (fy / fy.sum()).contiguous(), (fx / fx.sum()).contiguous()
+        _hip.depthwise_conv2d_same_separable(g, out, fy, fx)
+        if not np.array_equal(out.numpy(), C.depthwise_conv2d_same_separable(g.numpy(), fy.numpy(), fx.numpy())):
+            bad += 1
+            print('MISMATCH separable', k, planes, h, w)
 print('done, mismatches:', bad)

@@ -1,12 +1,12 @@
 """Fuzz the update stack (host stand-in, tests/hipcpu) against the oracle on random ragged shapes: the assertions of
 tests/test_hip_kernels.py::test_fused_update_random and ::test_normalize_and_producer_side_partials.
-    python tools/fuzz_update_host.py <seed> <cases>"""
+    python tests/tools/fuzz_update_host.py <seed> <cases>"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT + '/oracle', ROOT + '/tests'):
     sys.path.insert(0, p)
 import host_kernels           # noqa: E402

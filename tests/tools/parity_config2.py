@@ -10,7 +10,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 N = int(os.environ.get("TA_PARITY_IMAGES", "32"))
 
