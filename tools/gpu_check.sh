@@ -33,6 +33,9 @@ dimvariants)
 widened)
   timeout 300 python tools/tim_microbench.py 2>&1 | tail -5 | tee $OUT/tim_separable.txt
   timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider 2>&1 | tail -12 | tee $OUT/widened_pytest.txt ;;
+freq)
+  # SSM (20 spectrum views per iteration) with the rocFFT DCT pair and with the GEMM form
+  for v in 0 1; do TA_DCT_GEMM=$v timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | sed "s/^/TA_DCT_GEMM=$v /" | tee -a $OUT/bench_ssm_b16.txt; done ;;
 k2sweep)
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
 fast)
