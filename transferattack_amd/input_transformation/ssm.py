@@ -36,6 +36,7 @@ class SSM(MIFGSM):
         data, label = self._to_device(data, label)
         delta = self.init_delta(data)
         momentum = 0
+        fused = self._can_fuse_update()
         for _ in range(self.epoch):
             grads = None
             for s in range(self.num_spectrum):
@@ -45,6 +46,9 @@ class SSM(MIFGSM):
                     grads = torch.empty_like(grad)
                 _hip.grad_accumulate(grads, grad, first=(s == 0))
             grads = grads / self.num_spectrum
-            momentum = self.get_momentum(grads, momentum)
-            delta = self.update_delta(delta, data, momentum, self.alpha)
+            if fused:
+                momentum = self._fused_update(grads, momentum, delta, data)
+            else:
+                momentum = self.get_momentum(grads, momentum)
+                delta = self.update_delta(delta, data, momentum, self.alpha)
         return delta.detach()
