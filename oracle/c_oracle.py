@@ -212,3 +212,31 @@ def variance_finalize(acc, cur, count):
     lib().ta_oracle_variance_finalize(pa, pc, out.ctypes.data_as(_f32p), ctypes.c_float(count),
                                       ctypes.c_int64(acc.size))
     return out
+
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def sia_fwd(x, plan, noise, num_block):
+    """x [N,C,H,W], plan int32 [copies, stride] (transforms.sia_draw), noise shaped like the output stack"""
+    x, px = _f(x)
+    noise, pn = _f(noise)
+    plan = np.ascontiguousarray(plan, dtype=np.int32)
+    copies = plan.shape[0]
+    h, w = x.shape[-2:]
+    y = np.empty((copies * x.shape[0],) + x.shape[1:], dtype=np.float32)
+    lib().ta_oracle_sia_fwd(px, plan.ctypes.data_as(_i32p), pn, y.ctypes.data_as(_f32p),
+                            ctypes.c_int64(x.size // (h * w)), h, w, copies, num_block)
+    return y
+
+
+def sia_bwd(gy, plan, x, noise, num_block):
+    gy, pg = _f(gy)
+    x, px = _f(x)
+    noise, pn = _f(noise)
+    plan = np.ascontiguousarray(plan, dtype=np.int32)
+    h, w = x.shape[-2:]
+    gx = np.empty_like(x)
+    lib().ta_oracle_sia_bwd(pg, plan.ctypes.data_as(_i32p), px, pn, gx.ctypes.data_as(_f32p),
+                            ctypes.c_int64(x.size // (h * w)), h, w, plan.shape[0], num_block)
+    return gx

@@ -366,3 +366,78 @@ void ta_oracle_depthwise_conv2d_same_separable(const float* in, float* out, cons
     }
     free(t);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SIA block transform, transferattack/input_transformation/sia.py:41-100, from the int32 plan table the product draws
+ * (per copy: rows[nb+1], cols[nb+1], then per rectangle -- rows outer -- op, roll step, scale bits):
+ *   0 roll rows (x.roll(step, dims=2))   1 roll columns   2 flip rows   3 flip columns   4 rot90(k=2)
+ *   5 torch.rand(1)[0] * x               6 torch.clip(x + noise, 0, 1)
+ * x [planes][h][w]; y, noise, gy [copies][planes][h][w].  Backward: autograd's accumulation order over the copies is
+ * last copy first (pinned by tests/golden/sia.npz); clip passes the gradient where 0 <= x + noise <= 1.
+ * ---------------------------------------------------------------------------------------------- */
+static void sia_cell(const int32_t* plan, int nb, int r, int c, int* r_lo, int* bh, int* c_lo, int* bw, int* op,
+                     int* step, float* scale) {
+    const int32_t* rows = plan;
+    const int32_t* cols = plan + nb + 1;
+    int bi = 0, bj = 0;
+    while (bi + 1 < nb && r >= rows[bi + 1]) ++bi;
+    while (bj + 1 < nb && c >= cols[bj + 1]) ++bj;
+    const int32_t* blk = plan + 2 * (nb + 1) + 3 * (bi * nb + bj);
+    *r_lo = rows[bi]; *bh = rows[bi + 1] - rows[bi];
+    *c_lo = cols[bj]; *bw = cols[bj + 1] - cols[bj];
+    *op = blk[0]; *step = blk[1];
+    memcpy(scale, &blk[2], sizeof(float));
+}
+
+void ta_oracle_sia_fwd(const float* x, const int32_t* plan, const float* noise, float* y, int64_t planes, int h, int w,
+                       int copies, int nb) {
+    const int stride = 2 * (nb + 1) + 3 * nb * nb;
+    for (int k = 0; k < copies; ++k)
+        for (int64_t p = 0; p < planes; ++p)
+            for (int r = 0; r < h; ++r)
+                for (int c = 0; c < w; ++c) {
+                    int r_lo, bh, c_lo, bw, op, step;
+                    float scale;
+                    sia_cell(plan + k * stride, nb, r, c, &r_lo, &bh, &c_lo, &bw, &op, &step, &scale);
+                    int lr = r - r_lo, lc = c - c_lo;
+                    if (op == 0) lr = ((lr - step) % bh + bh) % bh;            /* out[i] = in[(i - step) mod n] */
+                    if (op == 1) lc = ((lc - step) % bw + bw) % bw;
+                    if (op == 2 || op == 4) lr = bh - 1 - lr;
+                    if (op == 3 || op == 4) lc = bw - 1 - lc;
+                    float v = x[(p * h + r_lo + lr) * w + c_lo + lc];
+                    const int64_t o = ((k * planes + p) * h + r) * (int64_t)w + c;
+                    if (op == 5) v = scale * v;
+                    if (op == 6) v = fminf(fmaxf(v + noise[o], 0.0f), 1.0f);
+                    y[o] = v;
+                }
+}
+
+void ta_oracle_sia_bwd(const float* gy, const int32_t* plan, const float* x, const float* noise, float* gx,
+                       int64_t planes, int h, int w, int copies, int nb) {
+    const int stride = 2 * (nb + 1) + 3 * nb * nb;
+    for (int64_t p = 0; p < planes; ++p)
+        for (int r = 0; r < h; ++r)
+            for (int c = 0; c < w; ++c) {
+                const int64_t here = (p * h + r) * (int64_t)w + c;
+                float acc = 0.0f;
+                for (int k = copies - 1; k >= 0; --k) {
+                    int r_lo, bh, c_lo, bw, op, step;
+                    float scale;
+                    sia_cell(plan + k * stride, nb, r, c, &r_lo, &bh, &c_lo, &bw, &op, &step, &scale);
+                    int lr = r - r_lo, lc = c - c_lo;
+                    if (op == 0) lr = (lr + step) % bh;                        /* where in[i] went */
+                    if (op == 1) lc = (lc + step) % bw;
+                    if (op == 2 || op == 4) lr = bh - 1 - lr;
+                    if (op == 3 || op == 4) lc = bw - 1 - lc;
+                    const int64_t base = (k * planes + p) * (int64_t)h * w;
+                    float g = gy[base + (int64_t)(r_lo + lr) * w + c_lo + lc];
+                    if (op == 5) g = g * scale;
+                    if (op == 6) {
+                        const float v = x[here] + noise[base + (int64_t)r * w + c];
+                        g = (v >= 0.0f && v <= 1.0f) ? g : 0.0f;
+                    }
+                    acc = (k == copies - 1) ? g : acc + g;
+                }
+                gx[here] = acc;
+            }
+}

@@ -200,3 +200,18 @@ def test_sia_block_transform(golden):
     y = O.sia_apply(xin, plans)
     assert same(y.detach().numpy(), g["y"])
     assert same(torch.autograd.grad(y, xin, gy)[0].numpy(), g["gx"])
+
+
+def test_sia_c_restatement(golden):
+    """the plain-C restatement of the SIA stack and its backward (integer index maps, one multiply, one add + clip),
+    driven by the product's plan table, against the reference's own tensors"""
+    import sys
+    sys.path.insert(0, ".")
+    from transferattack_amd.transforms import sia_draw
+    g = golden("sia")
+    x = t(g["x"])
+    np.random.seed(int(g["np_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    plan, noise = sia_draw(tuple(x.shape), 3, 20, lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi))
+    assert same(C.sia_fwd(g["x"], plan, noise.numpy(), 3), g["y"])
+    assert same(C.sia_bwd(g["gy"], plan, g["x"], noise.numpy(), 3), g["gx"])

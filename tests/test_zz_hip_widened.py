@@ -135,6 +135,9 @@ def test_sia_kernels_random(shape, nb, copies):
     gx = torch.empty_like(x_d)
     _hip.sia_bwd(gy.to(DEV), plan_d, x_d, gx, copies, nb, SIA_NOISE, noise=noise_d)
     assert np.array_equal(gx.cpu().numpy(), gx_ref.numpy())
+    # ... and the plain-C restatement, driven by the same plan table, says the same
+    assert np.array_equal(y.cpu().numpy(), C.sia_fwd(x.numpy(), plan, noise.numpy(), nb))
+    assert np.array_equal(gx.cpu().numpy(), C.sia_bwd(gy.numpy(), plan, x.numpy(), noise.numpy(), nb))
     # in-kernel noise: element o of the output stack gets value o of the Philox (seed, offset) stream
     y2 = torch.empty_like(y)
     _hip.sia_fwd(x_d, plan_d, y2, copies, nb, SIA_NOISE, seed=11, offset=3)
