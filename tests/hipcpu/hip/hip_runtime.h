@@ -5,7 +5,7 @@
 // oracle in a container that has no GPU.  It says nothing about speed and is never part of the product: only tests/
 // builds it (tests/hipcpu/hipcpu_build.py), the package cannot import it.
 //
-// Model: every lane of a workgroup is a fiber (ucontext) on one OS thread; __syncthreads() and the wave shuffles park
+// Model: every lane of a workgroup is a fiber (its own stack, switched in user space) on one OS thread; __syncthreads() and the wave shuffles park
 // the fiber until its group has arrived.  Workgroups are independent, so a small pool of OS threads runs them side by
 // side; `__shared__` arrays are thread_local statics (one workgroup per OS thread at a time).  Only what the csrc
 // kernels use is provided.

@@ -2,11 +2,40 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <sys/mman.h>
-#include <ucontext.h>
 #include <atomic>
 #include <thread>
 #include <vector>
 #include "hip/hip_runtime.h"
+
+#if !defined(__x86_64__)
+#error "tests/hipcpu switches fibers with a few lines of x86-64 assembly (the build container and the GPU boxes are x86-64)"
+#endif
+// void hipcpu_switch(void** save_sp, void* load_sp): park the caller (callee-saved registers + stack pointer) and resume
+// the context whose stack pointer is load_sp.  No signal-mask system call as in swapcontext -- a workgroup switches a
+// few hundred times per barrier.
+extern "C" void hipcpu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipcpu_switch
+    .type hipcpu_switch, @function
+hipcpu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipcpu_switch, .-hipcpu_switch
+)");
 
 namespace hipcpu {
 namespace {
@@ -14,14 +43,14 @@ namespace {
 constexpr size_t kStackBytes = 128 * 1024;
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     Idx tid;
     bool done;
 };
 
 // one per OS thread of the pool: the lanes of the workgroup it is currently running
 struct Worker {
-    ucontext_t scheduler;
+    void* scheduler = nullptr;
     std::vector<Fiber> lanes;
     char* stacks = nullptr;
     Idx bid, bdim, gdim;
@@ -36,7 +65,7 @@ thread_local Worker* worker = nullptr;
 
 void yield() {
     Worker* w = worker;
-    swapcontext(&w->lanes[w->current].ctx, &w->scheduler);
+    hipcpu_switch(&w->lanes[w->current].sp, w->scheduler);
 }
 
 void release_if_complete(Worker* w) {
@@ -60,7 +89,7 @@ void wave_barrier(Worker* w, unsigned wave) {
     while (gen == w->wave_generation[wave]) yield();
 }
 
-void lane_entry() {
+void lane_entry() {                                       // first frame of every fiber; never returns
     Worker* w = worker;
     (*w->body)();
     const unsigned lane = w->current;
@@ -69,6 +98,9 @@ void lane_entry() {
     --w->wave_alive[lane / 64];
     release_if_complete(w);
     release_wave_if_complete(w, lane / 64);
+    void* parked;
+    hipcpu_switch(&parked, w->scheduler);
+    __builtin_unreachable();
 }
 
 void run_workgroup(Worker* w, unsigned lanes) {
@@ -83,18 +115,21 @@ void run_workgroup(Worker* w, unsigned lanes) {
         f.done = false;
         f.tid = Idx{t % w->bdim.x, (t / w->bdim.x) % w->bdim.y, t / (w->bdim.x * w->bdim.y)};
         ++w->wave_alive[t / 64];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = w->stacks + static_cast<size_t>(t) * kStackBytes;
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = &w->scheduler;
-        makecontext(&f.ctx, lane_entry, 0);
+        // initial frame: six callee-saved registers, then lane_entry as the return address of hipcpu_switch, placed so
+        // that lane_entry starts with the stack alignment of a normal call (rsp + 8 divisible by 16)
+        char* top = w->stacks + static_cast<size_t>(t + 1) * kStackBytes;
+        void** slot = reinterpret_cast<void**>(top - 16);
+        slot[0] = reinterpret_cast<void*>(&lane_entry);
+        slot[1] = nullptr;
+        for (int k = 1; k <= 6; ++k) slot[-k] = nullptr;
+        f.sp = slot - 6;
     }
     unsigned remaining = lanes;
     while (remaining != 0)
         for (unsigned t = 0; t < lanes; ++t) {
             if (w->lanes[t].done) continue;
             w->current = t;
-            swapcontext(&w->scheduler, &w->lanes[t].ctx);
+            hipcpu_switch(&w->scheduler, w->lanes[t].sp);
             if (w->lanes[t].done) --remaining;
         }
 }
