@@ -124,9 +124,17 @@ void run_workgroup(Worker* w, unsigned lanes) {
         for (int k = 1; k <= 6; ++k) slot[-k] = nullptr;
         f.sp = slot - 6;
     }
+    // HIPCPU_ORDER=reverse runs the lanes of a workgroup last-to-first between barriers: a kernel whose result depends on
+    // the order in which lanes of DIFFERENT waves touch LDS / memory between two barriers (a missing barrier) gives a
+    // different answer under the two orders
+    static const bool reverse = []() {
+        const char* e = getenv("HIPCPU_ORDER");
+        return e != nullptr && e[0] == 'r';
+    }();
     unsigned remaining = lanes;
     while (remaining != 0)
-        for (unsigned t = 0; t < lanes; ++t) {
+        for (unsigned i = 0; i < lanes; ++i) {
+            const unsigned t = reverse ? lanes - 1 - i : i;
             if (w->lanes[t].done) continue;
             w->current = t;
             hipcpu_switch(&w->scheduler, w->lanes[t].sp);

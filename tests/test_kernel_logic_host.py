@@ -224,3 +224,25 @@ def test_dim_lane_kernels_other_geometries(monkeypatch, size, rate, geoms):
                                      ((2, 3, 64, 64), 5), ((1, 3, 50, 70), 7), ((1, 1, 5, 9), 15)])
 def test_separable_smoothing(widened_on_host, shape, k):
     W.test_separable_smoothing(shape, k)
+
+
+def test_kernels_under_reverse_lane_order(monkeypatch, golden, widened_on_host):
+    """HIPCPU_ORDER=reverse runs the lanes of a workgroup last-to-first between barriers.  A kernel that needs a barrier
+    it does not have (lanes of different waves meeting in LDS) answers differently under the two orders; all of them
+    must give the oracle's bytes under both."""
+    host_kernels.install(monkeypatch, tag="rev", env={"HIPCPU_ORDER": "reverse", "TA_DIM_FWD_VARIANT": "2",
+                                                       "TA_DIM_BWD_VARIANT": "1", "TA_TIM_VARIANT": "3"})
+    G.test_update_stack_golden(golden, "d09", 0.9, False)
+    G.test_fused_update_random((5, 3, 37, 41), False)
+    G.test_normalize_and_producer_side_partials((3, 3, 37, 41))
+    G.test_tim_random((4, 3, 224, 224), 15)
+    G.test_tim_random((2, 3, 50, 70), 9)
+    G.test_dim_golden(golden)
+    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
+    G.test_sim_admix_golden(golden)
+    G.test_vmi_kernels_and_philox()
+    W.test_separable_smoothing((4, 3, 224, 224), 15)
+    W.test_sia_kernels_golden(golden)
+    host_kernels.install(monkeypatch, tag="rev0", env={"HIPCPU_ORDER": "reverse"})      # the shipped variants
+    G.test_tim_random((4, 3, 224, 224), 15)
+    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
