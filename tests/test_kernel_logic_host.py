@@ -127,10 +127,14 @@ def test_dim_reads_stay_in_bounds(monkeypatch, variant):
             xg, keep = _guarded(x, at_end)
             xt = torch.from_numpy(xg)
             for rnd, top, left in geoms:
-                y, gx = torch.empty(x.shape), torch.empty(x.shape)
+                yg, keep_y = _guarded(np.zeros_like(x), at_end)            # the outputs are fenced in as well
+                gg, keep_g = _guarded(np.zeros_like(x), at_end)
+                y, gx = torch.from_numpy(yg), torch.from_numpy(gg)
                 _hip.dim_fwd(xt, y, resize, rnd, top, left)
                 _hip.dim_bwd(xt, gx, resize, rnd, top, left)
                 assert np.array_equal(y.numpy(), C.dim_fwd(x, (True, rnd, top, left), resize))
+                assert np.array_equal(gx.numpy(), C.dim_bwd(x, (True, rnd, top, left), resize))
+                del y, gx, yg, gg
             del xt, xg
             keep = None
 
@@ -146,10 +150,15 @@ def test_tim_reads_stay_in_bounds(monkeypatch, variant):
         w = (w / w.sum()).contiguous()
         for at_end in (True, False):
             gg, keep = _guarded(grad, at_end)
-            out = torch.empty(shape)
+            og, keep_o = _guarded(np.zeros_like(grad), at_end)
+            out = torch.from_numpy(og)
             _hip.depthwise_conv2d_same(torch.from_numpy(gg), out, w)
             assert np.array_equal(out.numpy(), C.depthwise_conv2d_same(grad, w.numpy()))
-            del gg
+            if k in (3, 5, 7, 15):
+                f = w.sum(dim=0).contiguous()
+                _hip.depthwise_conv2d_same_separable(torch.from_numpy(gg), out, f, f)
+                assert np.array_equal(out.numpy(), C.depthwise_conv2d_same_separable(grad, f.numpy(), f.numpy()))
+            del gg, out, og
             keep = None
 
 
@@ -246,3 +255,78 @@ def test_kernels_under_reverse_lane_order(monkeypatch, golden, widened_on_host):
     host_kernels.install(monkeypatch, tag="rev0", env={"HIPCPU_ORDER": "reverse"})      # the shipped variants
     G.test_tim_random((4, 3, 224, 224), 15)
     G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
+
+
+@pytest.mark.parametrize("at_end", [True, False])
+@pytest.mark.parametrize("shape", [(3, 3, 37, 41), (2, 1, 1, 7), (1, 3, 224, 224), (2, 3, 5, 6)])
+def test_streaming_kernels_stay_in_bounds(shape, at_end):
+    """every operand of the update / elementwise kernels -- inputs AND outputs -- flush against inaccessible pages:
+    a vector access that runs past a ragged tail, before the first element or beyond the last faults"""
+    from transferattack_amd import _hip
+    gen = torch.Generator().manual_seed(sum(shape))
+    keep = []
+
+    def guarded(tensor):
+        view, owner = _guarded(tensor.numpy(), at_end)
+        keep.append(owner)
+        return torch.from_numpy(view)
+
+    n = shape[0]
+    x = guarded(torch.rand(shape, generator=gen))
+    grad = guarded(torch.randn(shape, generator=gen) * 1e-3)
+    mom = guarded(torch.randn(shape, generator=gen))
+    var = guarded(torch.randn(shape, generator=gen) * 1e-4)
+    delta = guarded(torch.zeros(shape))
+    xadv = guarded(torch.zeros(shape))
+    out = guarded(torch.zeros(shape))
+    _hip.mi_update(grad, mom, mom, delta, x, 0.9, 1.6 / 255, 16 / 255, variance=var, x_adv=xadv)
+    _hip.momentum(grad, None, out, 1.0)
+    _hip.update_delta_linf(delta, x, mom, 1.6 / 255, 16 / 255, out, x_adv=xadv)
+    _hip.update_delta_linf(delta, x, mom, var.abs(), 16 / 255, out)
+    _hip.update_delta_l2(delta, x, grad, 0.3, 3.0, out)
+    c = shape[1]
+    mean, std = torch.tensor([0.485, 0.456, 0.406][:c]), torch.tensor([0.229, 0.224, 0.225][:c])
+    _hip.normalize_fwd(x, out, mean, std)
+    _hip.normalize_bwd(grad, out, std)
+    _hip.init_delta_uniform(delta, x, 16 / 255, seed=3, offset=1)
+    _hip.vmi_neighbor(x, delta, out, 0.1, seed=3, offset=2)
+    _hip.grad_accumulate(out, grad, first=True)
+    _hip.grad_accumulate(out, grad, first=False)
+    _hip.variance_finalize(out, grad, xadv, 20)
+    _hip.axpy(x, mom, 0.01, out)
+    copies = guarded(torch.zeros((5 * n,) + shape[1:]))
+    _hip.scale_copies_fwd(x, copies, 5)
+    _hip.scale_copies_bwd(copies, out, 5)
+    _hip.sum_copies_bwd(copies, out, 5)
+    mixed = guarded(torch.zeros((2 * 3 * n,) + shape[1:]))
+    perm = torch.cat([torch.randperm(n, generator=gen) for _ in range(3)])
+    _hip.admix_fwd(x, perm, mixed, 3, 2, 0.2)
+    _hip.admix_bwd(mixed, out, 3, 2)
+    u8 = torch.zeros((n,) + shape[2:] + (shape[1],), dtype=torch.uint8)
+    _hip.quantize_u8_nhwc(x, delta, u8)
+    del keep
+
+
+@pytest.mark.parametrize("at_end", [True, False])
+def test_sia_stays_in_bounds(at_end):
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import SIA_NOISE, sia_draw
+    keep = []
+
+    def guarded(array):
+        view, owner = _guarded(np.ascontiguousarray(array), at_end)
+        keep.append(owner)
+        return torch.from_numpy(view)
+
+    for shape, nb, copies in (((1, 2, 37, 41), 3, 3), ((1, 1, 9, 130), 2, 2)):
+        np.random.seed(nb)
+        torch.manual_seed(copies)
+        plan, noise = sia_draw(shape, nb, copies, lambda s, lo, hi: torch.zeros(s).uniform_(lo, hi))
+        x = torch.rand(shape)
+        xg, plan_g, noise_g = guarded(x.numpy()), guarded(plan), guarded(noise.numpy())
+        y = guarded(np.zeros((copies * shape[0],) + shape[1:], dtype=np.float32))
+        _hip.sia_fwd(xg, plan_g, y, copies, nb, SIA_NOISE, noise=noise_g)
+        assert np.array_equal(y.numpy(), C.sia_fwd(x.numpy(), plan, noise.numpy(), nb))
+        gx = guarded(np.zeros(shape, dtype=np.float32))
+        _hip.sia_bwd(y, plan_g, xg, gx, copies, nb, SIA_NOISE, noise=noise_g)
+        assert np.array_equal(gx.numpy(), C.sia_bwd(y.numpy(), plan, x.numpy(), noise.numpy(), nb))
