@@ -300,8 +300,21 @@ def gen_config1():
          seed_images=0, seed_labels=1, seed_weights=0)          # x_u8 = u8_images(16, 224, seed_images)
 
 
+def gen_config2():
+    """BASELINE.json configs[1] in miniature: MI-FGSM on ResNet-50 (seeded init, calibrated BatchNorm), 4 of the
+    synthetic images, eps=16/255, alpha=1.6/255, K=10, by the reference's own class on the CPU."""
+    n = 4
+    xu8 = u8_images(n, 224, 0)
+    label = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1))
+    atk = ref_shim.make_reference_attack("mifgsm", backbones.create("resnet50", seed=0, verbose=False))
+    x = xu8.float() / 255
+    delta = atk(x, label)
+    adv_u8 = ((x + delta).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)          # utils.py:64
+    save("config2_mifgsm_resnet50_n4", label=label, adv_u8=adv_u8, seed_images=0, seed_labels=1, seed_weights=0)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1", "config2"]
     for w in which:
         globals()["gen_" + w]()

@@ -365,3 +365,16 @@ def test_frequency_attacks_with_gemm_dct(golden, monkeypatch):
     torch.manual_seed(1234)
     d = atk(x, label).numpy()
     assert float((d != e["delta_fgsra"]).mean()) <= 0.01
+
+
+def test_config2_miniature_matches_reference(golden, monkeypatch):
+    """BASELINE.json configs[1] in miniature (MI-FGSM, ResNet-50, K = 10, four synthetic images): the product's attack
+    class with the oracle-backed binding writes the bytes the reference's own class wrote."""
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g = golden("config2_mifgsm_resnet50_n4")
+    x = u8_images(4, 224, int(g["seed_images"])).float() / 255
+    model = backbones.create("resnet50", seed=int(g["seed_weights"]), verbose=False)
+    delta = make("mifgsm", models=[model])(x, t(g["label"]))
+    import fgsm_oracle as O
+    assert np.array_equal(O.quantize_u8(x + delta), g["adv_u8"])
