@@ -178,3 +178,40 @@ def test_config2_end_to_end_through_kernels(golden):
     out = quantize_images(x, delta)
     print("configs[1] x4, K = 10: uint8 mismatch vs the reference's golden images %.2f%%"
           % (100 * float((out != g["adv_u8"]).mean())))
+
+
+@pytest.fixture
+def reference_sum_order(monkeypatch):
+    """TA_ATEN_SUM_LANES=8: |g| summed in the order of the AVX2 reference that wrote the goldens"""
+    host_kernels.install(monkeypatch, tag="aten8", env={"TA_ATEN_SUM_LANES": "8"})
+    monkeypatch.setattr(A, "DEV", "cpu")
+
+
+@pytest.mark.parametrize("name", ["mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim", "admix", "dts", "ens"])
+def test_loops_bit_exact_in_reference_sum_order(golden, reference_sum_order, name):
+    """with the one remaining difference removed -- the order in which |g| is added -- the kernels' code reproduces the
+    reference's golden PERTURBATIONS (fp32, not just the uint8 images) bit for bit, momentum attacks included"""
+    from transferattack_amd import backbones
+    g = golden("loops_toy")
+    x, label = A.t(g["x_u8"]).float() / 255, A.t(g["label"])
+    models = [backbones.create("toy_cnn", seed=3, verbose=False)]
+    if name == "ens":
+        models.append(backbones.create("toy_cnn", seed=4, verbose=False))
+    torch.manual_seed(1234)
+    assert np.array_equal(A.make(name, models)(x, label).numpy(), g["delta_" + name])
+
+
+def test_config2_byte_identical_in_reference_sum_order(golden, reference_sum_order):
+    """BASELINE.json configs[1] in miniature (MI-FGSM, ResNet-50, K = 10): end to end through the kernel sources, the
+    images are the reference's golden bytes -- the 14 % of test_config2_end_to_end_through_kernels came from the last bit
+    of sum|g| alone"""
+    from conftest import u8_images
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import quantize_images, wrap_model
+    import transferattack_amd as ta
+    g = golden("config2_mifgsm_resnet50_n4")
+    x = u8_images(4, 224, int(g["seed_images"])).float() / 255
+    model = backbones.create("resnet50", seed=int(g["seed_weights"]), verbose=False)
+    cls = ta.load_attack_class("mifgsm")
+    atk = type("HostMIFGSM", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval())})(model_name="injected")
+    assert np.array_equal(quantize_images(x, atk(x, A.t(g["label"]))), g["adv_u8"])

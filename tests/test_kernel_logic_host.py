@@ -330,3 +330,39 @@ def test_sia_stays_in_bounds(at_end):
         gx = guarded(np.zeros(shape, dtype=np.float32))
         _hip.sia_bwd(y, plan_g, xg, gx, copies, nb, SIA_NOISE, noise=noise_g)
         assert np.array_equal(gx.numpy(), C.sia_bwd(y.numpy(), plan, x.numpy(), noise.numpy(), nb))
+
+
+# ---- opt-in: |g| summed in the reference's (ATen cascade) order -> the momentum carries the reference's bits
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_reference_order_sum(monkeypatch, golden, lanes):
+    from transferattack_amd import _hip
+    host_kernels.install(monkeypatch, tag="aten%d" % lanes, env={"TA_ATEN_SUM_LANES": str(lanes)})
+    gen = torch.Generator().manual_seed(lanes)
+    for shape in ((3, 3, 224, 224), (2, 3, 37, 41), (2, 1, 1, 7), (1, 3, 8, 8), (2, 2, 64, 65), (1, 1, 1, 1)):
+        grad = torch.randn(shape, generator=gen)
+        var = torch.randn(shape, generator=gen) * 0.1
+        n, e = shape[0], grad[0].numel()
+        for v in (None, var):
+            ws = torch.full((int(_hip.load().ta_l1_workspace_floats(n, e)),), float("nan"))
+            rc = _hip.load().ta_abs_sum_partials(grad.data_ptr(), None if v is None else v.data_ptr(), ws.data_ptr(), n, e, None)
+            assert rc == 0
+            tiles = ws.numel() // (2 * n)
+            src = (grad if v is None else grad + v).abs().reshape(n, -1).numpy()
+            for b in range(n):
+                row = ws[b * tiles:(b + 1) * tiles].numpy()
+                assert row[0] == C.aten_row_sum(src[b], lanes) and not row[1:].any()
+    if lanes == 8:                                  # the goldens were written by an AVX2-order reference
+        g = golden("update_stack")
+        grad, mom, delta, x = (torch.from_numpy(g[k]) for k in ("grad", "momentum", "delta", "x"))
+        for tag, decay, first in (("first", 1.0, True), ("d1", 1.0, False), ("d09", 0.9, False), ("d0", 0.0, False)):
+            m = torch.empty_like(grad)
+            _hip.momentum(grad, None if first else mom, m, decay)
+            assert np.array_equal(m.numpy(), g["m_" + tag], equal_nan=True)            # bit for bit, not "close"
+            d, m2 = delta.clone(), torch.empty_like(grad)
+            _hip.mi_update(grad, None if first else mom.clone(), m2, d, x, decay, G.ALPHA, G.EPS)
+            assert np.array_equal(m2.numpy(), g["m_" + tag], equal_nan=True)
+            assert np.array_equal(d.numpy(), g["delta_" + tag])
+
+
+def test_reference_sum_order_gpu_test_on_host(golden, monkeypatch, widened_on_host):
+    W.test_reference_sum_order(golden, monkeypatch)

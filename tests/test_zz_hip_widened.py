@@ -355,3 +355,38 @@ def test_tim_loop_with_separable_smoothing(golden, monkeypatch):
     rate = mismatch(x, delta, g["delta_tim"])
     print("tim (separable smoothing): uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
     assert float(delta.abs().max()) <= EPS + 1e-7 and rate <= max(BOUND, 0.001)
+
+
+# -------------------------------------------------- opt-in: |g| summed in the reference's (ATen cascade) order
+def test_reference_sum_order(golden, monkeypatch):
+    """TA_ATEN_SUM_LANES=8: sum|g| evaluated as ATen's AVX2 cascade (the order of the reference that wrote the goldens)
+    -> g / mean|g|, the momentum and delta equal the reference's tensors BIT FOR BIT, where the default mode is only
+    within the rounding bound of conftest.assert_momentum_close; lanes = 16 reproduces the AVX-512 order of the oracle."""
+    import c_oracle as C
+    from transferattack_amd import _hip
+    g = golden("update_stack")
+    grad, mom, delta, x = (t(g[k]).to(DEV) for k in ("grad", "momentum", "delta", "x"))
+    monkeypatch.setenv("TA_ATEN_SUM_LANES", "8")
+    for tag, decay, first in (("first", 1.0, True), ("d1", 1.0, False), ("d09", 0.9, False), ("d0", 0.0, False)):
+        m = torch.empty_like(grad)
+        _hip.momentum(grad, None if first else mom, m, decay)
+        assert np.array_equal(m.cpu().numpy(), g["m_" + tag], equal_nan=True)
+        d, m2 = delta.clone(), torch.empty_like(grad)
+        _hip.mi_update(grad, None if first else mom.clone(), m2, d, x, decay, 1.6 / 255, EPS)
+        assert np.array_equal(m2.cpu().numpy(), g["m_" + tag], equal_nan=True)
+        assert np.array_equal(d.cpu().numpy(), g["delta_" + tag])
+    gen = torch.Generator().manual_seed(16)
+    for lanes in (8, 16):
+        monkeypatch.setenv("TA_ATEN_SUM_LANES", str(lanes))
+        for shape in ((4, 3, 224, 224), (2, 3, 37, 41), (2, 1, 1, 7)):
+            v = torch.randn(shape, generator=gen)
+            n, e = shape[0], v[0].numel()
+            ws = torch.zeros(int(_hip.load().ta_l1_workspace_floats(n, e)), device=DEV)
+            vd = v.to(DEV)
+            assert _hip.load().ta_abs_sum_partials(vd.data_ptr(), None, ws.data_ptr(), n, e,
+                                                   None if DEV == "cpu" else torch.cuda.current_stream().cuda_stream) == 0
+            tiles = ws.numel() // (2 * n)
+            rows = ws.cpu().numpy()
+            for b in range(n):
+                assert rows[b * tiles] == C.aten_row_sum(v[b].abs().reshape(-1).numpy(), lanes)
+    monkeypatch.delenv("TA_ATEN_SUM_LANES")

@@ -11,6 +11,7 @@
 // Arithmetic is kept in the reference's order with contraction off (-ffp-contract=off):
 //   q = g / (sum|g| / E);  m' = m*decay + q;  d' = d + alpha*sign(m');  d' = min(max(d',-eps),eps);
 //   d' = min(max(d', 0 - x), 1 - x)
+#include <stdlib.h>
 #include "update_common.h"
 
 namespace ta {
@@ -59,6 +60,91 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
     }
     const float total = block_sum(acc, lds);
     if (threadIdx.x == 0) ws[img * tiles + blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 in the REFERENCE's summation order (opt-in, TA_ATEN_SUM_LANES = 8 | 16).
+// grad.abs().mean(dim=(1,2,3)) on the reference's CPU path is ATen's vectorised cascade sum (SumKernel.cpp; restated
+// in oracle/ta_oracle.c: ta_oracle_aten_row_sum): `lanes` SIMD lanes x 4 interleaved accumulators = 4*lanes columns,
+// each column summed in blocks of 16 steps, 16 block sums into a level-1 sum, and so on for 4 levels, then the levels,
+// the 4 accumulators and the lanes folded in a fixed order.  Which `lanes` applies is a property of the CPU the
+// reference runs on (8 = AVX2, 16 = AVX-512).  This kernel evaluates that very expression tree -- every partial sum
+// has the same operands in the same order, only independent subtrees run in parallel -- so sum|g|, hence g / mean|g|,
+// the momentum and every later iterate carry the reference's bits.  One workgroup per image; the result goes to slot 0
+// of the image's partial-sum row and zeros to the other slots, so K2 / the momentum kernel are untouched.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAtenIlp = 4, kAtenLevelPower = 4, kAtenStep = 1 << kAtenLevelPower;
+constexpr int kAtenMaxLdsFloats = 16 * 1024;          // 64 KB of dynamic LDS: level-0 block sums are E / 16 floats (150528 -> 9408)
+
+template <bool HAS_V>
+__global__ __launch_bounds__(kBlock) void aten_order_abs_sum_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                                    float* __restrict__ ws, int64_t e, int tiles,
+                                                                    int lanes) {
+    __shared__ __attribute__((aligned(16))) float aten_lds[kAtenMaxLdsFloats];     // 64 KB; one workgroup per image
+    const int64_t img = blockIdx.x;
+    const float* gi = g + img * e;
+    const float* vi = HAS_V ? v + img * e : nullptr;
+    auto mag = [&](int64_t i) { return fabsf(HAS_V ? gi[i] + vi[i] : gi[i]); };
+    const int cols = lanes * kAtenIlp;
+    const int64_t steps = e / cols;
+    const int nb1 = static_cast<int>(steps >> kAtenLevelPower);                  // full level-0 blocks
+    const int nb2 = nb1 >> kAtenLevelPower, nb3 = nb2 >> kAtenLevelPower;
+    float* s1 = aten_lds;                                // [nb1][cols]
+    float* s2 = s1 + static_cast<int64_t>(nb1) * cols;   // [nb2][cols]
+    float* s3 = s2 + static_cast<int64_t>(nb2) * cols;   // [nb3][cols]
+    float* tot = s3 + static_cast<int64_t>(nb3) * cols;  // [cols]
+    // level 0: 16 consecutive steps of one column, left to right, starting from 0
+    for (int idx = threadIdx.x; idx < nb1 * cols; idx += kBlock) {
+        const int b = idx / cols, c = idx - b * cols;
+        float acc = 0.0f;
+        for (int j = 0; j < kAtenStep; ++j) acc += mag((static_cast<int64_t>(b) * kAtenStep + j) * cols + c);
+        s1[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nb2 * cols; idx += kBlock) {              // level 1: 16 block sums
+        const int d = idx / cols, c = idx - d * cols;
+        float acc = 0.0f;
+        for (int j = 0; j < kAtenStep; ++j) acc += s1[(d * kAtenStep + j) * cols + c];
+        s2[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nb3 * cols; idx += kBlock) {              // level 2
+        const int q = idx / cols, c = idx - q * cols;
+        float acc = 0.0f;
+        for (int j = 0; j < kAtenStep; ++j) acc += s2[(q * kAtenStep + j) * cols + c];
+        s3[idx] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        const int c = threadIdx.x;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int64_t i = static_cast<int64_t>(nb1) * kAtenStep; i < steps; ++i) a0 += mag(i * cols + c);   // steps past the last full block
+        for (int b = nb2 * kAtenStep; b < nb1; ++b) a1 += s1[b * cols + c];      // block sums not yet passed up
+        for (int d = nb3 * kAtenStep; d < nb2; ++d) a2 += s2[d * cols + c];
+        for (int q = 0; q < nb3; ++q) a3 += s3[q * cols + c];                    // the top level is never passed on
+        tot[c] = ((a0 + a1) + a2) + a3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t vec_size = e / lanes;
+        for (int64_t vv = steps * kAtenIlp; vv < vec_size; ++vv)                 // whole vectors beyond the last ILP group
+            for (int l = 0; l < lanes; ++l) tot[l] += mag(vv * lanes + l);
+        for (int k = 1; k < kAtenIlp; ++k)
+            for (int l = 0; l < lanes; ++l) tot[l] += tot[k * lanes + l];
+        float total = 0.0f;
+        for (int64_t i = vec_size * lanes; i < e; ++i) total += mag(i);         // scalar tail first, then the lanes in order
+        for (int l = 0; l < lanes; ++l) total += tot[l];
+        ws[img * tiles] = total;
+        for (int t = 1; t < tiles; ++t) ws[img * tiles + t] = 0.0f;
+    }
+}
+
+// 0 = off (the kernels' own fixed order); 8 / 16 = ATen's cascade order for that SIMD width.  Read at every call (a
+// getenv per launch is noise), so one process can run both modes.
+static int aten_sum_lanes() {
+    const char* env = getenv("TA_ATEN_SUM_LANES");
+    const int value = env == nullptr ? 0 : atoi(env);
+    return (value == 8 || value == 16) ? value : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +428,21 @@ static bool vec_ok(int64_t e, std::initializer_list<const void*> ptrs) {
 static int launch_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e, bool square,
                            hipStream_t st) {
     const int tiles = static_cast<int>(ceil_div(e, kTile));
+    if (const int lanes = square ? 0 : aten_sum_lanes()) {
+        const int cols = lanes * kAtenIlp;
+        const int64_t steps = e / cols, nb1 = steps >> kAtenLevelPower;
+        const int64_t floats = (nb1 + (nb1 >> kAtenLevelPower) + (nb1 >> (2 * kAtenLevelPower)) + 1) * cols;
+        // the cascade uses 16-step levels as long as ceil(log2(steps)) / 4 <= 4, i.e. up to 2^19 steps
+        TA_REQUIRE(floats <= kAtenMaxLdsFloats && steps <= (1ll << 19),
+                   "TA_ATEN_SUM_LANES: images of %lld elements exceed what the reference-order sum stages in LDS", (long long)e);
+        if (v)
+            hipLaunchKernelGGL(aten_order_abs_sum_kernel<true>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, st, g, v, ws,
+                               e, tiles, lanes);
+        else
+            hipLaunchKernelGGL(aten_order_abs_sum_kernel<false>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, st, g, v,
+                               ws, e, tiles, lanes);
+        return check_launch("aten_order_abs_sum");
+    }
     const dim3 grid(tiles, static_cast<unsigned>(n));
     const bool vec = vec_ok(e, {g, v});
 #define TA_K1(VEC, HV, SQ) \
@@ -480,7 +581,7 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
     TA_REQUIRE(g && delta && x && ws, "null pointer");
     TA_REQUIRE(!(partials_ready && v), "partials of |g| cannot be reused when a variance term is added");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!partials_ready)
+    if (!partials_ready || aten_sum_lanes() != 0)            // the reference-order sum is never taken from a producer
         if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
     const int tiles_ws = static_cast<int>(ceil_div(e, kTile));
     const StepParams p{decay, alpha, -eps, eps};
