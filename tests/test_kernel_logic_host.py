@@ -366,3 +366,7 @@ def test_reference_order_sum(monkeypatch, golden, lanes):
 
 def test_reference_sum_order_gpu_test_on_host(golden, monkeypatch, widened_on_host):
     W.test_reference_sum_order(golden, monkeypatch)
+
+
+def test_dct_forms_gpu_test_on_host(monkeypatch, widened_on_host):
+    W.test_dct_forms_agree_on_device(monkeypatch)

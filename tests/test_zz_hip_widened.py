@@ -390,3 +390,19 @@ def test_reference_sum_order(golden, monkeypatch):
             for b in range(n):
                 assert rows[b * tiles] == C.aten_row_sum(v[b].abs().reshape(-1).numpy(), lanes)
     monkeypatch.delenv("TA_ATEN_SUM_LANES")
+
+
+def test_dct_forms_agree_on_device(monkeypatch):
+    """the rocFFT (Makhoul) form and the opt-in dense-matrix form (TA_DCT_GEMM=1, rocBLAS) of the DCT pair shared by
+    FGSRA and SSM are the same transform on the device, up to fp32 rounding"""
+    from transferattack_amd.spectrum import MakhoulDct
+    fft = MakhoulDct()
+    monkeypatch.setenv("TA_DCT_GEMM", "1")
+    gemm = MakhoulDct()
+    gen = torch.Generator().manual_seed(3)
+    for shape in ((4, 3, 224, 224), (1, 2, 7, 10)):
+        x = torch.rand(shape, generator=gen).to(DEV)
+        a, b = fft.dct_2d(x), gemm.dct_2d(x)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        assert float((gemm.idct_2d(a) - fft.idct_2d(a)).abs().max()) <= 1e-4 * float(x.abs().max())
+        assert float((gemm.idct_2d(gemm.dct_2d(x)) - x).abs().max()) <= 1e-4
