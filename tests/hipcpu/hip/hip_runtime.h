@@ -21,7 +21,11 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#ifdef HIPCPU_SINGLE_WORKER               /* sanitizer build: plain statics (instrumented), one worker thread */
+#define __shared__ static
+#else
 #define __shared__ static thread_local    /* `extern __shared__` is rewritten to `extern thread_local` by hipcpu_build.py */
+#endif
 
 struct dim3 {
     unsigned x, y, z;

@@ -7,6 +7,10 @@
 #include <vector>
 #include "hip/hip_runtime.h"
 
+#ifdef HIPCPU_SINGLE_WORKER
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+
 #if !defined(__x86_64__)
 #error "tests/hipcpu switches fibers with a few lines of x86-64 assembly (the build container and the GPU boxes are x86-64)"
 #endif
@@ -188,6 +192,9 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     const uint64_t groups = static_cast<uint64_t>(grid.x) * grid.y * grid.z;
     unsigned pool = std::thread::hardware_concurrency();
     if (pool == 0) pool = 1;
+#ifdef HIPCPU_SINGLE_WORKER
+    pool = 1;                                             // `__shared__` arrays are process-wide statics in this build
+#endif
     if (pool > groups) pool = static_cast<unsigned>(groups);
     std::atomic<uint64_t> next{0};
     auto work = [&]() {
@@ -206,6 +213,9 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
             run_workgroup(&w, lanes);
         }
         worker = nullptr;
+#ifdef HIPCPU_SINGLE_WORKER
+        __asan_unpoison_memory_region(w.stacks, kStackBytes * lanes);    // fibers leave stack red zones in the shadow
+#endif
         munmap(w.stacks, kStackBytes * lanes);
     };
     std::vector<std::thread> threads;

@@ -15,7 +15,7 @@ _DYNAMIC_LDS = {"dim.hip": [("char", "smem_raw")], "tim.hip": [("float", "smem")
 
 
 def _host_text(text):
-    text = text.replace("extern __shared__", "extern thread_local")
+    text = text.replace("extern __shared__", "extern" if SANITIZE else "extern thread_local")
     text = text.replace('#include "../../include/ta_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "ta_hip.h"))
     # clang's ext_vector_type has no g++ counterpart with .x/.y members
     text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
@@ -26,10 +26,19 @@ def _host_text(text):
 HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip")     # not fused_update.hip
 
 
+# HIPCPU_SANITIZE=1: AddressSanitizer build (one worker thread, `__shared__` arrays as plain statics).  Every load /
+# store of a kernel to a tensor (torch / numpy heap blocks carry ASan red zones) is checked to the byte -- finer than the
+# guard-page tests.  The LDS arrays of TEMPLATE kernels are COMDAT statics, which ASan does not instrument, so an LDS
+# index out of range is still only caught through wrong results.  Run as
+#   LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+#   HIPCPU_SANITIZE=1 python -m pytest tests/test_kernel_logic_host.py
+SANITIZE = os.environ.get("HIPCPU_SANITIZE", "0") == "1"
+
+
 def build():
     """-> path of libta_host.so: the kernel sources of csrc compiled for the host; rebuilt when a source is newer."""
     os.makedirs(OUT, exist_ok=True)
-    lib = os.path.join(OUT, "libta_host.so")
+    lib = os.path.join(OUT, "libta_host_asan.so" if SANITIZE else "libta_host.so")
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
     sources = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     deps = sources + headers + [os.path.join(HERE, "hipcpu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), __file__]
@@ -42,12 +51,14 @@ def build():
             name = os.path.basename(src)
             text = _host_text(open(src).read())
             for ctype, var in _DYNAMIC_LDS.get(name, []):
-                text += "\nnamespace ta { thread_local __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (ctype, var, ctype)
+                text += "\nnamespace ta { %s __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (
+                    "" if SANITIZE else "thread_local", ctype, var, ctype)
             generated.append(os.path.join(OUT, os.path.splitext(name)[0] + "_host.cpp"))
             with open(generated[-1], "w") as fh:
                 fh.write(text)
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread",
-               "-Wno-attributes", "-Wno-unknown-pragmas", "-I", HERE, "-I", OUT] + generated + [
+        extra = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-DHIPCPU_SINGLE_WORKER"] if SANITIZE else []
+        cmd = ["g++", "-O1" if SANITIZE else "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+               "-pthread", "-Wno-attributes", "-Wno-unknown-pragmas", "-I", HERE, "-I", OUT] + extra + generated + [
                os.path.join(HERE, "hipcpu.cpp"), "-o", lib]
         subprocess.run(cmd, check=True, capture_output=True, text=True)
     return lib
