@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the FGSM-family hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 without a launcher: this process re-launches itself as N ranks (torch.distributed.run, one per GPU,
+        backend nccl = RCCL, rendezvous on 127.0.0.1) and fails loudly if fewer than N HIP devices are visible;
+        under torch.distributed.run (RANK / WORLD_SIZE set): it is one of those ranks.
 
 Workload (BASELINE.json configs[1]): MI-FGSM on ResNet-50, eps=16/255, alpha=1.6/255, K=10 iterations,
 synthetic 3x224x224 images.  One "step" = one batch of 125 images (1000/8: the per-GPU shard of the 1000-image
@@ -13,12 +16,16 @@ Inputs are resident in HBM before the timed region; the surrogate is the ResNet-
 random weights (no checkpoints offline); arithmetic is fp32 throughout, as in the reference.
 
 Multi-GPU: the 1000-image job shards by whole batches, no data-path collective: every rank runs
-its own K steps ("weak" scaling); value = images of all ranks / max-over-ranks time.
+its own K steps ("weak" scaling); value = images of all ranks / max-over-ranks time.  ``--attack ens --model a,b,c,d``
+on N = k*4 GPUs puts one surrogate per rank of a 4-rank model group (configs[4]): the two all-reduces of the ensemble
+path (logits forward, input gradient backward) run over RCCL, images shard over the k groups.
 
 One JSON line on rank 0, with
-  roofline      the fused momentum-sign-project update (ta_mi_update): algorithmic bytes 24 B/element
-                (read g, m, delta, x; write m, delta) x E x N per launch / mean launch duration measured with
-                HIP events on the launch stream inside the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+  roofline      the fused momentum-sign-project update (ta_mi_update): algorithmic bytes of every launch -- 4 B/element
+                per operand it actually moves: read g, m, delta, x, write m, delta = 24; first iteration (no momentum
+                yet) 20; +4 when it also writes x + delta for the next iteration -- summed over the launches / summed
+                launch durations, measured with HIP events on the launch stream inside the timed region; peak
+                8 TB/s (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).
   cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores,
                 same surrogate / workload, bounded sample.
 """
@@ -50,7 +57,6 @@ def parse():
     p.add_argument("--fold-bn", type=int, default=1,
                    help="fold the surrogate's eval-mode BatchNorm into its convolutions (algebraically exact)")
     p.add_argument("--channels-last", type=int, default=1, help="run the surrogate in NHWC memory format")
-    p.add_argument("--single-launch", type=int, default=int(os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0")))
     p.add_argument("--cpu-images", type=int, default=8, help="images of the CPU-baseline sample (0 = skip)")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
     p.add_argument("--kernel-times", type=int, default=0,
@@ -65,9 +71,9 @@ def synthetic_batch(n, seed):
     return x, y
 
 
-def kernel_sweep(single_flags=(0, 1), sizes=(32, 125, 250), reps=30):
-    """Stand-alone timing of the fused update at several batch sizes (operands rotate through 4 buffer sets,
-    ~0.3-2.4 GB, so the 256 MiB Infinity Cache cannot hold them)."""
+def kernel_sweep(sizes=(32, 125, 250), reps=30):
+    """Stand-alone timing of the fused update (K1 + K2: no producer has left |g| sums) at several batch sizes; operands
+    rotate through 4 buffer sets, ~0.3-2.4 GB, so the 256 MiB Infinity Cache cannot hold them."""
     from transferattack_amd import _hip
     out = {}
     e = 3 * 224 * 224
@@ -76,21 +82,19 @@ def kernel_sweep(single_flags=(0, 1), sizes=(32, 125, 250), reps=30):
         for k in range(4):
             g = torch.randn(n, 3, 224, 224, device="cuda") * 1e-4
             sets.append((g, torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g)))
-        for single in single_flags:
-            for i in range(5):
-                g, m, d, x = sets[i % 4]
-                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, single_launch=bool(single))
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            start.record()
-            for i in range(reps):
-                g, m, d, x = sets[i % 4]
-                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, single_launch=bool(single))
-            end.record()
-            torch.cuda.synchronize()
-            us = start.elapsed_time(end) * 1e3 / reps
-            out["n%d_%s" % (n, "single" if single else "two")] = {
-                "us": round(us, 2), "GBps": round(BYTES_PER_ELEM * e * n / us / 1e3, 1)}
+        for i in range(5):
+            g, m, d, x = sets[i % 4]
+            _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        start.record()
+        for i in range(reps):
+            g, m, d, x = sets[i % 4]
+            _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255)
+        end.record()
+        torch.cuda.synchronize()
+        us = start.elapsed_time(end) * 1e3 / reps
+        out["n%d_k1_k2" % n] = {"us": round(us, 2), "GBps": round(BYTES_PER_ELEM * e * n / us / 1e3, 1)}
         del sets
     return out
 
@@ -103,6 +107,7 @@ KERNEL_BYTES = {
     "momentum": lambda g, m_in, m_out, *a, **k: _NB(g) * (2 if m_in is None else 3),
     "update_delta_linf": lambda d, x, m, *a, **k: 4 * _NB(d),
     "depthwise_conv2d_same": lambda inp, out, w: _NB(inp) + _NB(out),
+    "sum_members": lambda grads, gx: _NB(gx) * (len(grads) + 1),
     "dim_fwd": lambda x, y, *a: _NB(x) + _NB(y),
     "dim_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
     "scale_copies_fwd": lambda x, y, *a: _NB(x) + _NB(y),
@@ -155,30 +160,47 @@ def summarise_kernels(records):
 
 
 def cpu_baseline(args):
-    """Oracle = the reference's ATen CPU arithmetic (oracle/fgsm_oracle.py), timed on this host's cores on a
-    bounded sample: ``cpu_images`` images x ``CPU_ITERS`` of the K=10 iterations (every iteration costs the same:
-    one surrogate forward/backward + the 13-kernel update stack), scaled to K=10."""
+    """The reference's CPU path on this host's cores, on a bounded sample: ``cpu_images`` images x ``CPU_ITERS`` of the
+    K=10 iterations (every iteration costs the same: one surrogate forward/backward + the 13-kernel update stack),
+    scaled to K=10.  kind "reference": the reference's OWN ``Attack.forward`` (imported from /root/reference through
+    oracle/ref_shim.py -- only where that tree exists, i.e. the build container); kind "port": the oracle
+    (oracle/fgsm_oracle.py, the same ATen ops in the same order) -- what runs on the GPU box."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fgsm_oracle as O
+    import ref_shim
     from transferattack_amd import backbones
     cpu_iters = 3
     cores = os.cpu_count() or 1
     model = backbones.create(args.model, seed=0, verbose=False)
     x, y = synthetic_batch(args.cpu_images, 0)
+    kind = "port"
+    run = lambda epoch: O.run_attack(args.attack, model, x, y, epoch=epoch)          # noqa: E731
+    if ref_shim.reference_available():
+        try:
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                ref_attack = ref_shim.make_reference_attack(args.attack, model)
+
+            def run(epoch):                                                          # noqa: F811
+                ref_attack.epoch = epoch
+                return ref_attack(x, y)
+            kind = "reference"
+        except Exception as exc:  # noqa: BLE001
+            print("reference attack class unavailable (%r): timing the oracle port" % (exc,), file=sys.stderr)
     # give the CPU path its best thread count (on a 2-socket host the default of one thread per core is far from
     # the fastest for an 8-image batch): probe a few counts on one iteration, keep the quickest
     default_threads = torch.get_num_threads()
     best = (float("inf"), default_threads)
     for th in sorted({min(t, default_threads) for t in (8, 16, 32, 64, default_threads)}):
         torch.set_num_threads(th)
-        O.run_attack(args.attack, model, x, y, epoch=1)                # warm-up at this count
+        run(1)                                                         # warm-up at this count
         t0 = time.time()
-        O.run_attack(args.attack, model, x, y, epoch=1)
+        run(1)
         best = min(best, (time.time() - t0, th))
     threads = best[1]
     torch.set_num_threads(threads)
     t0 = time.time()
-    O.run_attack(args.attack, model, x, y, epoch=cpu_iters)
+    run(cpu_iters)
     dt = (time.time() - t0) / cpu_iters * 10
     # update stack alone (get_momentum + update_delta), the reference's op string, N = 32
     n = 32
@@ -192,20 +214,43 @@ def cpu_baseline(args):
         mm = O.momentum_step(g, m, 1.0)
         O.delta_step(d, xx, mm, 1.6 / 255, 16 / 255)
     upd_ms = (time.time() - t1) / 5 * 1e3
-    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": threads, "kind": kind,
             "sample": "%d synthetic images, %s on %s, %d of the K=10 iterations timed and scaled to 10, torch CPU "
-                      "with %d threads on a %d-hw-thread host (oracle/fgsm_oracle.py)" % (
-                          args.cpu_images, args.attack, args.model, cpu_iters, threads, cores),
+                      "with %d threads on a %d-hw-thread host (%s)" % (
+                          args.cpu_images, args.attack, args.model, cpu_iters, threads, cores,
+                          "the reference's own Attack.forward via oracle/ref_shim.py" if kind == "reference"
+                          else "oracle/fgsm_oracle.py; /root/reference is not present on this host"),
             "update_stack_ms_n32": round(upd_ms, 3),
             "update_stack_GBps_n32": round(BYTES_PER_ELEM * 150528 * n / upd_ms / 1e6, 2)}
 
 
+def launch_ranks(args):
+    """``--gpus N`` without a launcher: start N ranks of this script (one process per GPU) and wait for them."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        sys.exit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, visible))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting what actually runs" % (args.gpus, world),
+              file=sys.stderr)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -216,18 +261,24 @@ def main():
     os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
     import transferattack_amd as ta
     from transferattack_amd import _hip
-    from transferattack_amd.attack import Attack
+    from transferattack_amd import dist as tadist
     _hip.load()
     torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
-    Attack.single_launch_update = bool(args.single_launch)
     model_name = args.model.split(",") if "," in args.model else args.model      # list -> EnsembleModel, as main.py:39-40
     import contextlib
+    shard_rank, shard_world, layout = rank, world, "image-shard x%d, no collective" % world
     with contextlib.redirect_stdout(sys.stderr):              # stdout carries exactly one line: the JSON result
-        attacker = ta.load_attack_class(args.attack)(model_name=model_name)
+        cls = ta.load_attack_class(args.attack)
+        if isinstance(model_name, list) and world > 1 and world % len(model_name) == 0:
+            attacker, member, shard_rank, shard_world = tadist.sharded_attack(cls, args.attack, model_name, world)
+            layout = "%d image shard(s) x %d model ranks (one surrogate per rank; RCCL all-reduce of logits and input " \
+                     "gradients)" % (shard_world, len(model_name))
+        else:
+            attacker = cls(model_name=model_name)
     dev = attacker.device
 
     total = args.steps + args.warmup
-    batches = [tuple(t.to(dev) for t in synthetic_batch(args.batch, 1000 * rank + 2 * i)) for i in range(min(total, 4))]
+    batches = [tuple(t.to(dev) for t in synthetic_batch(args.batch, 1000 * shard_rank + 2 * i)) for i in range(min(total, 4))]
 
     def step(i):
         x, y = batches[i % len(batches)]
@@ -240,25 +291,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _hip.profile_sink = []
+    _hip.stats["partials_reused"] = _hip.stats["k1_passes"] = 0
     kernel_records, restore_kernels = (instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
                                        if args.kernel_times else ({}, lambda: None))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sink, _hip.profile_sink = _hip.profile_sink, None
     restore_kernels()
+    per_rank = [round(args.steps * args.batch / mine, 2)]
+    observed_world, backend = 1, "none (single process)"
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        rates = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([per_rank[0]], device=dev, dtype=torch.float64))
+        per_rank = [round(float(r.item()), 2) for r in rates]
+        observed_world, backend = dist.get_world_size(), dist.get_backend()
 
     if rank == 0:
-        images = args.steps * args.batch * world
+        images = args.steps * args.batch * shard_world
         if not sink:        # attacks that call the two hooks separately (VMI): time the fused pair stand-alone
             x0 = batches[0][0]
             g0, m0, d0 = torch.randn_like(x0) * 1e-4, torch.randn_like(x0), torch.zeros_like(x0)
@@ -267,15 +326,22 @@ def main():
                 _hip.mi_update(g0, m0, m0, d0, x0, 1.0, 1.6 / 255, 16 / 255)
             torch.cuda.synchronize()
             _hip.profile_sink = None
-        durs_us = [s.elapsed_time(e) * 1e3 for s, e, _, _ in sink]
+        durs_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
+        launch_bytes = [n_ * e_ * b_ for _, _, n_, e_, b_ in sink]
         n_, e_ = sink[0][2], sink[0][3]
         mean_us = sum(durs_us) / len(durs_us)
-        achieved = BYTES_PER_ELEM * e_ * n_ / mean_us / 1e3          # GB/s
+        mean_bytes = sum(launch_bytes) / len(launch_bytes)
+        achieved = sum(launch_bytes) / sum(durs_us) / 1e3            # GB/s over the launches of the timed region
+        full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")
         if os.path.isfile(pmc_path):            # HBM bytes per launch from the committed rocprofv3 PMC passes
             pmc = json.load(open(pmc_path))
-            per_elem = pmc["mi_update_kernel"]["fetch_B_per_elem_corrected"] + pmc["mi_update_kernel"]["write_B_per_elem"]
+            k2 = pmc["mi_update_kernel"]
+            per_elem = k2["fetch_B_per_elem_corrected"] + k2["write_B_per_elem"]
+            # the counters were taken on the steady-state launch shape; scale to the mean algorithmic bytes of the loop's
+            # launches (first-iteration launches move one operand less)
+            per_elem *= mean_bytes / (n_ * e_) / k2.get("algorithmic_B_per_elem", BYTES_PER_ELEM)
             if _hip.stats["k1_passes"] > 0:
                 per_elem += pmc["abs_sum_partials_kernel"]["fetch_B_per_elem_corrected"]
             traffic = int(per_elem * e_ * n_)
@@ -288,20 +354,24 @@ def main():
                        "images_per_step": args.batch,
                        "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
                        "workload": "%s on %s (seeded random init), eps=16/255, alpha=1.6/255, K=10, synthetic "
-                                   "3x224x224, batches of %d, image-sharded over %d GPU(s)"
+                                   "3x224x224, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
-                                      args.batch, world),
+                                      args.batch, layout),
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
-                       "update_path": "single-launch" if args.single_launch else "two-launch",
-                       "parallelism": "image-shard x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": ("ta_mi_update_fused" if args.single_launch else
-                                    "ta_mi_update (mi_update_kernel; |g| tile sums produced by ta_normalize_bwd)"
-                                    if _hip.stats["k1_passes"] == 0 else
-                                    "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                       "parallelism": layout, "gpus_requested": args.gpus, "ranks_observed": observed_world,
+                       "collective_backend": backend, "images_per_s_per_rank": per_rank},
+            "roofline": {"bound": "hbm", "kernel": ("ta_mi_update (mi_update_kernel; |g| tile sums left by the kernel "
+                                                    "that produced g)" if _hip.stats["k1_passes"] == 0 else
+                                                    "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
-                         "algorithmic_bytes_per_launch": BYTES_PER_ELEM * e_ * n_,
+                         "algorithmic_bytes_per_launch": int(mean_bytes),
+                         "steady_state_launch": {"bytes": int(max(launch_bytes)),
+                                                 "mean_us": round(sum(d for d, _ in full) / len(full), 2),
+                                                 "GBps": round(sum(b for _, b in full) / sum(d for d, _ in full) / 1e3, 1)},
                          "k1_pass_skipped_launches": _hip.stats["partials_reused"],
+                         "k1_passes": _hip.stats["k1_passes"],
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
         }
         if kernel_records:

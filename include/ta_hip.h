@@ -26,13 +26,21 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 4
+#define TA_ABI_VERSION 5
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
 const char* ta_last_error(void);
 /* number of floats of scratch the l1-mean reduction needs for an (n, e) batch (>= n*ceil(e/3072)) */
 int64_t ta_l1_workspace_floats(int64_t n, int64_t e);
+/* |g| tile sums ("partials"): K1 and every elementwise producer below cut an image of e elements into
+ * ta_update_tiles(e) = ceil(e/3072) tiles and write one fp32 sum of |.| per tile, ws[img*S + tile].  The tile kernels
+ * (TIM convolution, DIM backward) write one sum per workgroup tile: ws[plane*T + tile], T = ta_conv_tiles(h, w) /
+ * ta_dim_bwd_tiles(size, resize), i.e. C*T consecutive sums per image.  ta_mi_update takes either layout through
+ * `ws_slots` = sums per image.  All sums are in a fixed order (no atomics). */
+int64_t ta_update_tiles(int64_t e);
+int64_t ta_conv_tiles(int h, int w);
+int64_t ta_dim_bwd_tiles(int size, int resize);
 
 /* ---- update stack ------------------------------------------------------------------------------
  * Attack.get_momentum  transferattack/attack.py:124-128   m <- m*decay + g / mean_{CHW}|g|
@@ -55,11 +63,15 @@ int ta_update_delta_linf(const float* delta_in, const float* x, const float* m, 
 int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, float alpha, float eps,
                        float* delta_out, float* ws, int64_t n, int64_t e, void* stream);
 /* fused get_momentum + update_delta (the headline kernel): reads g,(v),m,d,x  writes m,d,(x_adv).
- * 24 B/element algorithmic traffic (16 when m_in==NULL && m_out==NULL, the decay=0 / FGSM case).
- * partials_ready != 0: ws already holds the |g| tile sums (written by ta_normalize_bwd, the producer of g),
- * so the K1 pass over g is skipped and g is read exactly once. */
+ * 24 B/element algorithmic traffic; 20 on the first iteration (m_in==NULL); 16 when m_in==NULL && m_out==NULL (the
+ * decay=0 / FGSM / I-FGSM case: the momentum is never stored); +4 when x_adv (= x + d', the next iteration's input,
+ * attack.py:88) is written.
+ * ws_slots == 0: K1 runs first (ws = scratch of ta_l1_workspace_floats(n, e) floats).
+ * ws_slots  > 0: ws already holds ws_slots sums of |g| per image, written by the kernel that produced g
+ * (ta_normalize_bwd, ta_depthwise_conv2d_same, ta_dim_bwd, ta_scale_copies_bwd, ta_admix_bwd, ta_sum_copies_bwd,
+ * ta_sum_members), so the K1 pass over g is skipped and g is read exactly once. */
 int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                 const float* x, float* x_adv, float* ws, int partials_ready, float decay, float alpha,
+                 const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
                  float eps, int64_t n, int64_t e, void* stream);
 /* PreprocessingModel's Normalize (transferattack/utils.py:72-79, torchvision Normalize): y = (x - mean[c]) / std[c]
  * over [n, c, hw]; mean/std: device fp32 [c].  Backward gx = gy / std[c] (the last kernel of the surrogate's
@@ -68,16 +80,6 @@ int ta_normalize_fwd(const float* x, float* y, const float* mean, const float* s
                      int64_t hw, void* stream);
 int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int64_t hw,
                      void* stream);
-/* same arithmetic, single launch: the |g| partial sums are exchanged between the workgroups of an
- * image inside the kernel (agent-scope granules) so g is read from HBM exactly once.
- * `sync_ws` = ta_fused_sync_bytes(n, e) bytes, zeroed once by the caller when (n, e) changes. */
-int64_t ta_fused_sync_bytes(int64_t n, int64_t e);
-int ta_mi_update_fused(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                       const float* x, float* x_adv, void* sync_ws, float decay, float alpha,
-                       float eps, int64_t n, int64_t e, void* stream);
-/* host-synchronous check (and reset) of the exchange's sticky timeout word; 0 = no timeout so far */
-int ta_fused_sync_error(void* sync_ws, int64_t n, int64_t e, void* stream);
-
 /* Attack.init_delta random start (attack.py:133-141, linfty): d <- box(U(-eps,eps)); counter-based
  * Philox4x32-10 keyed by (seed, offset); noise (nullable) overrides the draw with caller noise */
 int ta_init_delta_uniform(float* delta, const float* x, const float* noise, float eps, uint64_t seed,
@@ -86,24 +88,19 @@ int ta_init_delta_uniform(float* delta, const float* x, const float* noise, floa
 /* ---- TIM: TIM.get_grad  input_transformation/tim.py:72-74 ------------------------------------------
  * depthwise k x k 'same' zero-padded correlation of every (n,c) plane with ONE k x k kernel `w`
  * (device pointer, k*k fp32, row-major).  Tap order is row-major FMA chain == the reference CPU path.
- * k <= 31; in and out must not alias.
+ * k <= 31; in and out must not alias.  ws (nullable): |out| sums, ta_conv_tiles(h, w_) per plane (TIM.get_grad is the
+ * last kernel that writes the gradient the update consumes).
  */
-int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, int k, int64_t planes,
+int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, float* ws, int k, int64_t planes,
                              int h, int w_, void* stream);
-/* Opt-in, NOT the reference's arithmetic: the same smoothing for a kernel that is an outer product wy (x) wx (all of
- * tim.py:42-66's kernel types are), evaluated as two 1-D ascending FMA chains -- t = sum_kx wx[kx]*in[y][x+kx-lo], then
- * out = sum_ky wy[ky]*t[y+ky-lo][x] -- 2k taps instead of k*k.  Differs from ta_depthwise_conv2d_same by rounding only
- * (~1e-7 relative); k in {3, 5, 7, 15}; wy, wx: device fp32 [k]. */
-int ta_depthwise_conv2d_same_separable(const float* in, float* out, const float* wy, const float* wx, int k,
-                                       int64_t planes, int h, int w, void* stream);
-
 /* ---- DIM: DIM.transform  input_transformation/dim.py:42-68 ----------------------------------------
  * y = bilinear(pad0(bilinear(x, rnd), resize, top, left), size); one geometry for the whole call.
- * fwd: x[planes,size,size] -> y[planes,size,size];  bwd: gy -> gx (exact adjoint, gather form).
+ * fwd: x[planes,size,size] -> y[planes,size,size];  bwd: gy -> gx (exact adjoint, gather form);
+ * ws (nullable): |gx| sums, ta_dim_bwd_tiles(size, resize) per plane.
  */
 int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top,
                int left, void* stream);
-int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize, int rnd, int top,
+int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
                int left, void* stream);
 
 /* ---- SIM / Admix: sim.py:36-40, admix.py:40-45 ------------------------------------------------------
@@ -111,16 +108,20 @@ int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize,
  * sim bwd : gx[b] = sum_i gy[i*n + b] / 2^i                      (i descending = autograd's order)
  * admix fwd: y[(i*num_admix + j)*n + b] = (x[b] + strength * x[perm[j*n + b]]) / 2^i
  * admix bwd: gx[b] = sum_j (sum_i gy[(i*num_admix + j)*n + b] / 2^i)  j, i descending (detached mix term)
- * perm: device int64 [num_admix*n].
+ * perm: device int64 [num_admix*n].  ws (nullable) of the backward kernels: |gx| sums, ta_update_tiles(e) per image.
  */
 int ta_scale_copies_fwd(const float* x, float* y, int64_t n, int64_t e, int num_scale, void* stream);
-int ta_scale_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_scale, void* stream);
+int ta_scale_copies_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int num_scale, void* stream);
 /* gx[b] = sum_i gy[i*n + b], i descending: backward of EMI-FGSM's stack of x + c_i*alpha*g_bar (emifgsm.py:57-58) */
-int ta_sum_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int copies, void* stream);
+int ta_sum_copies_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int copies, void* stream);
 int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
                  int num_scale, float strength, void* stream);
-int ta_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale,
+int ta_admix_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int num_admix, int num_scale,
                  void* stream);
+/* EnsembleModel.forward feeds the same x to every member (utils.py:98-99); autograd then adds the members' input
+ * gradients as they arrive, last member first: gx = ((g[m-1] + g[m-2]) + ...) + g[0].  One kernel instead of m-1 ATen
+ * adds; `gs`: HOST array of m <= 8 device pointers, each [n, e]; ws (nullable): |gx| sums, ta_update_tiles(e) per image. */
+int ta_sum_members(const float* const* gs, int m, float* gx, float* ws, int64_t n, int64_t e, void* stream);
 
 /* ---- SIA block transform: SIA.blocktransform / transform  input_transformation/sia.py:41-100 -------------
  * Every copy of the batch is cut into nb x nb rectangles; each gets one operation: 0 roll rows, 1 roll columns,

@@ -77,24 +77,11 @@ def main():
             args.model = args.model.split(',')
         shard_rank, shard_world = rank, world
         if isinstance(args.model, list) and world >= len(args.model) and world % len(args.model) == 0 and world > 1:
-            # one surrogate per rank of a model group (RCCL logit / gradient all-reduce for ENS, per-member broadcast
-            # for the attacks that address single members), image shards across groups
-            grp, member, shard_rank, shard_world = tadist.model_groups(world, len(args.model))
-            cls = transferattack.load_attack_class(args.attack)
-            name = args.model[member]
-
-            first = shard_rank * len(args.model)
-            group_ranks = list(range(first, first + len(args.model)))
-            per_member = args.attack in ('svre', 'cwa', 'adaea', 'smer')     # these index self.model.models[k]
-
-            class Sharded(cls):
-                def load_model(self, model_name):
-                    local = super().load_model(name)
-                    if per_member:
-                        return tadist.ShardedMembers(local, member, grp, group_ranks)
-                    return tadist.ShardedEnsemble(local, grp, len(args.model))
-
-            attacker = Sharded(model_name=args.model if per_member else name, targeted=args.targeted)
+            # one surrogate per rank of a model group (RCCL logit / gradient all-reduce inside ShardedEnsemble.forward for
+            # every attack class; per-member broadcast for the attacks that address single members), image shards
+            # across groups
+            attacker, member, shard_rank, shard_world = tadist.sharded_attack(
+                transferattack.load_attack_class(args.attack), args.attack, args.model, world, targeted=args.targeted)
             writer = member == 0
         else:
             attacker = transferattack.load_attack_class(args.attack)(model_name=args.model, targeted=args.targeted)

@@ -87,19 +87,6 @@ def depthwise_conv2d_same(x, w2d):
     return out
 
 
-def depthwise_conv2d_same_separable(x, wy, wx):
-    """the opt-in two-pass smoothing's own arithmetic (not a reference op; see ta_oracle.c)"""
-    x, px = _f(x)
-    wy, py = _f(wy)
-    wx, pwx = _f(wx)
-    h, wd = x.shape[-2:]
-    planes = x.size // (h * wd)
-    out = np.empty_like(x)
-    lib().ta_oracle_depthwise_conv2d_same_separable(px, out.ctypes.data_as(_f32p), py, pwx, wy.size, ctypes.c_int64(planes),
-                                                    h, wd)
-    return out
-
-
 def bilinear_fwd(x, out_size):
     x, px = _f(x)
     size = x.shape[-1]

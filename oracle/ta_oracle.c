@@ -334,39 +334,6 @@ void ta_oracle_variance_finalize(const float* acc, const float* cur, float* var,
     for (int64_t i = 0; i < numel; ++i) var[i] = acc[i] / count - cur[i];
 }
 
-/* Test infrastructure for the OPT-IN separable smoothing (ta_depthwise_conv2d_same_separable): two 1-D ascending FMA
- * chains over the zero-padded input.  Not a restatement of a reference op -- the reference evaluates the 2-D kernel
- * directly (ta_oracle_depthwise_conv2d_same above); this pins the kernel's own arithmetic, and the tests bound its
- * distance from the direct form. */
-void ta_oracle_depthwise_conv2d_same_separable(const float* in, float* out, const float* wy, const float* wx, int k,
-                                               int64_t planes, int h, int wd) {
-    const int lo = (k - 1) / 2;
-    float* t = (float*)malloc(sizeof(float) * (size_t)h * wd);
-    for (int64_t p = 0; p < planes; ++p) {
-        const float* ip = in + p * (int64_t)h * wd;
-        float* op = out + p * (int64_t)h * wd;
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < wd; ++x) {
-                float acc = 0.0f;
-                for (int kx = 0; kx < k; ++kx) {
-                    const int xx = x + kx - lo;
-                    acc = fmaf(wx[kx], (xx >= 0 && xx < wd) ? ip[y * wd + xx] : 0.0f, acc);
-                }
-                t[y * wd + x] = acc;
-            }
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < wd; ++x) {
-                float acc = 0.0f;
-                for (int ky = 0; ky < k; ++ky) {
-                    const int yy = y + ky - lo;
-                    acc = fmaf(wy[ky], (yy >= 0 && yy < h) ? t[yy * wd + x] : 0.0f, acc);
-                }
-                op[y * wd + x] = acc;
-            }
-    }
-    free(t);
-}
-
 /* ------------------------------------------------------------------------------------------------
  * SIA block transform, transferattack/input_transformation/sia.py:41-100, from the int32 plan table the product draws
  * (per copy: rows[nb+1], cols[nb+1], then per rectangle -- rows outer -- op, roll step, scale bits):

@@ -38,8 +38,7 @@ def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
     delta_out.copy_(O.delta_step(delta_in, data, grad, alpha, epsilon, norm="l2"))
 
 
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None,
-              single_launch=False):
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None):
     calls.append("mi_update")
     g = grad if variance is None else grad + variance
     m = O.momentum_step(g, 0 if momentum_in is None else momentum_in, decay)
@@ -151,9 +150,12 @@ def quantize_u8_nhwc(data, delta, out):
     out.copy_(_t(O.quantize_u8(data + delta)))
 
 
-def depthwise_conv2d_same_separable(inp, out, wy, wx):
-    calls.append("depthwise_conv2d_same_separable")
-    out.copy_(_t(C.depthwise_conv2d_same_separable(inp.numpy(), wy.numpy(), wx.numpy())))
+def sum_members(grads, gx):
+    calls.append("sum_members")
+    acc = grads[-1].clone()
+    for g in reversed(grads[:-1]):
+        acc = acc + g
+    gx.copy_(acc)
 
 
 def _sia_plans(plan, num_block, n, noise):
@@ -190,7 +192,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
         gx.copy_(torch.autograd.grad(y, xin, gy)[0])
 
 
-_NAMES = ["sia_fwd", "sia_bwd", "depthwise_conv2d_same_separable", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+_NAMES = ["sia_fwd", "sia_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd"]

@@ -40,16 +40,19 @@ def _ptr(t, dtype=torch.float32, name="tensor"):
 
 
 def install(monkeypatch, tag=None, env=None):
-    """``env``: knobs the library reads once (TA_TIM_VARIANT, TA_DIM_FWD_VARIANT); give each setting its own ``tag``."""
+    """``env``: environment knobs for the duration of the test; ``tag``: a private copy of the library (own statics)."""
     for key, value in (env or {}).items():
         monkeypatch.setenv(key, value)
     monkeypatch.setattr(_hip, "_lib", _bind(tag))
     monkeypatch.setattr(_hip, "_ptr", _ptr)
-    monkeypatch.setattr(_hip, "_stream", lambda: None)
+    monkeypatch.setattr(_hip, "_stream", lambda like=None: None)
+
+    def call(name, like, *args):                 # no device / stream on the host: the "launch" runs synchronously
+        _hip._check(getattr(_hip.load(), name)(*args, None), name)
+
+    monkeypatch.setattr(_hip, "_call", call)
     monkeypatch.setattr(_hip, "workspace", _hip.Workspace())
     monkeypatch.setattr(_hip, "_partials", None)
-    two_launch = _hip._mi_update                 # the single-launch exchange cannot run here: route it to the two-launch form
-    monkeypatch.setattr(_hip, "_mi_update", lambda *a: two_launch(*a[:10], False, *a[11:]))
     from transferattack_amd import attack as ta_attack, utils as ta_utils
     cpu = lambda: torch.device("cpu")            # noqa: E731  -- "the device this process drives" is the host here
     monkeypatch.setattr(ta_utils, "default_device", cpu)

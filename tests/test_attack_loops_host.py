@@ -118,13 +118,6 @@ def test_main_cli_resume(tmp_path, monkeypatch):
     assert [i for i in range(5) if after[i] != stamp[i]] == [2, 3]          # only the incomplete batch was redone
 
 
-def test_tim_loop_with_separable_smoothing(golden, monkeypatch):
-    import test_zz_hip_widened as W
-    monkeypatch.setattr(W, "DEV", "cpu")
-    monkeypatch.setattr(W, "BOUND", 0.0)
-    W.test_tim_loop_with_separable_smoothing(golden, monkeypatch)
-
-
 def test_config1_end_to_end_through_kernels(golden):
     """BASELINE.json configs[0] -- I-FGSM, ResNet-18, 16 images, eps = 16/255, K = 10 -- END TO END (no replayed
     gradients): the product's attack class, the binding and the kernel sources on the host, the surrogate on torch's CPU

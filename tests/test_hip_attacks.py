@@ -60,7 +60,7 @@ def test_config1_trajectory_replay(golden):
     m = None
     for it, rec in enumerate(trace):
         m_out = torch.empty_like(xd)
-        _hip.mi_update(rec["grad"].to(DEV), m, m_out, d, xd, 0.0, ALPHA, EPS, single_launch=bool(it % 2))
+        _hip.mi_update(rec["grad"].to(DEV), m, m_out, d, xd, 0.0, ALPHA, EPS)
         m = m_out
         assert torch.equal(d.cpu(), rec["delta"]), "iterate %d differs" % it
     out = torch.empty((16, 224, 224, 3), dtype=torch.uint8, device=DEV)

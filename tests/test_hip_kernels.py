@@ -56,19 +56,14 @@ def test_update_stack_golden(golden, tag, decay, first):
     d_out = torch.empty_like(delta)
     _hip.update_delta_linf(delta, x, dev(g["m_" + tag]), ALPHA, EPS, d_out)
     assert np.array_equal(host(d_out), g["delta_" + tag])               # same momentum in -> same bytes out
-    # fused path, two-launch and single-launch: identical to each other, and to the reference
-    outs = []
-    for single in (False, True):
-        d = delta.clone()
-        m = torch.empty_like(grad)
-        _hip.mi_update(grad, None if first else mom.clone(), m, d, x, decay, ALPHA, EPS, single_launch=single)
-        if single:
-            _hip.fused_sync_check(grad, grad.shape[0], grad[0].numel())
-        assert_momentum_close(host(m), g["m_" + tag], g["grad"], None if first else g["momentum"], decay)
-        assert_delta_equal(host(d), g["delta_" + tag], g["m_" + tag])
-        assert np.array_equal(host(d)[2], g["delta"][2])                # NaN momentum -> frozen delta
-        outs.append((host(m), host(d)))
-    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True) and np.array_equal(outs[0][1], outs[1][1])
+    # fused path: the same as the two hooks, and as the reference
+    d = delta.clone()
+    m = torch.empty_like(grad)
+    _hip.mi_update(grad, None if first else mom.clone(), m, d, x, decay, ALPHA, EPS)
+    assert_momentum_close(host(m), g["m_" + tag], g["grad"], None if first else g["momentum"], decay)
+    assert_delta_equal(host(d), g["delta_" + tag], g["m_" + tag])
+    assert np.array_equal(host(d)[2], g["delta"][2])                    # NaN momentum -> frozen delta
+    assert np.array_equal(host(m), host(m_out), equal_nan=True)
 
 
 def test_update_delta_variants_golden(golden):
@@ -87,8 +82,7 @@ def test_update_delta_variants_golden(golden):
 
 
 @pytest.mark.parametrize("shape", [(32, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (3, 3, 299, 299), (2, 1, 1, 7)])
-@pytest.mark.parametrize("single", [False, True])
-def test_fused_update_random(shape, single):
+def test_fused_update_random(shape):
     """BASELINE sizes and ragged ones (E not a multiple of 4, E < one tile, N = 1) against the torch oracle."""
     gen = torch.Generator().manual_seed(sum(shape))
     x = torch.randint(0, 256, shape, generator=gen).float() / 255
@@ -103,9 +97,7 @@ def test_fused_update_random(shape, single):
         d_ref = O.delta_step(delta, x, m_ref, ALPHA, EPS)
         d, m, xa = delta.clone().to(DEV), mom.clone().to(DEV), torch.empty(shape, device=DEV)   # updated in place
         _hip.mi_update(grad.to(DEV), m, m, d, x.to(DEV), decay, ALPHA, EPS,
-                       variance=var.to(DEV) if use_var else None, x_adv=xa, single_launch=single)
-        if single:
-            _hip.fused_sync_check(d, shape[0], d[0].numel())
+                       variance=var.to(DEV) if use_var else None, x_adv=xa)
         assert_momentum_close(host(m), m_ref.numpy(), gsum.numpy(), mom.numpy(), decay)
         assert_delta_equal(host(d), d_ref.numpy(), m_ref.numpy())
         assert np.array_equal(host(xa), host(x.to(DEV) + d))
@@ -114,20 +106,131 @@ def test_fused_update_random(shape, single):
                            m_ref.numpy())
 
 
-def test_single_launch_repeats_and_interleaves():
-    """The in-kernel exchange re-arms itself: many launches on the same sync buffer, different batches."""
-    gen = torch.Generator().manual_seed(0)
-    for shape in ((32, 3, 224, 224), (7, 3, 224, 224), (32, 3, 224, 224)):
-        x = torch.rand(shape, generator=gen).to(DEV)
-        grad = torch.randn(shape, generator=gen).to(DEV)
-        d1, d2 = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
-        m1, m2 = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
-        for it in range(12):
-            _hip.mi_update(grad, m1, m1, d1, x, 1.0, ALPHA, EPS, single_launch=False)
-            _hip.mi_update(grad, m2, m2, d2, x, 1.0, ALPHA, EPS, single_launch=True)
-            grad = grad.roll(1, 0) * 1.01
-        _hip.fused_sync_check(x, shape[0], x[0].numel())
-        assert torch.equal(d1, d2) and torch.equal(m1, m2)
+def test_update_without_momentum():
+    """decay == 0 (FGSM / I-FGSM): m' = m*0 + g/mean|g| never depends on a finite old momentum, so the fused update
+    neither reads nor stores it (16 B/element) -- same delta as the full form, for every iteration of a replayed loop"""
+    gen = torch.Generator().manual_seed(11)
+    for shape in ((4, 3, 224, 224), (3, 3, 37, 41)):
+        x = (torch.randint(0, 256, shape, generator=gen).float() / 255).to(DEV)
+        d_full, d_lean = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+        m_full = None
+        for it in range(4):
+            grad = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+            m_new = torch.empty(shape, device=DEV)
+            _hip.mi_update(grad, m_full, m_new, d_full, x, 0.0, ALPHA, EPS)
+            m_full = m_new
+            xa = torch.empty(shape, device=DEV)
+            _hip.mi_update(grad, None, None, d_lean, x, 0.0, ALPHA, EPS, x_adv=xa)
+            assert torch.equal(d_full, d_lean) and torch.equal(xa, x + d_lean)
+
+
+def _k1_sums(t):
+    """per-image sum|t| the way K1 adds it: [n] float32 (the fixed-order total the fused update divides by E)"""
+    n, e = t.shape[0], t[0].numel()
+    ws, slots = _hip.abs_sum_partials(t)
+    _hip.invalidate_partials()
+    return ws[:n * slots].view(n, slots)
+
+
+def _check_registered(out, exact):
+    """the registry holds sums for ``out``; per image they add up to sum|out| (bit-identical per-tile sums to K1's for
+    the kernels that use K1's tiling, else equal to an fp64 sum within fp32 summation error)"""
+    assert _hip._partials is not None and _hip._partials[0].data_ptr() == out.data_ptr()
+    entry = _hip._partials
+    _, _, ws, slots = entry
+    n = out.shape[0]
+    sums = ws[:n * slots].view(n, slots).clone()
+    k1 = _k1_sums(out)
+    _hip._partials = entry                       # the K1 run above replaced the producer's entry: put it back
+    if exact:
+        assert slots == k1.shape[1] and torch.equal(sums, k1)
+    truth = out.double().abs().flatten(1).sum(1)
+    np.testing.assert_allclose(host(sums.double().sum(1)), host(truth), rtol=2e-6)
+    return sums
+
+
+def test_producer_side_partials_all_kernels():
+    """every kernel that can be the LAST writer of the input gradient leaves the per-tile sums of |g|; with them the
+    fused update gives what it gives after its own K1 pass (bit for bit where the tiling is K1's; else the momentum
+    within the summation-order bound and delta equal wherever the momentum sign is unambiguous)"""
+    gen = torch.Generator().manual_seed(5)
+    for shape in ((4, 3, 224, 224), (2, 3, 37, 41)):
+        n = shape[0]
+        data = torch.rand(shape, generator=gen).to(DEV)
+        mom = torch.randn(shape, generator=gen).to(DEV)
+
+        def run_update(g, expect_reuse):
+            before = dict(_hip.stats)
+            d, m = torch.zeros(shape, device=DEV), mom.clone()
+            _hip.mi_update(g, m, m, d, data, 1.0, ALPHA, EPS)
+            key = "partials_reused" if expect_reuse else "k1_passes"
+            assert _hip.stats[key] == before[key] + 1
+            return d, m
+
+        def check(out, exact):
+            _check_registered(out, exact)
+            d1, m1 = run_update(out, True)                 # consumes the registered sums
+            d2, m2 = run_update(out.clone(), False)        # another tensor: own K1 pass
+            if exact:
+                assert torch.equal(d1, d2) and torch.equal(m1, m2)
+            else:
+                assert_momentum_close(host(m1), host(m2), host(out), host(mom), 1.0)
+                assert_delta_equal(host(d1), host(d2), host(m2))
+
+        # TIM convolution
+        grad = (torch.randn(shape, generator=gen) * 1e-3).to(DEV)
+        w = torch.rand(15, 15, generator=gen)
+        out = torch.empty(shape, device=DEV)
+        _hip.depthwise_conv2d_same(grad, out, (w / w.sum()).to(DEV))
+        check(out, False)
+        # DIM backward (lane kernel at 1.1, table kernel at 2.0)
+        size = shape[-1]
+        if shape[-1] == shape[-2]:
+            for resize, rnd, top, left in ((int(size * 1.1), size + 9, 3, 5), (2 * size, size + 30, 7, 1)):
+                gx = torch.empty(shape, device=DEV)
+                _hip.dim_bwd(grad, gx, resize, rnd, top, left)
+                check(gx, False)
+        # SIM / EMI / Admix backward, ensemble member sum: K1's own tiling
+        gy = (torch.randn((5 * n,) + shape[1:], generator=gen) * 1e-3).to(DEV)
+        gx = torch.empty(shape, device=DEV)
+        _hip.scale_copies_bwd(gy, gx, 5)
+        check(gx, True)
+        _hip.sum_copies_bwd(gy, gx, 5)
+        check(gx, True)
+        gy = (torch.randn((6 * n,) + shape[1:], generator=gen) * 1e-3).to(DEV)
+        _hip.admix_bwd(gy, gx, 3, 2)
+        check(gx, True)
+        members = [(torch.randn(shape, generator=gen) * 1e-3).to(DEV) for _ in range(4)]
+        _hip.sum_members(members, gx)
+        check(gx, True)
+        # a kernel of the binding that overwrites the gradient drops the sums
+        _hip.sum_members(members, gx)
+        _hip.axpy(members[0], members[1], 0.5, gx)
+        assert _hip._partials is None
+
+
+def test_sum_members():
+    """the ensemble's fan-out backward: the members' gradients added last member first, like autograd's input buffer"""
+    gen = torch.Generator().manual_seed(6)
+    for shape, m in (((3, 3, 224, 224), 4), ((2, 3, 7, 9), 3), ((1, 1, 1, 5), 2), ((2, 3, 31, 33), 8)):
+        gs = [torch.randn(shape, generator=gen) for _ in range(m)]
+        ref = gs[-1].clone()
+        for g in reversed(gs[:-1]):
+            ref = ref + g
+        gx = torch.empty(shape, device=DEV)
+        _hip.sum_members([g.to(DEV) for g in gs], gx)
+        assert np.array_equal(host(gx), ref.numpy())
+    # and through autograd: x feeding several modules == torch's own accumulation
+    from transferattack_amd.utils import _FanOut
+    x = torch.randn(2, 3, 16, 16, generator=gen)
+    ws = [torch.randn(2, 3, 16, 16, generator=gen) for _ in range(4)]
+    r = torch.randn(2, 3, 16, 16, generator=gen)
+    xin = x.clone().requires_grad_(True)
+    ref = torch.autograd.grad((torch.stack([(xin * w).tanh() for w in ws]).mean(0) * r).sum(), xin)[0]
+    xd = x.to(DEV).requires_grad_(True)
+    views = _FanOut.apply(xd, 4)
+    got = torch.autograd.grad((torch.stack([(v * w.to(DEV)).tanh() for v, w in zip(views, ws)]).mean(0) * r.to(DEV)).sum(), xd)[0]
+    np.testing.assert_allclose(host(got), ref.numpy(), rtol=1e-5, atol=1e-7)     # tanh differs in the last bit across devices
 
 
 def test_fused_update_under_graph_capture():
@@ -353,6 +456,43 @@ def test_vmi_kernels_and_philox():
     _hip.init_delta_uniform(dl, x.to(DEV), EPS, seed=9, offset=1)
     ref = O.box_clamp(torch.from_numpy(C.philox_uniform(x.numel(), 9, 1, np.float32(EPS)).reshape(shape)), 0 - x, 1 - x)
     assert np.array_equal(host(dl), ref.numpy())
+
+
+def test_streaming_kernels_at_batch_size():
+    """VMI / NI / random-start / accumulate kernels at the reference's batch shape (32 x 3 x 224 x 224), against the
+    reference's torch expressions (bit-exact) and the restated Philox stream"""
+    gen = torch.Generator().manual_seed(12)
+    shape = (32, 3, 224, 224)
+    x = torch.randint(0, 256, shape, generator=gen).float() / 255
+    d = (torch.rand(shape, generator=gen) - 0.5) * EPS
+    noise = (torch.rand(shape, generator=gen) - 0.5) * 3 * EPS
+    g1, g2 = torch.randn(shape, generator=gen) * 1e-3, torch.randn(shape, generator=gen) * 1e-3
+    xd, dd = x.to(DEV), d.to(DEV)
+    out = torch.empty(shape, device=DEV)
+    _hip.vmi_neighbor(xd, dd, out, 1.5 * EPS, noise=noise.to(DEV))
+    assert np.array_equal(host(out), (x + d + noise).numpy())
+    _hip.vmi_neighbor(xd, dd, out, 1.5 * EPS, seed=77, offset=3)
+    stream = C.philox_uniform(x.numel(), 77, 3, np.float32(1.5 * EPS)).reshape(shape)
+    assert np.array_equal(host(out), (x + d).numpy() + stream)
+    acc = torch.empty(shape, device=DEV)
+    _hip.grad_accumulate(acc, g1.to(DEV), first=True)
+    _hip.grad_accumulate(acc, g2.to(DEV), first=False)
+    assert np.array_equal(host(acc), (g1 + g2).numpy())
+    var = torch.empty(shape, device=DEV)
+    _hip.variance_finalize(acc, g1.to(DEV), var, 20)
+    assert np.array_equal(host(var), ((g1 + g2) / 20 - g1).numpy())
+    _hip.axpy(xd, g1.to(DEV), ALPHA, out)
+    assert np.array_equal(host(out), (x + ALPHA * g1).numpy())
+    _hip.init_delta_uniform(out, xd, EPS, noise=noise.clamp(-EPS, EPS).to(DEV))
+    assert np.array_equal(host(out), O.delta_init(x, EPS, True, noise=noise.clamp(-EPS, EPS)).numpy())
+    _hip.init_delta_uniform(out, xd, EPS, seed=9, offset=1)
+    ref = O.box_clamp(torch.from_numpy(C.philox_uniform(x.numel(), 9, 1, np.float32(EPS)).reshape(shape)), 0 - x, 1 - x)
+    assert np.array_equal(host(out), ref.numpy())
+    # momentum with a variance term (VMI: get_momentum(grad + variance)) at this size
+    m_prev = torch.randn(shape, generator=gen)
+    m_out = torch.empty(shape, device=DEV)
+    _hip.momentum(g1.to(DEV), m_prev.to(DEV), m_out, 1.0, variance=g2.to(DEV))
+    assert_momentum_close(host(m_out), O.momentum_step(g1 + g2, m_prev, 1.0).numpy(), (g1 + g2).numpy(), m_prev.numpy(), 1.0)
 
 
 def test_bad_arguments_fail_loudly():

@@ -5,7 +5,7 @@ re-used here function by function at sizes the stand-in finishes quickly).
 
 What this proves: indexing, tiling, staging through the shared arrays, barriers, tail handling, rounding order and
 the binding's argument marshalling.  What it does not: anything about the gfx950 build (another compiler, no real
-wave execution, no non-temporal paths, no single-launch exchange) or about speed -- the GPU tests stay the parity
+wave execution, no non-temporal paths) or about speed -- the GPU tests stay the parity
 gate.  Test infrastructure only."""
 import numpy as np
 import pytest
@@ -41,23 +41,12 @@ test_dim_random = G.test_dim_random
 
 @pytest.mark.parametrize("shape", [(32, 3, 224, 224), (5, 3, 37, 41), (1, 3, 8, 8), (3, 3, 299, 299), (2, 1, 1, 7)])
 def test_fused_update_random(shape):
-    G.test_fused_update_random(shape, False)          # the single-launch form cannot run here (see tests/hipcpu)
+    G.test_fused_update_random(shape)
 
 
-# ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
-def test_tim_variants(monkeypatch, golden, variant):
-    host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
-    G.test_tim_golden(golden)
-    G.test_tim_random((4, 3, 224, 224), 15)
-    G.test_tim_random((2, 3, 37, 41), 15)
-
-
-def test_dim_separable_forward(monkeypatch, golden):
-    host_kernels.install(monkeypatch, tag="dimsep", env={"TA_DIM_FWD_VARIANT": "1"})
-    G.test_dim_golden(golden)
-    G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
-    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
+test_producer_side_partials_all_kernels = G.test_producer_side_partials_all_kernels
+test_sum_members = G.test_sum_members
+test_update_without_momentum = G.test_update_without_momentum
 
 
 def test_bad_arguments_fail_loudly():
@@ -73,24 +62,8 @@ def test_bad_arguments_fail_loudly():
         _hip.momentum(x.double(), None, torch.empty_like(x), 1.0)
 
 
-# ---- the tuning variants behind TA_TIM_VARIANT / TA_DIM_FWD_VARIANT (read once per library load -> private copies)
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
-def test_tim_variants(monkeypatch, golden, variant):
-    host_kernels.install(monkeypatch, tag="tim" + variant, env={"TA_TIM_VARIANT": variant})
-    G.test_tim_golden(golden)
-    G.test_tim_random((1, 2, 224, 224), 15)
-    G.test_tim_random((1, 1, 37, 41), 15)
-
-
-def test_dim_separable_forward(monkeypatch, golden):
-    host_kernels.install(monkeypatch, tag="dimsep", env={"TA_DIM_FWD_VARIANT": "1"})
-    G.test_dim_golden(golden)
-    G.test_dim_random(224, 1.1, [(237, 3, 5)])
-    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0)])
-
-
-def test_dim_lane_per_column_forward(monkeypatch, golden):
-    host_kernels.install(monkeypatch, tag="dimlanes", env={"TA_DIM_FWD_VARIANT": "2"})
+def test_dim_lane_and_table_kernels(golden):
+    """resize ratios 1.1 / 1.5 run the lane-per-column kernels, ratio 2 the table-driven gathers"""
     G.test_dim_golden(golden)
     G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
     G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
@@ -116,10 +89,8 @@ def _guarded(array, at_end):
     return view, m
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
-def test_dim_reads_stay_in_bounds(monkeypatch, variant):
+def test_dim_reads_stay_in_bounds():
     from transferattack_amd import _hip
-    host_kernels.install(monkeypatch, tag="dimoob" + variant, env={"TA_DIM_FWD_VARIANT": variant})
     gen = torch.Generator().manual_seed(1)
     for size, resize, geoms in ((224, 246, [(245, 0, 1), (224, 22, 0), (230, 0, 16)]), (33, 66, [(40, 5, 20), (65, 0, 1)])):
         x = torch.rand(1, 1, size, size, generator=gen).numpy()
@@ -139,10 +110,8 @@ def test_dim_reads_stay_in_bounds(monkeypatch, variant):
             keep = None
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
-def test_tim_reads_stay_in_bounds(monkeypatch, variant):
+def test_tim_reads_stay_in_bounds():
     from transferattack_amd import _hip
-    host_kernels.install(monkeypatch, tag="timoob" + variant, env={"TA_TIM_VARIANT": variant})
     gen = torch.Generator().manual_seed(2)
     for shape, k in (((1, 1, 224, 224), 15), ((1, 1, 37, 41), 15), ((1, 1, 64, 64), 7), ((1, 1, 33, 33), 4)):
         grad = torch.randn(shape, generator=gen).numpy()
@@ -154,23 +123,11 @@ def test_tim_reads_stay_in_bounds(monkeypatch, variant):
             out = torch.from_numpy(og)
             _hip.depthwise_conv2d_same(torch.from_numpy(gg), out, w)
             assert np.array_equal(out.numpy(), C.depthwise_conv2d_same(grad, w.numpy()))
-            if k in (3, 5, 7, 15):
-                f = w.sum(dim=0).contiguous()
-                _hip.depthwise_conv2d_same_separable(torch.from_numpy(gg), out, f, f)
-                assert np.array_equal(out.numpy(), C.depthwise_conv2d_same_separable(grad, f.numpy(), f.numpy()))
             del gg, out, og
             keep = None
 
 
-def test_dim_lane_per_column_backward(monkeypatch, golden):
-    host_kernels.install(monkeypatch, tag="dimbwdlanes", env={"TA_DIM_BWD_VARIANT": "1", "TA_DIM_FWD_VARIANT": "2"})
-    G.test_dim_golden(golden)
-    G.test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
-    G.test_dim_random(64, 1.5, [(64, 0, 31), (95, 0, 0), (80, 7, 9)])
-    G.test_dim_random(33, 2.0, [(40, 5, 20), (65, 0, 1)])                  # ratio 2: falls back to the table-driven form
-
-
-# ---- SIA: the (not yet run) GPU tests of tests/test_zz_hip_widened.py, on the host stand-in
+# ---- SIA: the GPU tests of tests/test_zz_hip_widened.py, on the host stand-in
 import test_zz_hip_widened as W          # noqa: E402
 
 
@@ -191,22 +148,6 @@ def test_sia_kernels_random(widened_on_host, shape, nb, copies):
     W.test_sia_kernels_random(shape, nb, copies)
 
 
-def test_xcd_major_tile_order(monkeypatch, golden):
-    """TA_XCD_MAJOR_TILES=1 only changes WHICH workgroup computes which tile (a bijection on the tile ids): every
-    TIM / DIM kernel, shipped and variant, must give the same bytes"""
-    host_kernels.install(monkeypatch, tag="xcd", env={"TA_XCD_MAJOR_TILES": "1", "TA_DIM_FWD_VARIANT": "2",
-                                                       "TA_DIM_BWD_VARIANT": "1", "TA_TIM_VARIANT": "3"})
-    G.test_tim_golden(golden)
-    G.test_tim_random((4, 3, 224, 224), 15)
-    G.test_tim_random((2, 3, 50, 70), 9)                       # generic kernel
-    G.test_dim_golden(golden)
-    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
-    G.test_dim_random(33, 2.0, [(40, 5, 20)])                  # falls back to the table-driven kernels
-    host_kernels.install(monkeypatch, tag="xcd0", env={"TA_XCD_MAJOR_TILES": "1"})
-    G.test_tim_random((4, 3, 224, 224), 15)
-    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
-
-
 def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
     """the BASELINE-size property tests of the GPU tier, with the sizes cut to what the stand-in finishes quickly"""
     monkeypatch.setattr(W, "FULL_N", 12)
@@ -223,26 +164,18 @@ def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
     (299, 1.1, [(300, 10, 20), (327, 0, 0)]),
     (40, 1.45, [(57, 0, 0), (41, 8, 16)]),
 ])
-def test_dim_lane_kernels_other_geometries(monkeypatch, size, rate, geoms):
+def test_dim_lane_kernels_other_geometries(size, rate, geoms):
     """tile widths, row counts (RPW 10 and 17) and hit-run lengths the default 224 / 1.1 setting does not reach"""
-    host_kernels.install(monkeypatch, tag="dimlanes_all", env={"TA_DIM_FWD_VARIANT": "2", "TA_DIM_BWD_VARIANT": "1"})
     G.test_dim_random(size, rate, geoms)
-
-
-@pytest.mark.parametrize("shape,k", [((4, 3, 224, 224), 15), ((2, 3, 299, 299), 15), ((2, 3, 37, 41), 15), ((2, 3, 64, 64), 3),
-                                     ((2, 3, 64, 64), 5), ((1, 3, 50, 70), 7), ((1, 1, 5, 9), 15)])
-def test_separable_smoothing(widened_on_host, shape, k):
-    W.test_separable_smoothing(shape, k)
 
 
 def test_kernels_under_reverse_lane_order(monkeypatch, golden, widened_on_host):
     """HIPCPU_ORDER=reverse runs the lanes of a workgroup last-to-first between barriers.  A kernel that needs a barrier
     it does not have (lanes of different waves meeting in LDS) answers differently under the two orders; all of them
     must give the oracle's bytes under both."""
-    host_kernels.install(monkeypatch, tag="rev", env={"HIPCPU_ORDER": "reverse", "TA_DIM_FWD_VARIANT": "2",
-                                                       "TA_DIM_BWD_VARIANT": "1", "TA_TIM_VARIANT": "3"})
+    host_kernels.install(monkeypatch, tag="rev", env={"HIPCPU_ORDER": "reverse"})
     G.test_update_stack_golden(golden, "d09", 0.9, False)
-    G.test_fused_update_random((5, 3, 37, 41), False)
+    G.test_fused_update_random((5, 3, 37, 41))
     G.test_normalize_and_producer_side_partials((3, 3, 37, 41))
     G.test_tim_random((4, 3, 224, 224), 15)
     G.test_tim_random((2, 3, 50, 70), 9)
@@ -250,11 +183,9 @@ def test_kernels_under_reverse_lane_order(monkeypatch, golden, widened_on_host):
     G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
     G.test_sim_admix_golden(golden)
     G.test_vmi_kernels_and_philox()
-    W.test_separable_smoothing((4, 3, 224, 224), 15)
+    G.test_dim_random(33, 2.0, [(40, 5, 20)])                  # the table-driven kernels
+    G.test_producer_side_partials_all_kernels()
     W.test_sia_kernels_golden(golden)
-    host_kernels.install(monkeypatch, tag="rev0", env={"HIPCPU_ORDER": "reverse"})      # the shipped variants
-    G.test_tim_random((4, 3, 224, 224), 15)
-    G.test_dim_random(224, 1.1, [(245, 0, 1), (237, 3, 5)])
 
 
 @pytest.mark.parametrize("at_end", [True, False])
@@ -366,6 +297,8 @@ def test_reference_order_sum(monkeypatch, golden, lanes):
 
 def test_reference_sum_order_gpu_test_on_host(golden, monkeypatch, widened_on_host):
     W.test_reference_sum_order(golden, monkeypatch)
+
+
 
 
 def test_dct_forms_gpu_test_on_host(monkeypatch, widened_on_host):

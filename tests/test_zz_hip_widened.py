@@ -320,43 +320,6 @@ def test_transform_properties_at_shard_size():
     assert abs(lhs - rhs) <= 1e-5 * (ys.double() * gs.double()).abs().sum().item()
 
 
-# ------------------------------------------------------------------------- opt-in separable smoothing
-@pytest.mark.parametrize("shape,k", [((4, 3, 224, 224), 15), ((2, 3, 299, 299), 15), ((2, 3, 37, 41), 15), ((2, 3, 64, 64), 3),
-                                     ((2, 3, 64, 64), 5), ((1, 3, 50, 70), 7), ((1, 1, 5, 9), 15)])
-def test_separable_smoothing(shape, k):
-    """ta_depthwise_conv2d_same_separable: bit-exact against its own two-pass restatement (oracle/ta_oracle.c), and
-    within 1e-6 of max|out| of the reference's direct convolution for the reference's kernels -- two decades inside the
-    1e-5 gradient budget of BASELINE.json."""
-    import c_oracle as C
-    from transferattack_amd import _hip
-    gen = torch.Generator().manual_seed(k + shape[-1])
-    grad = torch.randn(shape, generator=gen)
-    profile = np.exp(-np.linspace(-3, 3, k) ** 2 / 2.0)
-    factor = torch.from_numpy((profile / profile.sum()).astype(np.float32))
-    plane = np.outer(profile, profile)
-    w2d = torch.from_numpy((plane / plane.sum()).astype(np.float32))
-    out = torch.empty(shape, device=DEV)
-    _hip.depthwise_conv2d_same_separable(grad.to(DEV), out, factor.to(DEV), factor.to(DEV))
-    assert np.array_equal(out.cpu().numpy(), C.depthwise_conv2d_same_separable(grad.numpy(), factor.numpy(), factor.numpy()))
-    direct = C.depthwise_conv2d_same(grad.numpy(), w2d.numpy())
-    assert float(np.abs(out.cpu().numpy() - direct).max()) <= 1e-6 * float(np.abs(direct).max())
-
-
-def test_tim_loop_with_separable_smoothing(golden, monkeypatch):
-    """the TIM loop with TA_TIM_SEPARABLE=1 against the reference's golden loop: the smoothing differs by rounding
-    only, so the perturbation may differ in the few pixels whose momentum sign that decides"""
-    monkeypatch.setenv("TA_TIM_SEPARABLE", "1")
-    g = golden("loops_toy")
-    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
-    cls = ta.load_attack_class("tim")
-    model = backbones.create("toy_cnn", seed=3, verbose=False)
-    atk = type("DevTIM", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})(model_name="injected")
-    delta = atk(x, label).cpu()
-    rate = mismatch(x, delta, g["delta_tim"])
-    print("tim (separable smoothing): uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
-    assert float(delta.abs().max()) <= EPS + 1e-7 and rate <= max(BOUND, 0.001)
-
-
 # -------------------------------------------------- opt-in: |g| summed in the reference's (ATen cascade) order
 def test_reference_sum_order(golden, monkeypatch):
     """TA_ATEN_SUM_LANES=8: sum|g| evaluated as ATen's AVX2 cascade (the order of the reference that wrote the goldens)

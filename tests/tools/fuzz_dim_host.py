@@ -2,7 +2,6 @@
 import os, sys, numpy as np, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT+'/oracle', ROOT+'/tests'): sys.path.insert(0,p)
-os.environ['TA_DIM_FWD_VARIANT']='2'; os.environ['TA_DIM_BWD_VARIANT']='1'
 import host_kernels, c_oracle as C
 class P:
     def setattr(self,o,n,v): setattr(o,n,v)

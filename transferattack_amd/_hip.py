@@ -28,6 +28,9 @@ SIGNATURES = {
     "ta_abi_version": (_int, []),
     "ta_last_error": (ctypes.c_char_p, []),
     "ta_l1_workspace_floats": (_i64, [_i64, _i64]),
+    "ta_update_tiles": (_i64, [_i64]),
+    "ta_conv_tiles": (_i64, [_int, _int]),
+    "ta_dim_bwd_tiles": (_i64, [_int, _int]),
     "ta_abs_sum_partials": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "ta_momentum": (_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp]),
     "ta_update_delta_linf": (_int, [_vp, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _i64, _vp]),
@@ -35,19 +38,16 @@ SIGNATURES = {
     "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
-    "ta_fused_sync_bytes": (_i64, [_i64, _i64]),
-    "ta_mi_update_fused": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _i64, _vp]),
-    "ta_fused_sync_error": (_int, [_vp, _i64, _i64, _vp]),
     "ta_init_delta_uniform": (_int, [_vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
-    "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
-    "ta_depthwise_conv2d_same_separable": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
+    "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
-    "ta_dim_bwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
+    "ta_dim_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
-    "ta_scale_copies_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
-    "ta_sum_copies_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
+    "ta_scale_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "ta_sum_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ta_admix_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _f32, _vp]),
-    "ta_admix_bwd": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "ta_admix_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "ta_sum_members": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "ta_sia_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
     "ta_sia_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
     "ta_vmi_neighbor": (_int, [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
@@ -57,7 +57,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipExtensionError(RuntimeError):
@@ -108,8 +108,10 @@ def _ptr(t, dtype=torch.float32, name="tensor"):
     return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(like=None):
+    """The torch HIP stream of the tensor's device (not of whatever device is current: ``torch.cuda.set_device`` is
+    thread-local, so an io thread of rank k > 0 would otherwise launch on GPU 0)."""
+    return torch.cuda.current_stream(None if like is None else like.device).cuda_stream
 
 
 def _check(rc, what):
@@ -118,21 +120,32 @@ def _check(rc, what):
         raise HipExtensionError("%s failed (rc=%d): %s" % (what, rc, msg))
 
 
+def _call(name, like, *args):
+    """lib.<name>(*args, stream) on ``like``'s device and its current torch stream; raises on a non-zero return."""
+    fn = getattr(load(), name)
+    dev = like.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):                    # the launch needs the tensor's device current in THIS thread
+            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    _check(rc, name)
+
+
 def _batch(t):
     return t.shape[0], t[0].numel()
 
 
 # ------------------------------------------------------------------------------------------ workspaces
 class Workspace:
-    """Per-(device, stream) scratch for the reductions / the in-kernel exchange; grown on demand."""
+    """Per-(device, stream) scratch for the reductions; grown on demand."""
 
     def __init__(self):
         self._l1 = {}
-        self._sync = {}
 
     def l1(self, like, n, e):
         _ptr(like)
-        key = (like.device, torch.cuda.current_stream().cuda_stream)
+        key = (like.device, _stream(like))
         need = load().ta_l1_workspace_floats(n, e)
         buf = self._l1.get(key)
         if buf is None or buf.numel() < need:
@@ -140,101 +153,53 @@ class Workspace:
             self._l1[key] = buf
         return buf
 
-    def sync(self, like, n, e):
-        _ptr(like)
-        key = (like.device, torch.cuda.current_stream().cuda_stream, n, e)
-        buf = self._sync.get(key)
-        if buf is None:
-            nbytes = load().ta_fused_sync_bytes(n, e)
-            buf = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=like.device)
-            self._sync[key] = buf
-        return buf
-
 
 workspace = Workspace()
 
 
-# ------------------------------------------------------------------------------------------- update stack
-def momentum(grad, momentum_in, momentum_out, decay, variance=None):
-    n, e = _batch(grad)
-    ws = workspace.l1(grad, n, e)
-    _check(load().ta_momentum(_ptr(grad, name="grad"), _ptr(variance, name="variance"),
-                              _ptr(momentum_in, name="momentum"), _ptr(momentum_out, name="momentum_out"),
-                              _ptr(ws), decay, n, e, _stream()), "ta_momentum")
-
-
-def update_delta_linf(delta_in, data, momentum_, alpha, epsilon, delta_out, x_adv=None):
-    alpha_t = alpha if isinstance(alpha, torch.Tensor) else None
-    if alpha_t is not None and alpha_t.shape != delta_in.shape:
-        alpha_t = alpha_t.expand_as(delta_in).contiguous()
-    _check(load().ta_update_delta_linf(_ptr(delta_in, name="delta"), _ptr(data, name="data"),
-                                       _ptr(momentum_, name="grad"), 0.0 if alpha_t is not None else float(alpha),
-                                       _ptr(alpha_t, name="alpha"), float(epsilon), _ptr(delta_out, name="delta_out"),
-                                       _ptr(x_adv, name="x_adv"), delta_in.numel(), _stream()),
-           "ta_update_delta_linf")
-
-
-def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
-    n, e = _batch(delta_in)
-    ws = workspace.l1(delta_in, n, e)
-    _check(load().ta_update_delta_l2(_ptr(delta_in, name="delta"), _ptr(data, name="data"), _ptr(grad, name="grad"),
-                                     float(alpha), float(epsilon), _ptr(delta_out, name="delta_out"), _ptr(ws), n, e,
-                                     _stream()), "ta_update_delta_l2")
-
-
-# bench.py sets this to a list to time every fused-update launch with HIP events on the launch stream
-profile_sink = None
-
-
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None,
-              single_launch=False):
-    """Fused get_momentum + update_delta; ``delta`` is updated in place, momentum_out may alias momentum_in."""
-    n, e = _batch(grad)
-    if profile_sink is not None:
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch,
-                   n, e)
-        end.record()
-        profile_sink.append((start, end, n, e))
-        return
-    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch, n, e)
-
-
-def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, single_launch,
-               n, e):
-    args = (_ptr(grad, name="grad"), _ptr(variance, name="variance"), _ptr(momentum_in, name="momentum"),
-            _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"), _ptr(data, name="data"),
-            _ptr(x_adv, name="x_adv"))
-    if single_launch:
-        sync = workspace.sync(grad, n, e)
-        _check(load().ta_mi_update_fused(*args, sync.data_ptr(), float(decay), float(alpha), float(epsilon), n, e,
-                                         _stream()), "ta_mi_update_fused")
-    else:
-        ready = _take_partials(grad) if variance is None else None
-        stats["partials_reused" if ready is not None else "k1_passes"] += 1
-        ws = ready if ready is not None else workspace.l1(grad, n, e)
-        _check(load().ta_mi_update(*args, _ptr(ws), 1 if ready is not None else 0, float(decay), float(alpha),
-                                   float(epsilon), n, e, _stream()), "ta_mi_update")
-
-
-# ---- producer-side |g| partial sums ---------------------------------------------------------------------
-# normalize_bwd (the last kernel of the surrogate's backward) leaves the per-tile sums of |g| of the gradient it
-# produced here; mi_update consumes them if -- and only if -- it is handed that very tensor, unmodified.  The
-# entry holds a strong reference to the gradient, so its memory cannot be recycled while the entry is live.
-_partials = None            # (grad tensor, grad._version, ws tensor)
+# ---- producer-side |g| tile sums ("partials") -----------------------------------------------------------
+# The kernel that writes the input gradient LAST (ta_normalize_bwd for the plain attacks; TIM's convolution, the DIM /
+# SIM / Admix / EMI backward kernels, the ensemble's member sum otherwise) also leaves per-tile sums of |g| here;
+# mi_update consumes them -- and skips its own pass over g -- if and only if it is handed that very tensor, unmodified:
+#   * the entry holds a strong reference to the gradient, so its memory cannot be recycled while the entry is live;
+#   * pointer, shape and autograd version must match (torch in-place ops bump the version);
+#   * every wrapper of this module that WRITES a tensor drops the entry if it writes that memory, and code that
+#     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials()``;
+#   * one slot only: the next producer overwrites it.
+_partials = None            # (grad tensor, grad._version, ws tensor, sums per image)
 stats = {"partials_reused": 0, "k1_passes": 0}
+
+
+def _register_partials(grad, ws, slots):
+    global _partials
+    _partials = (grad, grad._version, ws, int(slots))
+
+
+def invalidate_partials():
+    global _partials
+    _partials = None
+
+
+def _wrote(*tensors):
+    """A kernel of this module wrote ``tensors``: sums registered for that memory are stale."""
+    global _partials
+    if _partials is not None:
+        ptr = _partials[0].data_ptr()
+        for t in tensors:
+            if t is not None and t.data_ptr() == ptr:
+                _partials = None
+                return
 
 
 def _take_partials(grad):
     global _partials
     entry, _partials = _partials, None
-    if entry is None:
-        return None
-    tensor, version, ws = entry
+    if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
+        return None                                   # the reference-order sum is never taken from a producer
+    tensor, version, ws, slots = entry
     if (tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
-            and tensor._version == version):
-        return ws
+            and tensor._version == version and tensor.device == grad.device):
+        return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
         print("partials not reused: ptr %x vs %x, shape %s vs %s, version %d/%d vs %d" % (
             tensor.data_ptr(), grad.data_ptr(), tuple(tensor.shape), tuple(grad.shape), tensor._version,
@@ -242,129 +207,230 @@ def _take_partials(grad):
     return None
 
 
+def _new_ws(like, count):
+    return torch.empty(max(int(count), 1), dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------- update stack
+def momentum(grad, momentum_in, momentum_out, decay, variance=None):
+    n, e = _batch(grad)
+    ws = workspace.l1(grad, n, e)
+    _wrote(momentum_out)
+    _call("ta_momentum", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"),
+          _ptr(momentum_in, name="momentum"), _ptr(momentum_out, name="momentum_out"), _ptr(ws), decay, n, e)
+
+
+def update_delta_linf(delta_in, data, momentum_, alpha, epsilon, delta_out, x_adv=None):
+    alpha_t = alpha if isinstance(alpha, torch.Tensor) else None
+    if alpha_t is not None and alpha_t.shape != delta_in.shape:
+        alpha_t = alpha_t.expand_as(delta_in).contiguous()
+    _wrote(delta_out, x_adv)
+    _call("ta_update_delta_linf", delta_in, _ptr(delta_in, name="delta"), _ptr(data, name="data"),
+          _ptr(momentum_, name="grad"), 0.0 if alpha_t is not None else float(alpha), _ptr(alpha_t, name="alpha"),
+          float(epsilon), _ptr(delta_out, name="delta_out"), _ptr(x_adv, name="x_adv"), delta_in.numel())
+
+
+def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
+    n, e = _batch(delta_in)
+    ws = workspace.l1(delta_in, n, e)
+    _wrote(delta_out)
+    _call("ta_update_delta_l2", delta_in, _ptr(delta_in, name="delta"), _ptr(data, name="data"), _ptr(grad, name="grad"),
+          float(alpha), float(epsilon), _ptr(delta_out, name="delta_out"), _ptr(ws), n, e)
+
+
+# bench.py sets this to a list to time every fused-update launch with HIP events on the launch stream
+profile_sink = None
+
+
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None):
+    """Fused get_momentum + update_delta; ``delta`` is updated in place, momentum_out may alias momentum_in.
+    ``momentum_in`` None = first iteration; ``momentum_out`` None = the momentum is not kept (decay == 0);
+    ``x_adv`` (optional) receives data + delta', the next iteration's input."""
+    n, e = _batch(grad)
+    if profile_sink is not None:
+        dev = grad.device
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(torch.cuda.current_stream(dev))
+        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e)
+        end.record(torch.cuda.current_stream(dev))
+        bytes_per_elem = 4 * (3 + (variance is not None) + (momentum_in is not None) + 1 + (momentum_out is not None)
+                              + (x_adv is not None))       # r g,(v),(m),d,x  w (m),d,(x_adv)
+        profile_sink.append((start, end, n, e, bytes_per_elem))
+        return
+    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e)
+
+
+def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e):
+    ready = _take_partials(grad) if variance is None else None
+    stats["partials_reused" if ready is not None else "k1_passes"] += 1
+    ws, slots = ready if ready is not None else (workspace.l1(grad, n, e), 0)
+    _call("ta_mi_update", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"),
+          _ptr(momentum_in, name="momentum"), _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"),
+          _ptr(data, name="data"), _ptr(x_adv, name="x_adv"), _ptr(ws), slots, float(decay), float(alpha),
+          float(epsilon), n, e)
+
+
+def abs_sum_partials(grad, variance=None):
+    """K1 alone: (ws, sums per image) for ``grad`` (+ variance), registered as the partials of ``grad``."""
+    n, e = _batch(grad)
+    slots = load().ta_update_tiles(e)
+    ws = _new_ws(grad, n * slots)
+    _call("ta_abs_sum_partials", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"), _ptr(ws), n, e)
+    if variance is None:
+        _register_partials(grad, ws, slots)
+    return ws, slots
+
+
 def normalize_fwd(x, y, mean, std):
     n, c = x.shape[0], x.shape[1]
-    _check(load().ta_normalize_fwd(_ptr(x, name="x"), _ptr(y, name="y"), _ptr(mean, name="mean"), _ptr(std, name="std"),
-                                   n, c, x[0, 0].numel(), _stream()), "ta_normalize_fwd")
+    _wrote(y)
+    _call("ta_normalize_fwd", x, _ptr(x, name="x"), _ptr(y, name="y"), _ptr(mean, name="mean"), _ptr(std, name="std"),
+          n, c, x[0, 0].numel())
 
 
 def normalize_bwd(gy, gx, std):
     """gx = gy / std[c]; also registers the |gx| tile sums for the fused update that consumes gx next."""
-    global _partials
     n, c = gy.shape[0], gy.shape[1]
-    ws = torch.empty(max(load().ta_l1_workspace_floats(n, gy[0].numel()), 1), dtype=torch.float32, device=gy.device)
-    _check(load().ta_normalize_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"), _ptr(ws), n, c,
-                                   gy[0, 0].numel(), _stream()), "ta_normalize_bwd")
-    _partials = (gx, gx._version, ws)
-
-
-def fused_sync_check(like, n, e):
-    sync = workspace.sync(like, n, e)
-    _check(load().ta_fused_sync_error(sync.data_ptr(), n, e, _stream()), "ta_fused_sync_error")
+    slots = load().ta_update_tiles(gy[0].numel())
+    ws = _new_ws(gy, n * slots)
+    _call("ta_normalize_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"), _ptr(ws), n, c,
+          gy[0, 0].numel())
+    _register_partials(gx, ws, slots)
 
 
 def init_delta_uniform(delta, data, epsilon, seed=0, offset=0, noise=None):
-    _check(load().ta_init_delta_uniform(_ptr(delta, name="delta"), _ptr(data, name="data"), _ptr(noise, name="noise"),
-                                        float(epsilon), seed, offset, delta.numel(), _stream()),
-           "ta_init_delta_uniform")
+    _wrote(delta)
+    _call("ta_init_delta_uniform", delta, _ptr(delta, name="delta"), _ptr(data, name="data"), _ptr(noise, name="noise"),
+          float(epsilon), seed, offset, delta.numel())
 
 
 # --------------------------------------------------------------------------------------------- transforms
 def depthwise_conv2d_same(inp, out, weight2d):
+    """out = depthwise k x k 'same' correlation of inp; registers the |out| tile sums (TIM.get_grad produces the
+    gradient the update consumes)."""
     k = weight2d.shape[-1]
     h, w = inp.shape[-2:]
-    _check(load().ta_depthwise_conv2d_same(_ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(weight2d, name="kernel"),
-                                           k, inp.numel() // (h * w), h, w, _stream()), "ta_depthwise_conv2d_same")
-
-
-def depthwise_conv2d_same_separable(inp, out, wy, wx):
-    """opt-in two-pass form for outer-product kernels (rounding differs from the reference's direct convolution)"""
-    h, w = inp.shape[-2:]
-    _check(load().ta_depthwise_conv2d_same_separable(_ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(wy, name="wy"),
-                                                     _ptr(wx, name="wx"), wy.numel(), inp.numel() // (h * w), h, w,
-                                                     _stream()), "ta_depthwise_conv2d_same_separable")
+    planes = inp.numel() // (h * w)
+    per_image = inp[0].numel() // (h * w) if inp.dim() == 4 else 0
+    tiles = load().ta_conv_tiles(h, w)
+    ws = _new_ws(inp, planes * tiles) if per_image else None
+    _call("ta_depthwise_conv2d_same", inp, _ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(weight2d, name="kernel"),
+          _ptr(ws), k, planes, h, w)
+    if ws is not None:
+        _register_partials(out, ws, per_image * tiles)
+    else:
+        _wrote(out)
 
 
 def dim_fwd(x, y, resize, rnd, top, left):
     size = x.shape[-1]
-    _check(load().ta_dim_fwd(_ptr(x, name="x"), _ptr(y, name="y"), x.numel() // (size * size), size, resize, rnd, top,
-                             left, _stream()), "ta_dim_fwd")
+    _wrote(y)
+    _call("ta_dim_fwd", x, _ptr(x, name="x"), _ptr(y, name="y"), x.numel() // (size * size), size, resize, rnd, top, left)
 
 
 def dim_bwd(gy, gx, resize, rnd, top, left):
     size = gy.shape[-1]
-    _check(load().ta_dim_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), gy.numel() // (size * size), size, resize, rnd,
-                             top, left, _stream()), "ta_dim_bwd")
+    planes = gy.numel() // (size * size)
+    per_image = gy[0].numel() // (size * size) if gy.dim() == 4 else 0
+    tiles = load().ta_dim_bwd_tiles(size, resize)
+    ws = _new_ws(gy, planes * tiles) if per_image else None
+    _call("ta_dim_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws), planes, size, resize, rnd, top, left)
+    if ws is not None:
+        _register_partials(gx, ws, per_image * tiles)
+    else:
+        _wrote(gx)
 
 
 def scale_copies_fwd(x, y, num_scale):
     n, e = _batch(x)
-    _check(load().ta_scale_copies_fwd(_ptr(x, name="x"), _ptr(y, name="y"), n, e, num_scale, _stream()),
-           "ta_scale_copies_fwd")
+    _wrote(y)
+    _call("ta_scale_copies_fwd", x, _ptr(x, name="x"), _ptr(y, name="y"), n, e, num_scale)
+
+
+def _image_sums(like, n, e):
+    slots = load().ta_update_tiles(e)
+    return _new_ws(like, n * slots), slots
 
 
 def scale_copies_bwd(gy, gx, num_scale):
     n, e = _batch(gx)
-    _check(load().ta_scale_copies_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, num_scale, _stream()),
-           "ta_scale_copies_bwd")
+    ws, slots = _image_sums(gx, n, e)
+    _call("ta_scale_copies_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws), n, e, num_scale)
+    _register_partials(gx, ws, slots)
 
 
 def sum_copies_bwd(gy, gx, copies):
     n, e = _batch(gx)
-    _check(load().ta_sum_copies_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, copies, _stream()),
-           "ta_sum_copies_bwd")
+    ws, slots = _image_sums(gx, n, e)
+    _call("ta_sum_copies_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws), n, e, copies)
+    _register_partials(gx, ws, slots)
 
 
 def admix_fwd(x, perm, y, num_admix, num_scale, strength):
     n, e = _batch(x)
-    _check(load().ta_admix_fwd(_ptr(x, name="x"), _ptr(perm, torch.int64, "perm"), _ptr(y, name="y"), n, e, num_admix,
-                               num_scale, float(strength), _stream()), "ta_admix_fwd")
+    _wrote(y)
+    _call("ta_admix_fwd", x, _ptr(x, name="x"), _ptr(perm, torch.int64, "perm"), _ptr(y, name="y"), n, e, num_admix,
+          num_scale, float(strength))
 
 
 def admix_bwd(gy, gx, num_admix, num_scale):
     n, e = _batch(gx)
-    _check(load().ta_admix_bwd(_ptr(gy, name="gy"), _ptr(gx, name="gx"), n, e, num_admix, num_scale, _stream()),
-           "ta_admix_bwd")
+    ws, slots = _image_sums(gx, n, e)
+    _call("ta_admix_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws), n, e, num_admix, num_scale)
+    _register_partials(gx, ws, slots)
+
+
+def sum_members(grads, gx):
+    """gx = ((g[m-1] + g[m-2]) + ...) + g[0] -- the members' input gradients of an EnsembleModel, in autograd's
+    accumulation order; registers the |gx| tile sums."""
+    m = len(grads)
+    n, e = _batch(gx)
+    ws, slots = _image_sums(gx, n, e)
+    ptrs = (ctypes.c_void_p * m)(*[_ptr(g, name="member gradient") for g in grads])
+    _call("ta_sum_members", gx, ptrs, m, _ptr(gx, name="gx"), _ptr(ws), n, e)
+    _register_partials(gx, ws, slots)
 
 
 def sia_fwd(x, plan, y, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
     h, w = x.shape[-2:]
-    _check(load().ta_sia_fwd(_ptr(x, name="x"), _ptr(plan, torch.int32, "plan"), _ptr(noise, name="noise"), _ptr(y, name="y"),
-                             x.numel() // (h * w), h, w, copies, num_block, float(noise_radius), seed, offset, _stream()),
-           "ta_sia_fwd")
+    _wrote(y)
+    _call("ta_sia_fwd", x, _ptr(x, name="x"), _ptr(plan, torch.int32, "plan"), _ptr(noise, name="noise"), _ptr(y, name="y"),
+          x.numel() // (h * w), h, w, copies, num_block, float(noise_radius), seed, offset)
 
 
 def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, noise=None):
     h, w = x.shape[-2:]
-    _check(load().ta_sia_bwd(_ptr(gy, name="gy"), _ptr(plan, torch.int32, "plan"), _ptr(x, name="x"), _ptr(noise, name="noise"),
-                             _ptr(gx, name="gx"), x.numel() // (h * w), h, w, copies, num_block, float(noise_radius), seed,
-                             offset, _stream()), "ta_sia_bwd")
+    _wrote(gx)
+    _call("ta_sia_bwd", gy, _ptr(gy, name="gy"), _ptr(plan, torch.int32, "plan"), _ptr(x, name="x"),
+          _ptr(noise, name="noise"), _ptr(gx, name="gx"), x.numel() // (h * w), h, w, copies, num_block,
+          float(noise_radius), seed, offset)
 
 
 # ---------------------------------------------------------------------------------------------- VMI / NI
 def vmi_neighbor(data, delta, out, radius, seed=0, offset=0, noise=None):
-    _check(load().ta_vmi_neighbor(_ptr(data, name="data"), _ptr(delta, name="delta"), _ptr(noise, name="noise"),
-                                  _ptr(out, name="out"), float(radius), seed, offset, data.numel(), _stream()),
-           "ta_vmi_neighbor")
+    _wrote(out)
+    _call("ta_vmi_neighbor", data, _ptr(data, name="data"), _ptr(delta, name="delta"), _ptr(noise, name="noise"),
+          _ptr(out, name="out"), float(radius), seed, offset, data.numel())
 
 
 def grad_accumulate(acc, grad, first):
-    _check(load().ta_grad_accumulate(_ptr(acc, name="acc"), _ptr(grad, name="grad"), 1 if first else 0, acc.numel(),
-                                     _stream()), "ta_grad_accumulate")
+    _wrote(acc)
+    _call("ta_grad_accumulate", acc, _ptr(acc, name="acc"), _ptr(grad, name="grad"), 1 if first else 0, acc.numel())
 
 
 def variance_finalize(acc, cur_grad, out, count):
-    _check(load().ta_variance_finalize(_ptr(acc, name="acc"), _ptr(cur_grad, name="grad"), _ptr(out, name="variance"),
-                                       float(count), acc.numel(), _stream()), "ta_variance_finalize")
+    _wrote(out)
+    _call("ta_variance_finalize", acc, _ptr(acc, name="acc"), _ptr(cur_grad, name="grad"), _ptr(out, name="variance"),
+          float(count), acc.numel())
 
 
 def axpy(x, m, coeff, out):
-    _check(load().ta_axpy(_ptr(x, name="x"), _ptr(m, name="momentum"), float(coeff), _ptr(out, name="out"), x.numel(),
-                          _stream()), "ta_axpy")
+    _wrote(out)
+    _call("ta_axpy", x, _ptr(x, name="x"), _ptr(m, name="momentum"), float(coeff), _ptr(out, name="out"), x.numel())
 
 
 # ------------------------------------------------------------------------------------------------- output
 def quantize_u8_nhwc(data, delta, out):
     n, c, h, w = data.shape
-    _check(load().ta_quantize_u8_nhwc(_ptr(data, name="data"), _ptr(delta, name="delta"),
-                                      _ptr(out, torch.uint8, "out"), n, c, h, w, _stream()), "ta_quantize_u8_nhwc")
+    _call("ta_quantize_u8_nhwc", data, _ptr(data, name="data"), _ptr(delta, name="delta"), _ptr(out, torch.uint8, "out"),
+          n, c, h, w)

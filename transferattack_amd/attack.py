@@ -11,9 +11,12 @@ Hook names, signatures, defaults and error behaviour are the reference's, so its
 
 What runs where: the surrogate forward/backward is PyTorch-ROCm (MIOpen / rocBLAS); ``get_momentum`` and
 ``update_delta`` are HIP kernels (``ta_momentum``, ``ta_update_delta_linf|l2``).  When a subclass overrides
-neither hook, ``forward`` replaces the pair by ONE fused launch sequence (``ta_mi_update``): per-image sum|g|,
-then momentum accumulate + sign + alpha-step + eps-ball + image-box in a single pass (24 B/element instead of
-the reference's 13 ATen kernels / ~116 B/element).  There is no CPU fallback: tensors must be on a HIP device.
+neither hook, ``forward`` replaces the pair by ONE fused launch (``ta_mi_update``): momentum accumulate + sign +
+alpha-step + eps-ball + image-box in a single pass that also writes ``data + delta`` for the next iteration
+(attack.py:88) -- 24 (+4) B/element instead of the reference's 13 ATen kernels / ~116 B/element.  The per-image
+sum|g| it needs comes from the kernel that wrote the gradient (``_hip`` partials registry), so g is read once.  With
+``decay == 0`` (FGSM, I-FGSM) the momentum is neither read nor stored (16 B/element).  There is no CPU fallback:
+tensors must be on a HIP device.
 """
 import os
 
@@ -24,11 +27,21 @@ from . import _hip, backbones
 from .utils import EnsembleModel, default_device, wrap_model, img_max, img_min, clamp  # noqa: F401
 
 
+class _AdvInput(torch.autograd.Function):
+    """``data + delta`` when the sum is already in memory (written by the fused update of the previous iteration):
+    hands out that buffer, the gradient flows to ``delta`` unchanged -- exactly AddBackward's behaviour."""
+
+    @staticmethod
+    def forward(ctx, delta, x_adv):
+        return x_adv.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class Attack(object):
     """Base class for all attacks (same constructor as transferattack/attack.py:12-38)."""
-
-    # set TA_SINGLE_LAUNCH_UPDATE=1 to use the single-launch variant of the fused update (ta_mi_update_fused)
-    single_launch_update = os.environ.get("TA_SINGLE_LAUNCH_UPDATE", "0") == "1"
 
     def __init__(self, attack, model_name, epsilon, targeted, random_start, norm, loss, device=None):
         if norm not in ['l2', 'linfty']:
@@ -87,12 +100,17 @@ class Attack(object):
         delta = self.init_delta(data)
         momentum = 0
         fused = self._can_fuse_update()
-        for _ in range(self.epoch):
-            logits = self.get_logits(self.transform(data + delta, momentum=momentum))
+        x_adv = None                      # data + delta as left behind by the fused update (bit-identical to the add)
+        for it in range(self.epoch):
+            x_in = data + delta if x_adv is None else _AdvInput.apply(delta, x_adv)
+            logits = self.get_logits(self.transform(x_in, momentum=momentum))
             loss = self.get_loss(logits, label)
             grad = self.get_grad(loss, delta)
             if fused:
-                momentum = self._fused_update(grad, momentum, delta, data)
+                if x_adv is None and it + 1 < self.epoch:
+                    x_adv = torch.empty_like(data)
+                momentum = self._fused_update(grad, momentum, delta, data,
+                                              x_adv=x_adv if it + 1 < self.epoch else None)
             else:
                 momentum = self.get_momentum(grad, momentum)
                 delta = self.update_delta(delta, data, momentum, self.alpha)
@@ -103,17 +121,23 @@ class Attack(object):
         return (self.norm == 'linfty' and cls.get_momentum is Attack.get_momentum
                 and cls.update_delta is Attack.update_delta and not isinstance(self.alpha, torch.Tensor))
 
-    def _fused_update(self, grad, momentum, delta, data, variance=None, alpha=None):
+    def _fused_update(self, grad, momentum, delta, data, variance=None, alpha=None, x_adv=None):
         """get_momentum + update_delta in one pass; ``delta`` (a leaf) is updated in place -- the graph of
-        this iteration has already been consumed by ``get_grad``.  Returns the new momentum tensor."""
+        this iteration has already been consumed by ``get_grad``.  Returns the new momentum (a tensor, or the
+        Python 0 it started as when ``decay == 0``: ``m*0 + g/mean|g|`` never looks at the old momentum, so it is
+        neither stored nor read back -- FGSM / I-FGSM move 16 B/element).  ``x_adv`` (optional buffer) receives
+        ``data + delta`` for the next iteration."""
         grad = grad.contiguous()
         m_in = momentum if isinstance(momentum, torch.Tensor) else None
-        m_out = m_in if m_in is not None else torch.empty_like(grad)
+        if self.decay == 0 and m_in is None:
+            m_out = None
+        else:
+            m_out = m_in if m_in is not None else torch.empty_like(grad)
         if variance is not None and not isinstance(variance, torch.Tensor):
             variance = None                                   # the Python 0 of the first VMI iteration
         _hip.mi_update(grad, m_in, m_out, delta.detach(), data, self.decay, self.alpha if alpha is None else alpha,
-                       self.epsilon, variance=variance, single_launch=self.single_launch_update)
-        return m_out
+                       self.epsilon, variance=variance, x_adv=x_adv)
+        return momentum if m_out is None else m_out
 
     # ------------------------------------------------------------------------------------------ hooks
     def get_logits(self, x, **kwargs):

@@ -10,8 +10,11 @@
 //   backward  four updates per output pixel in output order, acc = fma(ly*lx, g, acc)
 //             (cpu_upsample_linear_backward).  The gather visits, for one target pixel, exactly the
 //             updates that hit it, in that same order -> bit-identical accumulation.
-// The 1-D tap tables (and, for the backward, the inverse "which outputs touch this source index" ranges)
-// are rebuilt in LDS by every workgroup: <= 250 entries, cheaper than a host round trip per iteration.
+// Two kernel families: the lane-per-column kernels (dim_fwd_lanes_kernel / dim_bwd_lanes_kernel) cover every geometry
+// the reference can draw (resize <= 1.5 * size); the table-driven gathers (dim_fwd_kernel / dim_bwd_kernel) take the
+// rest (resize ratios up to ~2.4).  Same arithmetic, same bits.  The backward kernels also emit the per-tile sums of
+// |gx| (ws, nullable): when DIM's backward is the last kernel that writes the input gradient, the fused update reads
+// them instead of running its own pass over g (update.hip, K1).
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -39,7 +42,6 @@ constexpr int kDimMaxSide = 1024;       // LDS tables are sized for sides up to 
 
 // ---------------------------------------------------------------------------------------- forward
 constexpr int kDimFwdTile = 32;         // 32 x 32 outputs per workgroup, 4 per lane
-constexpr int kDimFwdVariantDefault = 0;
 constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of the padded image; resize/size <= ~2.4
 
 // Two stages through LDS: (1) the window of the zero-padded, rescaled image that this output tile touches is
@@ -47,7 +49,7 @@ constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of th
 // is evaluated once per tile instead of up to 4 times, and no intermediate ever reaches HBM.
 __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          int size, int resize, int rnd, int top, int left,
-                                                         int tiles_per_side, int xcd_major) {
+                                                         int tiles_per_side) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
     Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
     __syncthreads();
 
     const int tiles = tiles_per_side * tiles_per_side;
-    const unsigned tid = tile_id(xcd_major);
+    const unsigned tid = blockIdx.x;
     const int64_t plane = tid / tiles;
     const int t = tid % tiles;
     const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
@@ -98,90 +100,19 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_kernel(const float* __restrict
     }
 }
 
-// Separable form of the same forward (bit-identical: ATen's bilinear IS "width first, then height").  Four passes
-// over LDS-resident rectangles, each lane bound to one COLUMN so its horizontal tap pair lives in registers and the
-// vertical tap pair is wave-uniform: ~6 instructions per produced value instead of ~40, no div/mod by runtime sizes.
-//   H1  T[r][c]   = fma(lx0, x[r][i0], lx1 * x[r][i1])          rows of x behind the window, window columns
-//   V1  mid[p][c] = fma(ly0, T[i0][c], ly1 * T[i1][c])  (or 0)   the zero-padded, rescaled window
-//   H2  u[p][ox]  = fma(lx0, mid[p][i0], lx1 * mid[p][i1])       window rows, the tile's 32 output columns
-//   V2  y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
-__global__ __launch_bounds__(kBlock) void dim_fwd_sep_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             int size, int resize, int rnd, int top, int left,
-                                                             int tiles_per_side, int ws, int xcd_major) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Tap* t2 = reinterpret_cast<Tap*>(smem_raw);          // [size]   resize -> size   (second resample)
-    Tap* t1 = t2 + size;                                 // [rnd]    size -> rnd      (first resample)
-    float* T = reinterpret_cast<float*>(t1 + rnd);       // [ws][ws]
-    float* mid = T + ws * ws;                            // [ws][ws]
-    float* u = mid + ws * ws;                            // [ws][32]
-    for (int o = threadIdx.x; o < size; o += kBlock) t2[o] = make_tap(o, resize, size);
-    for (int o = threadIdx.x; o < rnd; o += kBlock) t1[o] = make_tap(o, size, rnd);
-    __syncthreads();
-
-    const int tiles = tiles_per_side * tiles_per_side;
-    const unsigned tid = tile_id(xcd_major);
-    const int64_t plane = tid / tiles;
-    const int t = tid % tiles;
-    const int oy0 = (t / tiles_per_side) * kDimFwdTile, ox0 = (t % tiles_per_side) * kDimFwdTile;
-    const int oy1 = min(oy0 + kDimFwdTile, size) - 1, ox1 = min(ox0 + kDimFwdTile, size) - 1;
-    const float* xp = x + plane * static_cast<int64_t>(size) * size;
-    float* yp = y + plane * static_cast<int64_t>(size) * size;
-    const int py_lo = t2[oy0].i0, py_hi = t2[oy1].i1, px_lo = t2[ox0].i0, px_hi = t2[ox1].i1;
-    const int mh = py_hi - py_lo + 1, mw = px_hi - px_lo + 1;                 // <= ws (host-checked)
-    // rows of the rescaled image inside the window, and the rows of x behind them
-    const int ry_a = max(py_lo - top, 0), ry_b = min(py_hi - top, rnd - 1);
-    const bool any_rows = ry_a <= ry_b;
-    const int sr_lo = any_rows ? t1[ry_a].i0 : 0;
-    const int sh = any_rows ? t1[ry_b].i1 - sr_lo + 1 : 0;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rx = px_lo + lane - left;
-    const bool col_ok = lane < mw && rx >= 0 && rx < rnd;
-    Tap tx{0, 0, 0.f, 0.f};
-    if (col_ok) tx = t1[rx];
-
-    if (col_ok)                                                               // H1
-        for (int r = wave; r < sh; r += kBlock / 64) {
-            const float* row = xp + (sr_lo + r) * size;
-            T[r * ws + lane] = fmaf(tx.l0, row[tx.i0], tx.l1 * row[tx.i1]);
-        }
-    __syncthreads();
-    if (lane < mw)                                                            // V1
-        for (int p = wave; p < mh; p += kBlock / 64) {
-            const int ry = py_lo + p - top;
-            float val = 0.0f;                                                 // the zero padding of dim.py:65
-            if (col_ok && ry >= 0 && ry < rnd) {
-                const Tap ty = t1[ry];
-                val = fmaf(ty.l0, T[(ty.i0 - sr_lo) * ws + lane], ty.l1 * T[(ty.i1 - sr_lo) * ws + lane]);
-            }
-            mid[p * ws + lane] = val;
-        }
-    __syncthreads();
-    const int ox = threadIdx.x & 31, grp = threadIdx.x >> 5;                  // 8 row groups x 32 output columns
-    const bool out_col = ox0 + ox <= ox1;
-    if (out_col) {                                                            // H2
-        const Tap tx2 = t2[ox0 + ox];
-        for (int p = grp; p < mh; p += kBlock / 32)
-            u[p * 32 + ox] = fmaf(tx2.l0, mid[p * ws + tx2.i0 - px_lo], tx2.l1 * mid[p * ws + tx2.i1 - px_lo]);
-    }
-    __syncthreads();
-    if (out_col)                                                              // V2
-        for (int ly = grp; oy0 + ly <= oy1; ly += kBlock / 32) {
-            const Tap ty2 = t2[oy0 + ly];
-            yp[(oy0 + ly) * size + ox0 + ox] =
-                fmaf(ty2.l0, u[(ty2.i0 - py_lo) * 32 + ox], ty2.l1 * u[(ty2.i1 - py_lo) * 32 + ox]);
-        }
-}
-
-// Lane-per-column form of the separable forward (TA_DIM_FWD_VARIANT=2), written for instruction count: the shipped
-// gather spends ~190 instructions per output pixel (per-workgroup rebuild of all 460 taps, div/mod by the runtime window
+// Lane-per-column separable forward (bit-identical: ATen's bilinear IS "width first, then height"), written for
+// instruction count: the table-driven gather above spends ~190 instructions per output pixel (per-workgroup rebuild of all 460 taps, div/mod by the runtime window
 // width, 64-bit addressing), and its measured time is what instruction issue alone predicts.  Here
 //   * a tile is THO=32 output rows x `tw` (<= 64) output columns, `tw` chosen on the host so that the window of the
 //     padded image behind it is at most 64 columns wide: one LANE per window column, all four passes run over rows;
 //   * every lane builds only its own two column taps (registers) and at most one row tap (LDS); the two divisions
 //     in/out are done once on the host (same IEEE single division);
 //   * the x rows behind the window are fetched with all loads of a lane issued back to back (RPW rows per wave).
-// Arithmetic and rounding order are those of dim_fwd_sep_kernel / ATen (width first, then height) -> bit-identical.
+// Arithmetic and rounding order are ATen's (width first, then height) -> bit-identical to dim_fwd_kernel.
+//   H1  T[r][c]   = fma(lx0, x[r][i0], lx1 * x[r][i1])          rows of x behind the window, window columns
+//   V1  mid[p][c] = fma(ly0, T[i0][c], ly1 * T[i1][c])  (or 0)   the zero-padded, rescaled window
+//   H2  u[p][ox]  = fma(lx0, mid[p][i0], lx1 * mid[p][i1])       window rows, the tile's output columns
+//   V2  y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
 constexpr int kDimLaneRows = 32;        // THO
 
 __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) {
@@ -198,7 +129,7 @@ template <int RPW>                      // rows per wave of the LDS rectangles: 
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int xcd_major) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
     __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
@@ -209,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
     const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(tile_id(xcd_major));
+    const int tid = static_cast<int>(blockIdx.x);
     const int plane = tid / tiles;                                     // grid < 2^31 (host-checked)
     const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
@@ -310,7 +241,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
 
 // --------------------------------------------------------------------------------------- backward
 constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
-constexpr int kDimBwdVariantDefault = 0;
 constexpr int kDimBwdMaxMid = 80;       // side of the LDS-resident window of d(rescaled); rate <= ~2.4
 
 struct Range {
@@ -318,8 +248,9 @@ struct Range {
 };
 
 __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                         int size, int resize, int rnd, int top, int left,
-                                                         int tiles_per_side, int xcd_major) {
+                                                         float* __restrict__ ws, int size, int resize, int rnd, int top,
+                                                         int left, int tiles_per_side) {
+    __shared__ float red[kBlock / kWave];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Tap* t2 = reinterpret_cast<Tap*>(smem_raw);                  // [size]    out pixel  -> padded index
     Tap* t1 = t2 + size;                                         // [rnd]     rescaled   -> x index
@@ -349,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
     __syncthreads();
 
     const int tiles = tiles_per_side * tiles_per_side;
-    const unsigned tid = tile_id(xcd_major);
+    const unsigned tid = blockIdx.x;
     const int64_t plane = tid / tiles;
     const int t = tid % tiles;
     const int iy0 = (t / tiles_per_side) * kDimBwdTile, ix0 = (t % tiles_per_side) * kDimBwdTile;
@@ -390,6 +321,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
     __syncthreads();
 
     // stage B: gx[iy][ix] = gather over the rescaled pixels touching it
+    float asum = 0.0f;
 #pragma unroll
     for (int u = 0; u < kDimBwdTile * kDimBwdTile / kBlock; ++u) {
         const int local = u * kBlock + threadIdx.x;
@@ -414,11 +346,14 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_kernel(const float* __restrict
             }
         }
         gxp[static_cast<int64_t>(iy) * size + ix] = acc;
+        asum += fabsf(acc);
     }
+    const float total = block_sum(asum, red);
+    if (ws != nullptr && threadIdx.x == 0) ws[tid] = total;
 }
 
 
-// Lane-per-column form of the backward (TA_DIM_BWD_VARIANT=1), the counterpart of dim_fwd_lanes_kernel.  The adjoint
+// Lane-per-column form of the backward, the counterpart of dim_fwd_lanes_kernel.  The adjoint
 // cannot be made separable without changing the rounding (ATen accumulates fma(ly*lx, g, acc) over the output pixels in
 // row-major order), so both stages stay 2-D gathers in that order -- but the bookkeeping changes:
 //   * the outputs that touch one source index form a contiguous run o = first .. first+n-1 (taps are monotone), n <= 3
@@ -502,22 +437,24 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     return acc;
 }
 
-template <int RPW>
+template <int RPW, int SB>              // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels)
 __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                               int size, int resize, int rnd, int top, int left,
+                                                               float* __restrict__ ws, int size, int resize, int rnd,
+                                                               int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int xcd_major) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
     __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
     __shared__ __attribute__((aligned(16))) Hit colA[64];               // window column px -> output columns
     __shared__ __attribute__((aligned(16))) Hit rowA[ROWS];             // window row py    -> output rows
     __shared__ __attribute__((aligned(16))) float mid[ROWS * 64];       // d(rescaled) window
+    __shared__ float red[kBlock / kWave];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(tile_id(xcd_major));
+    const int tid = static_cast<int>(blockIdx.x);
     const int plane = tid / tiles;
     const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
@@ -600,12 +537,14 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     }
     __syncthreads();
     // -- stage B: gx[iy][ix]
+    float asum = 0.0f;
+    Hit hx = colB[lane < twc ? lane : 0];
+    if (lane >= twc) hx.both = 0u;
+    const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;     // all lanes of the wave vote
     if (lane < twc) {
-        const Hit hx = colB[lane];
-        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        int col[kHitSlots];
+        int col[SB];
 #pragma unroll
-        for (int k = 0; k < kHitSlots; ++k) col[k] = min(hx.first - rx_lo + k, 63);
+        for (int k = 0; k < SB; ++k) col[k] = min(hx.first - rx_lo + k, 63);
         unsigned out = static_cast<unsigned>((iy0 + wave) * size + ix0 + lane) * 4u;
         const unsigned bstep = 16u * static_cast<unsigned>(size);
 #pragma unroll 1
@@ -617,26 +556,29 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
             float acc = 0.0f;
             if (!any_both_x && both_y == 0u) {
 #pragma unroll
-                for (int ky = 0; ky < kHitSlots; ++ky)
+                for (int ky = 0; ky < SB; ++ky)
                     if (ky < n_y) {
                         const float* mrow = mid + (first_y + ky) * 64;
 #pragma unroll
-                        for (int kx = 0; kx < kHitSlots; ++kx)
+                        for (int kx = 0; kx < SB; ++kx)
                             acc = hit_accumulate<true>(acc, mrow[col[kx]], hy->w[ky], 0.0f, false, hx, kx);
                     }
             } else {
 #pragma unroll
-                for (int ky = 0; ky < kHitSlots; ++ky)
+                for (int ky = 0; ky < SB; ++ky)
                     if (ky < n_y) {
                         const float* mrow = mid + (first_y + ky) * 64;
 #pragma unroll
-                        for (int kx = 0; kx < kHitSlots; ++kx)
+                        for (int kx = 0; kx < SB; ++kx)
                             acc = hit_accumulate<false>(acc, mrow[col[kx]], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
                     }
             }
             *reinterpret_cast<float*>(gxp + out) = acc;
+            asum += fabsf(acc);
         }
     }
+    const float total = block_sum(asum, red);
+    if (ws != nullptr && threadIdx.x == 0) ws[tid] = total;
 }
 
 }  // namespace ta
@@ -650,23 +592,46 @@ static int check_geom(int64_t planes, int size, int resize, int rnd, int top, in
     return 0;
 }
 
+// largest number of outputs of a 1-D resample (in_size -> out_size) that touch one source index; same fp32 arithmetic as
+// the kernels' make_tap (fmaf is the exact fused operation on the host as well)
+static int max_hits(int in_size, int out_size) {
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    int count[kDimMaxSide] = {0};                       // in_size <= kDimMaxSide (check_geom)
+    for (int o = 0; o < out_size; ++o) {
+        float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
+        src = src < 0.0f ? 0.0f : src;
+        int i0 = static_cast<int>(src);
+        i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+        const int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+        ++count[i0];
+        if (i1 != i0) ++count[i1];
+    }
+    int best = 0;
+    for (int i = 0; i < in_size; ++i) best = count[i] > best ? count[i] : best;
+    return best;
+}
+
+static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
+    if (size <= 0 || resize <= 0) return 0;
+    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+        const double up = static_cast<double>(resize) / size;
+        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
+        const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
+        if (tw >= 8 && rows <= 68) return ceil_div(size, tw) * ceil_div(size, kDimLaneRows);
+    }
+    const int64_t tps = ceil_div(size, kDimBwdTile);
+    return tps * tps;
+}
+
+extern "C" int64_t ta_dim_bwd_tiles(int size, int resize) { return ta_dim_bwd_tiles_impl(size, resize); }
+
 extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top, int left,
                           void* stream) {
     TA_REQUIRE(x && y && x != y, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
-    const int tps = static_cast<int>(ceil_div(size, kDimFwdTile));
-    const int64_t blocks = planes * tps * tps;
-    TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
-    // a 32-pixel output tile reads at most this many padded pixels per axis
-    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimFwdTile) * resize, size)) + 3;
-    TA_REQUIRE(mid_side <= kDimFwdMaxMid, "resize ratio %d/%d too large for the fused forward", resize, size);
-    // TA_DIM_FWD_VARIANT (tuning knob): 0 = 16-tap gather per window pixel, 1 = separable four-pass form,
-    // 2 = separable, one lane per window column (falls back to 0 for resize ratios above ~2)
-    static const int variant = []() {
-        const char* e = getenv("TA_DIM_FWD_VARIANT");
-        return e == nullptr ? kDimFwdVariantDefault : atoi(e);
-    }();
-    if (variant == 2 && static_cast<int64_t>(size) * size < (1ll << 30)) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // lane-per-column kernel: every geometry with resize <= ~2 * size (all the reference draws: resize_rate 1.1)
+    if (static_cast<int64_t>(size) * size < (1ll << 30)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double ratio = static_cast<double>(resize) / size;
@@ -678,41 +643,35 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             if (rows <= 40)
-                hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             else
-                hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, y,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             return check_launch("dim_fwd_lanes");
         }
     }
-    if (variant == 1 && mid_side <= 64 && static_cast<int64_t>(size) * size < (1ll << 31)) {
-        const int ws = mid_side + 1;                     // the x rectangle can be one row taller than the window
-        const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * (2 * ws * ws + ws * 32);
-        hipLaunchKernelGGL(dim_fwd_sep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                           static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, ws, xcd_major_tiles());
-        return check_launch("dim_fwd_sep");
-    }
+    // table-driven gather: resize ratios up to ~2.4
+    const int tps = static_cast<int>(ceil_div(size, kDimFwdTile));
+    const int64_t blocks = planes * tps * tps;
+    TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
+    // a 32-pixel output tile reads at most this many padded pixels per axis
+    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimFwdTile) * resize, size)) + 3;
+    TA_REQUIRE(mid_side <= kDimFwdMaxMid, "resize ratio %d/%d too large for the fused forward", resize, size);
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(float) * mid_side * mid_side;
-    hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                       static_cast<hipStream_t>(stream), x, y, size, resize, rnd, top, left, tps, xcd_major_tiles());
+    hipLaunchKernelGGL(dim_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem, st, x, y, size, resize, rnd,
+                       top, left, tps);
     return check_launch("dim_fwd");
 }
 
-extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, int resize, int rnd, int top, int left,
-                          void* stream) {
+extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
+                          int left, void* stream) {
     TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
-    // a 32-pixel tile of x (plus one neighbour each side) is fed by at most this many rescaled pixels per axis
-    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimBwdTile + 2) * rnd, size)) + 3;
-    TA_REQUIRE(mid_side <= kDimBwdMaxMid, "resize ratio %d/%d too large for the fused backward", rnd, size);
-    // TA_DIM_BWD_VARIANT (tuning knob): 0 = table-driven gather, 1 = lane-per-column gather (needs resize > size,
-    // resize <= 1.5 * size and < 2^28 elements per plane; otherwise 0 runs)
-    static const int bwd_variant = []() {
-        const char* e = getenv("TA_DIM_BWD_VARIANT");
-        return e == nullptr ? kDimBwdVariantDefault : atoi(e);
-    }();
-    if (bwd_variant == 1 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // lane-per-column gather: resize > size, resize <= 1.5 * size and < 2^28 elements per plane (the choice depends on
+    // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives)
+    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double up = static_cast<double>(resize) / size;                          // bound for rnd / size
@@ -723,22 +682,26 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, int64_t planes, int size, 
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-            if (rows <= 40)
-                hipLaunchKernelGGL(dim_bwd_lanes_kernel<10>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
-            else
-                hipLaunchKernelGGL(dim_bwd_lanes_kernel<17>, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), gy, gx,
-                                   size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, xcd_major_tiles());
+            const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
+#define TA_DIM_BWD(RPW, SB)                                                                                          \
+    hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
+                       left, scale1, scale2, tw, tiles_x, tiles_y)
+            if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }
+            else { if (three) TA_DIM_BWD(17, 3); else TA_DIM_BWD(17, 4); }
+#undef TA_DIM_BWD
             return check_launch("dim_bwd_lanes");
         }
     }
+    // a 32-pixel tile of x (plus one neighbour each side) is fed by at most this many rescaled pixels per axis
+    const int mid_side = static_cast<int>(ceil_div(static_cast<int64_t>(kDimBwdTile + 2) * rnd, size)) + 3;
+    TA_REQUIRE(mid_side <= kDimBwdMaxMid, "resize ratio %d/%d too large for the fused backward", rnd, size);
     const int tps = static_cast<int>(ceil_div(size, kDimBwdTile));
     const int64_t blocks = planes * tps * tps;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
     // LDS is sized for the window this geometry needs (not the 80 x 80 worst case): ~18 KB at 224/246 -> 8 workgroups/CU
     const size_t smem = sizeof(Tap) * (static_cast<size_t>(size) + rnd) + sizeof(Range) * (static_cast<size_t>(resize) + size) +
                         sizeof(float) * mid_side * mid_side;
-    hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem,
-                       static_cast<hipStream_t>(stream), gy, gx, size, resize, rnd, top, left, tps, xcd_major_tiles());
+    hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem, st, gy, gx, ws, size, resize,
+                       rnd, top, left, tps);
     return check_launch("dim_bwd");
 }

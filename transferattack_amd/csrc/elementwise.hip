@@ -53,12 +53,28 @@ __global__ __launch_bounds__(kBlock) void scale_copies_fwd_kernel(const float* _
     });
 }
 
+// The backward kernels below run one image per blockIdx.y (tiles of 3072 elements, K1's layout) and also emit the
+// per-tile sums of |gx| (ws, nullable): when one of them is the last kernel that writes the input gradient, the fused
+// update takes mean|g| from these sums and reads g once.
+// same per-thread order as abs_sum_partials_kernel (K1): the sums carry K1's bits
+__device__ __forceinline__ void add_abs4(float& asum, float4 a) {
+    asum += fabsf(a.x); asum += fabsf(a.y); asum += fabsf(a.z); asum += fabsf(a.w);
+}
+__device__ __forceinline__ void emit_tile_sum(float asum, float* __restrict__ ws, float* red) {
+    const float total = block_sum(asum, red);
+    if (ws != nullptr && threadIdx.x == 0) ws[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = total;
+}
+
 // gx = sum_i gy_i / 2^i accumulated i = num_scale-1 .. 0 (the order autograd's input buffer sees)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void scale_copies_bwd_kernel(const float* __restrict__ gy,
-                                                                  float* __restrict__ gx, int64_t ne,
-                                                                  int num_scale) {
-    for_tile<VEC>(ne, [&](int64_t i, auto vec) {
+                                                                  float* __restrict__ gx, float* __restrict__ ws,
+                                                                  int64_t ne, int64_t e, int num_scale) {
+    __shared__ float red[kBlock / kWave];
+    const int64_t img0 = static_cast<int64_t>(blockIdx.y) * e;
+    float asum = 0.0f;
+    for_tile<VEC>(e, [&](int64_t ii, auto vec) {
+        const int64_t i = img0 + ii;
         const float top = ldexpf(1.0f, -(num_scale - 1));
         if constexpr (decltype(vec)::value) {
             float s = top;
@@ -68,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void scale_copies_bwd_kernel(const float* _
                 acc = add4(acc, scale4(ld4(gy + c * ne + i), s));
             }
             st4(gx + i, acc);
+            add_abs4(asum, acc);
         } else {
             float s = top;
             float acc = gy[(num_scale - 1) * ne + i] * s;
@@ -76,26 +93,65 @@ __global__ __launch_bounds__(kBlock) void scale_copies_bwd_kernel(const float* _
                 acc += gy[c * ne + i] * s;
             }
             gx[i] = acc;
+            asum += fabsf(acc);
         }
     });
+    emit_tile_sum(asum, ws, red);
 }
 
 // gx = sum_i gy_i accumulated i = copies-1 .. 0: backward of a stack of `copies` unit-gain views of x
 // (EMI-FGSM's sample stack, emifgsm.py:57-58), in the order autograd's input buffer adds them
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void sum_copies_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                int64_t ne, int copies) {
-    for_tile<VEC>(ne, [&](int64_t i, auto vec) {
+                                                                float* __restrict__ ws, int64_t ne, int64_t e, int copies) {
+    __shared__ float red[kBlock / kWave];
+    const int64_t img0 = static_cast<int64_t>(blockIdx.y) * e;
+    float asum = 0.0f;
+    for_tile<VEC>(e, [&](int64_t ii, auto vec) {
+        const int64_t i = img0 + ii;
         if constexpr (decltype(vec)::value) {
             float4 acc = ld4(gy + (copies - 1) * ne + i);
             for (int c = copies - 2; c >= 0; --c) acc = add4(acc, ld4(gy + c * ne + i));
             st4(gx + i, acc);
+            add_abs4(asum, acc);
         } else {
             float acc = gy[(copies - 1) * ne + i];
             for (int c = copies - 2; c >= 0; --c) acc += gy[c * ne + i];
             gx[i] = acc;
+            asum += fabsf(acc);
         }
     });
+    emit_tile_sum(asum, ws, red);
+}
+
+// gx = ((g[m-1] + g[m-2]) + ...) + g[0]: the members' input gradients of an EnsembleModel (utils.py:98-99: the same x
+// feeds every member), added in the order autograd's input buffer receives them (last member first)
+constexpr int kMaxMembers = 8;
+struct MemberPtrs {
+    const float* p[kMaxMembers];
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void sum_members_kernel(MemberPtrs gs, int m, float* __restrict__ gx,
+                                                             float* __restrict__ ws, int64_t e) {
+    __shared__ float red[kBlock / kWave];
+    const int64_t img0 = static_cast<int64_t>(blockIdx.y) * e;
+    float asum = 0.0f;
+    for_tile<VEC>(e, [&](int64_t ii, auto vec) {
+        const int64_t i = img0 + ii;
+        if constexpr (decltype(vec)::value) {
+            float4 acc = ld4(gs.p[m - 1] + i);
+            for (int c = m - 2; c >= 0; --c) acc = add4(acc, ld4(gs.p[c] + i));
+            st4(gx + i, acc);
+            add_abs4(asum, acc);
+        } else {
+            float acc = gs.p[m - 1][i];
+            for (int c = m - 2; c >= 0; --c) acc += gs.p[c][i];
+            gx[i] = acc;
+            asum += fabsf(acc);
+        }
+    });
+    emit_tile_sum(asum, ws, red);
 }
 
 // ---- Admix --------------------------------------------------------------------------------------
@@ -129,10 +185,12 @@ __global__ __launch_bounds__(kBlock) void admix_fwd_kernel(const float* __restri
 // gx[b] = sum over j = num_admix-1..0 of ( sum over i = num_scale-1..0 of gy[i][j][b] / 2^i )
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void admix_bwd_kernel(const float* __restrict__ gy,
-                                                           float* __restrict__ gx, int64_t n, int64_t e,
-                                                           int num_admix, int num_scale) {
+                                                           float* __restrict__ gx, float* __restrict__ ws,
+                                                           int64_t n, int64_t e, int num_admix, int num_scale) {
+    __shared__ float red[kBlock / kWave];
     const int64_t b = blockIdx.y;
     const float top = ldexpf(1.0f, -(num_scale - 1));
+    float asum = 0.0f;
     for_tile<VEC>(e, [&](int64_t i, auto vec) {
         if constexpr (decltype(vec)::value) {
             float4 total;
@@ -146,6 +204,7 @@ __global__ __launch_bounds__(kBlock) void admix_bwd_kernel(const float* __restri
                 total = (j == num_admix - 1) ? acc : add4(total, acc);
             }
             st4(gx + b * e + i, total);
+            add_abs4(asum, total);
         } else {
             float total = 0.0f;
             for (int j = num_admix - 1; j >= 0; --j) {
@@ -158,8 +217,10 @@ __global__ __launch_bounds__(kBlock) void admix_bwd_kernel(const float* __restri
                 total = (j == num_admix - 1) ? acc : total + acc;
             }
             gx[b * e + i] = total;
+            asum += fabsf(total);
         }
     });
+    emit_tile_sum(asum, ws, red);
 }
 
 // ---- VMI / NI / init ----------------------------------------------------------------------------
@@ -300,26 +361,46 @@ extern "C" int ta_scale_copies_fwd(const float* x, float* y, int64_t n, int64_t 
     return check_launch("scale_copies_fwd");
 }
 
-extern "C" int ta_scale_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_scale, void* stream) {
-    TA_REQUIRE(gy && gx && n > 0 && e > 0 && num_scale > 0 && num_scale < 31, "bad arguments");
+#define TA_IMAGE_GRID(n, e) dim3(static_cast<unsigned>(ceil_div((e), kTile)), static_cast<unsigned>(n))
+
+extern "C" int ta_scale_copies_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int num_scale,
+                                   void* stream) {
+    TA_REQUIRE(gy && gx && n > 0 && n <= 65535 && e > 0 && num_scale > 0 && num_scale < 31, "bad arguments");
     const int64_t ne = n * e;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ne % 4 == 0 && all16({gy, gx}))
-        hipLaunchKernelGGL(scale_copies_bwd_kernel<true>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, num_scale);
+    if (e % 4 == 0 && all16({gy, gx}))
+        hipLaunchKernelGGL(scale_copies_bwd_kernel<true>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, gy, gx, ws, ne, e, num_scale);
     else
-        hipLaunchKernelGGL(scale_copies_bwd_kernel<false>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, num_scale);
+        hipLaunchKernelGGL(scale_copies_bwd_kernel<false>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, gy, gx, ws, ne, e, num_scale);
     return check_launch("scale_copies_bwd");
 }
 
-extern "C" int ta_sum_copies_bwd(const float* gy, float* gx, int64_t n, int64_t e, int copies, void* stream) {
-    TA_REQUIRE(gy && gx && n > 0 && e > 0 && copies > 0, "bad arguments");
+extern "C" int ta_sum_copies_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int copies, void* stream) {
+    TA_REQUIRE(gy && gx && n > 0 && n <= 65535 && e > 0 && copies > 0, "bad arguments");
     const int64_t ne = n * e;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ne % 4 == 0 && all16({gy, gx}))
-        hipLaunchKernelGGL(sum_copies_bwd_kernel<true>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, copies);
+    if (e % 4 == 0 && all16({gy, gx}))
+        hipLaunchKernelGGL(sum_copies_bwd_kernel<true>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, gy, gx, ws, ne, e, copies);
     else
-        hipLaunchKernelGGL(sum_copies_bwd_kernel<false>, TA_FLAT_GRID(ne), dim3(kBlock), 0, st, gy, gx, ne, copies);
+        hipLaunchKernelGGL(sum_copies_bwd_kernel<false>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, gy, gx, ws, ne, e, copies);
     return check_launch("sum_copies_bwd");
+}
+
+extern "C" int ta_sum_members(const float* const* gs, int m, float* gx, float* ws, int64_t n, int64_t e, void* stream) {
+    TA_REQUIRE(gs && gx && m >= 1 && m <= kMaxMembers && n > 0 && n <= 65535 && e > 0, "bad arguments (1 <= m <= 8)");
+    MemberPtrs ptrs;
+    bool vec = e % 4 == 0 && aligned16(gx);
+    for (int k = 0; k < kMaxMembers; ++k) {
+        ptrs.p[k] = k < m ? gs[k] : nullptr;
+        TA_REQUIRE(k >= m || gs[k] != nullptr, "null member gradient");
+        vec = vec && (k >= m || aligned16(gs[k]));
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec)
+        hipLaunchKernelGGL(sum_members_kernel<true>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, ptrs, m, gx, ws, e);
+    else
+        hipLaunchKernelGGL(sum_members_kernel<false>, TA_IMAGE_GRID(n, e), dim3(kBlock), 0, st, ptrs, m, gx, ws, e);
+    return check_launch("sum_members");
 }
 
 extern "C" int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64_t n, int64_t e, int num_admix,
@@ -335,16 +416,16 @@ extern "C" int ta_admix_fwd(const float* x, const int64_t* perm, float* y, int64
     return check_launch("admix_fwd");
 }
 
-extern "C" int ta_admix_bwd(const float* gy, float* gx, int64_t n, int64_t e, int num_admix, int num_scale,
+extern "C" int ta_admix_bwd(const float* gy, float* gx, float* ws, int64_t n, int64_t e, int num_admix, int num_scale,
                             void* stream) {
     TA_REQUIRE(gy && gx && n > 0 && n <= 65535 && e > 0 && num_admix > 0 && num_scale > 0 && num_scale < 31,
                "bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
     if (e % 4 == 0 && all16({gy, gx}))
-        hipLaunchKernelGGL(admix_bwd_kernel<true>, grid, dim3(kBlock), 0, st, gy, gx, n, e, num_admix, num_scale);
+        hipLaunchKernelGGL(admix_bwd_kernel<true>, grid, dim3(kBlock), 0, st, gy, gx, ws, n, e, num_admix, num_scale);
     else
-        hipLaunchKernelGGL(admix_bwd_kernel<false>, grid, dim3(kBlock), 0, st, gy, gx, n, e, num_admix, num_scale);
+        hipLaunchKernelGGL(admix_bwd_kernel<false>, grid, dim3(kBlock), 0, st, gy, gx, ws, n, e, num_admix, num_scale);
     return check_launch("admix_bwd");
 }
 

@@ -23,14 +23,6 @@ int check_launch(const char* what) {
     return 0;
 }
 
-int xcd_major_tiles() {
-    static const int on = []() {
-        const char* e = getenv("TA_XCD_MAJOR_TILES");
-        return e != nullptr && atoi(e) != 0 ? 1 : 0;
-    }();
-    return on;
-}
-
 }  // namespace ta
 
 extern "C" int ta_abi_version(void) { return TA_ABI_VERSION; }

@@ -15,7 +15,6 @@ constexpr int kTile = kBlock * kVec * kUnroll;   // 3072 elements per workgroup 
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
-int xcd_major_tiles();       // TA_XCD_MAJOR_TILES (tuning knob, read once): 1 = tile kernels walk the tiles XCD-major
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -39,18 +38,6 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
     for (int w = 1; w < kBlock / kWave; ++w) t += lds[w];
     __syncthreads();
     return t;
-}
-
-// Tile kernels: which tile this workgroup works on.  The hardware deals consecutive workgroup ids round-robin over the
-// 8 XCDs (each with its own L2), so neighbouring tiles of a plane -- which share halo rows -- land on 8 different L2s.
-// With `xcd_major` the ids are re-read XCD-major: the workgroups of XCD k take the k-th contiguous eighth of the tiles,
-// so neighbours share an L2.  A bijection on the first 8 * (n / 8) ids; the tail keeps its ids.
-constexpr int kXcds = 8;
-__device__ __forceinline__ unsigned tile_id(int xcd_major) {
-    const unsigned id = blockIdx.x, n = gridDim.x;
-    const unsigned per = n / kXcds;
-    if (!xcd_major || id >= per * kXcds) return id;
-    return (id % kXcds) * per + id / kXcds;
 }
 
 __device__ __forceinline__ float sign_of(float m) {   // torch.sign: NaN -> 0, +-0 -> 0

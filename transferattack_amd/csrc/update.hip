@@ -1,7 +1,7 @@
 // Update stack of the iterative FGSM loop for gfx950 (MI355X):
 //   K1  per-image sum|g|            (reference: grad.abs().mean(dim=(1,2,3)), attack.py:128)
-//   K2  fused momentum + sign + alpha-step + eps-ball projection + image-box clamp
-//                                    (reference: attack.py:124-128 and 145-153, utils.py:68-69)
+//   K2  fused momentum + sign + alpha-step + eps-ball projection + image-box clamp (+ x_adv = x + delta' for the
+//       next iteration)             (reference: attack.py:124-128 and 145-153, utils.py:68-69, attack.py:88)
 // Both kernels tile an image into 3072-element workgroup tiles (150528 = 49 tiles): every lane keeps
 // three 16-byte accesses per operand in flight, consecutive lanes touch consecutive 16 B (1 KiB per
 // wave instruction).  K1 and K2 use the same (tile, image) -> blockIdx map so the second read of g
@@ -383,10 +383,22 @@ __global__ __launch_bounds__(kBlock) void l2_step_kernel(const float* delta_in,
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
-        for (int64_t i = off; i < left && i < off + VEC; ++i) {
-            const float d = delta_in[base + i] + (g[base + i] / gnorm) * alpha;
-            delta_out[base + i] = d;
-            acc += d * d;
+        if (off + VEC <= left) {
+            Pack<VEC> pd, pg, od;
+            pd.load(delta_in + base + off);
+            pg.load(g + base + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                od[k] = pd[k] + (pg[k] / gnorm) * alpha;
+                acc += od[k] * od[k];
+            }
+            od.store(delta_out + base + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < left && i < off + VEC; ++i) {
+                const float d = delta_in[base + i] + (g[base + i] / gnorm) * alpha;
+                delta_out[base + i] = d;
+                acc += d * d;
+            }
         }
     }
     const float total = block_sum(acc, lds);
@@ -407,11 +419,24 @@ __global__ __launch_bounds__(kBlock) void l2_renorm_kernel(float* delta, const f
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
-        for (int64_t i = off; i < left && i < off + VEC; ++i) {
-            float d = delta[base + i];
-            if (norm > eps) d = d * scale;
-            const float xx = x[base + i];
-            delta[base + i] = fminf(fmaxf(d, 0.0f - xx), 1.0f - xx);
+        if (off + VEC <= left) {
+            Pack<VEC> pd, px, od;
+            pd.load(delta + base + off);
+            px.load(x + base + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float d = pd[k];
+                if (norm > eps) d = d * scale;
+                od[k] = fminf(fmaxf(d, 0.0f - px[k]), 1.0f - px[k]);
+            }
+            od.store(delta + base + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < left && i < off + VEC; ++i) {
+                float d = delta[base + i];
+                if (norm > eps) d = d * scale;
+                const float xx = x[base + i];
+                delta[base + i] = fminf(fmaxf(d, 0.0f - xx), 1.0f - xx);
+            }
         }
     }
 }
@@ -470,6 +495,8 @@ static int check_batch(int64_t n, int64_t e) {
     TA_REQUIRE(ceil_div(e, kTile) < (1ll << 31), "image too large");
     return 0;
 }
+
+extern "C" int64_t ta_update_tiles(int64_t e) { return e > 0 ? ceil_div(e, kTile) : 0; }
 
 extern "C" int64_t ta_l1_workspace_floats(int64_t n, int64_t e) {
     if (n <= 0 || e <= 0) return 0;
@@ -538,10 +565,16 @@ extern "C" int ta_update_delta_l2(const float* delta_in, const float* x, const f
     float* ws_d2 = ws + n * tiles;
     if (int rc = launch_partials(g, nullptr, ws_g2, n, e, true, st)) return rc;
     const dim3 grid(tiles, static_cast<unsigned>(n));
-    hipLaunchKernelGGL((l2_step_kernel<1>), grid, dim3(kBlock), 0, st, delta_in, g, delta_out, ws_g2, ws_d2,
-                       alpha, e, tiles);
+    const bool vec = vec_ok(e, {delta_in, x, g, delta_out});
+    if (vec)
+        hipLaunchKernelGGL((l2_step_kernel<4>), grid, dim3(kBlock), 0, st, delta_in, g, delta_out, ws_g2, ws_d2, alpha, e, tiles);
+    else
+        hipLaunchKernelGGL((l2_step_kernel<1>), grid, dim3(kBlock), 0, st, delta_in, g, delta_out, ws_g2, ws_d2, alpha, e, tiles);
     if (int rc = check_launch("l2_step")) return rc;
-    hipLaunchKernelGGL((l2_renorm_kernel<1>), grid, dim3(kBlock), 0, st, delta_out, x, ws_d2, eps, e, tiles);
+    if (vec)
+        hipLaunchKernelGGL((l2_renorm_kernel<4>), grid, dim3(kBlock), 0, st, delta_out, x, ws_d2, eps, e, tiles);
+    else
+        hipLaunchKernelGGL((l2_renorm_kernel<1>), grid, dim3(kBlock), 0, st, delta_out, x, ws_d2, eps, e, tiles);
     return check_launch("l2_renorm");
 }
 
@@ -575,15 +608,17 @@ extern "C" int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, f
 }
 
 extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                            const float* x, float* x_adv, float* ws, int partials_ready, float decay, float alpha,
+                            const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
                             float eps, int64_t n, int64_t e, void* stream) {
     if (int rc = check_batch(n, e)) return rc;
-    TA_REQUIRE(g && delta && x && ws, "null pointer");
-    TA_REQUIRE(!(partials_ready && v), "partials of |g| cannot be reused when a variance term is added");
+    TA_REQUIRE(g && delta && x && ws && ws_slots >= 0, "null pointer");
+    TA_REQUIRE(!(ws_slots && v), "partials of |g| cannot be reused when a variance term is added");
+    TA_REQUIRE(!(ws_slots && aten_sum_lanes() != 0),
+               "TA_ATEN_SUM_LANES: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!partials_ready || aten_sum_lanes() != 0)            // the reference-order sum is never taken from a producer
+    if (ws_slots == 0)
         if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
-    const int tiles_ws = static_cast<int>(ceil_div(e, kTile));
+    const int tiles_ws = ws_slots > 0 ? ws_slots : static_cast<int>(ceil_div(e, kTile));
     const StepParams p{decay, alpha, -eps, eps};
     const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
     // stream past the caches only when one launch moves more than the Infinity Cache can hold

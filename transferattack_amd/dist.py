@@ -6,9 +6,9 @@ The reference is single-process, single-GPU (main.py:31, 43); nothing here has a
   batch and Admix mixes images within a batch (dim.py:54-63, admix.py:44), so batches are never re-cut.  Every
   batch is seeded from (base_seed, batch_idx) (``seed_batch``) so the output does not depend on the GPU count.
   No collective on the data path.
-* Ensemble attacks (ENS) put one surrogate per rank of a model group: ``ShardedEnsemble`` averages the logits with
-  one RCCL all-reduce ([N,1000] fp32) and ``allreduce_input_grad`` sums the input gradients with another
-  ([N,3,224,224] fp32) -- the only two exchange steps the path has.  Ranks of a group see the same images and,
+* A list of surrogates (ENS, or any attack run on ``--model a,b,...``) puts one surrogate per rank of a model group:
+  ``ShardedEnsemble.forward`` averages the logits with one RCCL all-reduce ([N,1000] fp32) and, in its backward, sums
+  the members' input gradients with another ([N,3,224,224] fp32) -- the only two exchange steps the path has.  Ranks of a group see the same images and,
   after the second all-reduce, hold identical gradients, so each runs the identical fused update locally.
 * Attacks that address single members (SVRE, CWA, AdaEA, SMER: ``self.model.models[k](x)``, svre.py:72-83,
   cwa.py:71-81, adaea.py:65-82, smer.py:80-106) use ``ShardedMembers``: ``models[k]`` is a handle that runs on the rank
@@ -25,6 +25,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+
+def _invalidate_partials():
+    """Drop the |g| tile sums a HIP kernel may have registered for a gradient a collective has just replaced or
+    modified (transferattack_amd._hip partials registry)."""
+    from . import _hip
+    _hip.invalidate_partials()
 
 
 def rank_world():
@@ -95,6 +102,24 @@ class _AllReduceMean(torch.autograd.Function):
         return grad / ctx.members, None, None
 
 
+class _SumInputGrad(torch.autograd.Function):
+    """identity on x; backward: all-reduce(sum) of d(loss)/dx over the group -- every member contributes
+    (1/M) J_m^T dL/dz, the sum is what ``EnsembleModel`` (utils.py:82-105) gives on one device.  The sum goes into a
+    fresh tensor and the producer-side |g| sums are dropped (they describe the local member's gradient only)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        total = grad.contiguous().clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
+        _invalidate_partials()
+        return total, None
+
+
 class ShardedEnsemble(nn.Module):
     """Drop-in for ``EnsembleModel`` (utils.py:82-105, mode 'mean') when each rank of ``group`` holds ONE member:
     forward = local member + all-reduce(mean) of the logits.  ``models`` / ``num_models`` / ``device`` keep the
@@ -111,14 +136,9 @@ class ShardedEnsemble(nn.Module):
         self.device = next(local_model.parameters()).device
 
     def forward(self, x):
+        if x.requires_grad:
+            x = _SumInputGrad.apply(x, self.group)
         return _AllReduceMean.apply(self.local(x), self.group, self.num_models)
-
-
-def allreduce_input_grad(grad, group):
-    """Sum over the members of d(loss)/d(delta) -- the second exchange step of the ensemble path."""
-    grad = grad.contiguous()
-    dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-    return grad
 
 
 class _OwnerCall(torch.autograd.Function):
@@ -154,6 +174,7 @@ class _OwnerCall(torch.autograd.Function):
         else:
             gx = torch.empty(ctx.x_shape, dtype=grad_logits.dtype, device=grad_logits.device)
         dist.broadcast(gx, src=handle.owner, group=handle.group)
+        _invalidate_partials()                    # every rank of the group must take the same path through the update
         return gx, None
 
 
@@ -201,6 +222,7 @@ class _GatherLogits(torch.autograd.Function):
         owner = ctx.owner
         gx = torch.autograd.grad(out, leaf, grad[owner.index].contiguous(), retain_graph=True)[0].contiguous()
         dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=owner.group)
+        _invalidate_partials()                    # gx was modified in place behind torch's back
         return gx, None
 
 
@@ -243,6 +265,7 @@ class ShardedMembers(nn.Module):
             mine = torch.autograd.grad(loss_of_logits(out), leaf, retain_graph=True)[0].contiguous()
         parts = [torch.empty_like(mine) for _ in range(self.num_models)]
         dist.all_gather(parts, mine, group=self.group)
+        _invalidate_partials()
         return parts
 
     def member_losses(self, inputs, loss_of_logits):
@@ -260,3 +283,30 @@ class ShardedMembers(nn.Module):
 
     def parameters(self, recurse=True):
         return self.local.parameters(recurse)
+
+
+PER_MEMBER_ATTACKS = ('svre', 'cwa', 'adaea', 'smer')        # these index self.model.models[k] (svre.py:72-83, ...)
+
+
+def sharded_attack(cls, attack_name, model_names, world, **ctor_kwargs):
+    """One surrogate per rank of a model group: build ``cls`` so that this rank loads only ITS member and sees the others
+    through ``ShardedEnsemble`` (logit / input-gradient all-reduce) or, for the attacks that address single members,
+    ``ShardedMembers``.  Collective: every rank calls it.  Returns (attacker, member_index, shard_rank, shard_world);
+    images are sharded over the ``shard_world`` groups, the ranks of one group process the same batches."""
+    members = len(model_names)
+    grp, member, shard_rank, shard_world = model_groups(world, members)
+    name = model_names[member]
+    first = shard_rank * members
+    group_ranks = list(range(first, first + members))
+    per_member = attack_name in PER_MEMBER_ATTACKS
+
+    class Sharded(cls):
+        def load_model(self, model_name):
+            local = super().load_model(name)
+            if per_member:
+                return ShardedMembers(local, member, grp, group_ranks)
+            return ShardedEnsemble(local, grp, members)
+
+    Sharded.__name__ = "Sharded" + cls.__name__
+    attacker = Sharded(model_name=list(model_names) if per_member else name, **ctor_kwargs)
+    return attacker, member, shard_rank, shard_world

@@ -1,10 +1,10 @@
 """ENS (Liu et al., ICLR 2017) -- MI-FGSM on the mean of several surrogates' logits.
 Mirror of transferattack/ensemble/ens.py:31-36; the averaging lives in ``EnsembleModel`` (utils.py:82-105) when
 all members sit on one GPU, or in ``transferattack_amd.dist.ShardedEnsemble`` when there is one member per rank:
-then the logits are averaged by one RCCL all-reduce and ``get_grad`` sums the members' input-gradients with a
-second one, after which every rank of the group runs the identical fused update."""
+then the logits are averaged by one RCCL all-reduce forward and the members' input-gradients are summed by a second
+one backward (both inside ``ShardedEnsemble.forward``, so every attack class gets them), after which every rank of the
+group runs the identical fused update."""
 from ..attack import Attack
-from ..dist import ShardedEnsemble, allreduce_input_grad
 
 
 class ENS(Attack):
@@ -15,9 +15,3 @@ class ENS(Attack):
                  random_start=False, norm='linfty', loss='crossentropy', device=None, attack='ENS', **kwargs):
         super().__init__(attack, model_name, epsilon, targeted, random_start, norm, loss, device)
         self._schedule(alpha, epoch, decay)
-
-    def get_grad(self, loss, delta, **kwargs):
-        grad = super().get_grad(loss, delta, **kwargs)
-        if isinstance(self.model, ShardedEnsemble):
-            grad = allreduce_input_grad(grad, self.model.group)
-        return grad

@@ -1,13 +1,7 @@
 """TIM (Dong et al., CVPR 2019) -- smooth the input gradient with a k x k kernel (depthwise, 'same').
 Mirror of transferattack/input_transformation/tim.py:35-74.  The convolution is ``ta_depthwise_conv2d_same``:
-LDS-tiled, same row-major FMA chain as the reference's CPU path (bit-identical smoothing).
-
-``TA_TIM_SEPARABLE=1`` (opt-in) switches to ``ta_depthwise_conv2d_same_separable``: every kernel type of the
-reference is an outer product of a 1-D profile with itself, so two 1-D passes give the same smoothing with 2k instead of
-k*k taps -- but with different rounding than the reference's direct convolution (~1e-7 relative), which is why it is
-not the default."""
-import os
-
+LDS-tiled, same row-major FMA chain as the reference's CPU path (bit-identical smoothing). The same kernel leaves the per-tile sums of |grad| for the
+fused update (TIM.get_grad is the last kernel that writes the gradient), so the update reads the gradient once."""
 import numpy as np
 import torch
 
@@ -50,17 +44,11 @@ class TIM(MIFGSM):
             profile = _PROFILE_1D[kind](kernel_size, nsig)
             plane = np.outer(profile, profile)
             plane = plane / plane.sum()
-        # the 1-D factor with  outer(factor, factor) == plane  in exact arithmetic (the opt-in separable path)
-        factor = np.ones(kernel_size) / kernel_size if kind == 'uniform' else profile / profile.sum()
-        self.kernel_factor = torch.from_numpy(factor.astype(np.float32)).to(self.device)
         planes = np.stack([plane] * 3)[:, None]                          # one identical kernel per colour plane
         return torch.from_numpy(planes.astype(np.float32)).to(self.device)
 
     def get_grad(self, loss, delta, **kwargs):
         grad = torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0].contiguous()
         out = torch.empty_like(grad)
-        if os.environ.get("TA_TIM_SEPARABLE", "0") == "1" and self.kernel_factor.numel() in (3, 5, 7, 15):
-            _hip.depthwise_conv2d_same_separable(grad, out, self.kernel_factor, self.kernel_factor)
-        else:
-            _hip.depthwise_conv2d_same(grad, out, self.kernel[0, 0].contiguous())
+        _hip.depthwise_conv2d_same(grad, out, self.kernel[0, 0].contiguous())
         return out

@@ -155,6 +155,25 @@ def save_images(output_dir, adversaries, filenames, perturbations=None):
         list(pool.map(write, range(len(filenames))))
 
 
+class _FanOut(torch.autograd.Function):
+    """x handed to every member of an ensemble.  Backward: the members' input gradients are added by ONE HIP kernel in
+    the order autograd's input buffer would add them (last member first: ((g[m-1] + g[m-2]) + ...) + g[0]), which
+    also leaves the per-tile sums of |g| for the fused update."""
+
+    @staticmethod
+    def forward(ctx, x, members):
+        return tuple(x.view_as(x) for _ in range(members))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if len(grads) == 1:
+            return grads[0], None
+        grads = [g.contiguous() for g in grads]
+        gx = torch.empty_like(grads[0])
+        _hip.sum_members(grads, gx)
+        return gx, None
+
+
 class EnsembleModel(nn.Module):
     """Several wrapped surrogates evaluated on the same input; 'mean' averages logits, 'ind' stacks them
     (utils.py:82-105).  ``models`` stays a plain list (attacks index ``self.model.models[k]``)."""
@@ -171,7 +190,12 @@ class EnsembleModel(nn.Module):
         self.mode = mode
 
     def forward(self, x):
-        outputs = torch.stack([model(x) for model in self.models], dim=0)
+        if x.requires_grad and x.dtype == torch.float32 and x.dim() == 4 and 1 < len(self.models) <= 8:
+            # the attack path (HIP kernels whatever device x claims to be on, like _Normalize: no torch fallback)
+            views = _FanOut.apply(x, len(self.models))
+            outputs = torch.stack([model(v) for model, v in zip(self.models, views)], dim=0)
+        else:
+            outputs = torch.stack([model(x) for model in self.models], dim=0)
         if self.mode == 'mean':
             return torch.mean(outputs, dim=0)
         if self.mode == 'ind':
