@@ -111,6 +111,10 @@ def main():
         if pending_write is not None:
             pending_write.result()
     elif rank == 0:
+        if not os.environ.get("TA_WEIGHTS_DIR") and os.environ.get("TA_ALLOW_RANDOM_INIT", "0") != "1":
+            raise SystemExit("--eval needs the victims' pretrained weights (TA_WEIGHTS_DIR=<dir with <name>.pth>): the attack "
+                             "success rate against seeded random-init victims says nothing about the reference's numbers "
+                             "(TA_ALLOW_RANDOM_INIT=1 runs it anyway, e.g. for plumbing tests)")
         res = '|'
         for model_name, model in load_pretrained_model(cnn_model_paper, vit_model_paper):
             model = wrap_model(model.eval().to(default_device()))

@@ -339,6 +339,8 @@ def run_attack(name, backbones, data, label, trace=None, **overrides):
         g = torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0]
         if kernel is not None:
             g = tim_smooth(g, kernel)              # tim.py:72-74
+        if trace is not None:
+            rec.setdefault("grads", []).append(g)  # every get_grad result of the iteration, in call order
         return g
 
     delta = delta_init(data, eps, cfg["random_start"]).requires_grad_(True)

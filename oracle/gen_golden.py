@@ -313,8 +313,63 @@ def gen_config2():
     save("config2_mifgsm_resnet50_n4", label=label, adv_u8=adv_u8, seed_images=0, seed_labels=1, seed_weights=0)
 
 
+def _adv_u8(x, delta):
+    return ((x + delta).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)            # utils.py:64
+
+
+def gen_config3():
+    """BASELINE.json configs[2] in miniature: DTS (DIM o SIM on the input, TIM on the gradient) on
+    ResNet-50, 2 images x 5 scale copies, K=10, by the reference's own DIM / TIM / SIM methods on the CPU."""
+    n = 2
+    xu8 = u8_images(n, 224, 0)
+    label = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1))
+    backbone = backbones.create("resnet50", seed=0, verbose=False)
+    DTS = _dts_class()                                     # imports the reference package first
+    from transferattack.utils import wrap_model
+    DTS.load_model = lambda self, name: wrap_model(backbone.eval())
+    atk = DTS(model_name="injected")
+    x = xu8.float() / 255
+    torch.manual_seed(1234)
+    delta = atk(x, label)
+    save("config3_dts_resnet50_n2", label=label, adv_u8=_adv_u8(x, delta), seed_images=0, seed_labels=1, seed_weights=0,
+         seed_draws=1234)
+
+
+def gen_config4():
+    """BASELINE.json configs[3] in miniature: VMI-FGSM on ViT-B/16 (timm layout, seeded init), 2 images, 4 variance
+    samples (20 in the config), K=3 (10 in the config), by the reference's own class on the CPU
+    (gradient/vmifgsm.py:42-97); and the same on ResNet-18 with the full 20 samples, K=3."""
+    n = 2
+    xu8 = u8_images(n, 224, 0)
+    label = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1))
+    x = xu8.float() / 255
+    out = dict(label=label, seed_images=0, seed_labels=1, seed_weights=0, seed_draws=1234)
+    for tag, model, kw in (("vit", "vit_base_patch16_224", dict(num_neighbor=4, epoch=3)),
+                           ("resnet18", "resnet18", dict(num_neighbor=20, epoch=3))):
+        atk = ref_shim.make_reference_attack("vmifgsm", backbones.create(model, seed=0, verbose=False), **kw)
+        torch.manual_seed(1234)
+        out["adv_u8_" + tag] = _adv_u8(x, atk(x, label))
+    save("config4_vmifgsm_n2", **out)
+
+
+def gen_config5():
+    """BASELINE.json configs[4] in miniature: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 (299-pixel branch of
+    wrap_model) + ViT-B/16 through the reference's EnsembleModel (utils.py:82-105), 2 images, K=3."""
+    n = 2
+    xu8 = u8_images(n, 224, 0)
+    label = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1))
+    members = [backbones.create(m, seed=0, verbose=False) for m in ENS_MEMBERS]
+    atk = ref_shim.make_reference_attack("ens", members, epoch=3)
+    x = xu8.float() / 255
+    delta = atk(x, label)
+    save("config5_ens4_n2", label=label, adv_u8=_adv_u8(x, delta), seed_images=0, seed_labels=1, seed_weights=0)
+
+
+ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1", "config2"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1", "config2", "config3", "config4", "config5"]
     for w in which:
         globals()["gen_" + w]()

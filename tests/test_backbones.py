@@ -1,0 +1,264 @@
+"""CPU: the surrogate definitions the hot path differentiates through.
+
+The reference pulls its surrogates from torchvision / timm with downloaded weights (transferattack/attack.py:48-60);
+neither package exists here, so ``transferattack_amd.backbones`` carries its own definitions.  What must hold for a
+standard checkpoint to load into them -- and what these tests pin, from rules written down independently of the
+module code -- is the state-dict contract: every key torchvision / timm publish for the architecture, with its shape, and
+nothing else; plus the published parameter totals.  Second half: ``fold_batchnorm`` (the arrangement bench.py measures)
+is the same function as the unfolded network -- checked in fp64, where the algebra is exact to rounding.
+"""
+import pytest
+import torch
+
+from transferattack_amd import backbones
+
+
+def _bn(prefix, c):
+    return {prefix + ".weight": (c,), prefix + ".bias": (c,), prefix + ".running_mean": (c,),
+            prefix + ".running_var": (c,), prefix + ".num_batches_tracked": ()}
+
+
+def _resnet_keys(block, layers):
+    """torchvision.models.resnet: stem conv1/bn1, layer1..4 of BasicBlock (expansion 1) / Bottleneck (expansion 4),
+    downsample = (conv1x1, bn) on the first block of a stage when stride or width changes, fc"""
+    exp = 1 if block == "basic" else 4
+    keys = {"conv1.weight": (64, 3, 7, 7)}
+    keys.update(_bn("bn1", 64))
+    inplanes = 64
+    for stage, (planes, count) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        for b in range(count):
+            p = "layer%d.%d" % (stage, b)
+            stride = 2 if (b == 0 and stage > 1) else 1
+            if block == "basic":
+                keys[p + ".conv1.weight"] = (planes, inplanes, 3, 3)
+                keys[p + ".conv2.weight"] = (planes, planes, 3, 3)
+                keys.update(_bn(p + ".bn1", planes))
+                keys.update(_bn(p + ".bn2", planes))
+            else:
+                keys[p + ".conv1.weight"] = (planes, inplanes, 1, 1)
+                keys[p + ".conv2.weight"] = (planes, planes, 3, 3)
+                keys[p + ".conv3.weight"] = (planes * 4, planes, 1, 1)
+                keys.update(_bn(p + ".bn1", planes))
+                keys.update(_bn(p + ".bn2", planes))
+                keys.update(_bn(p + ".bn3", planes * 4))
+            if b == 0 and (stride != 1 or inplanes != planes * exp):
+                keys[p + ".downsample.0.weight"] = (planes * exp, inplanes, 1, 1)
+                keys.update(_bn(p + ".downsample.1", planes * exp))
+            inplanes = planes * exp
+    keys["fc.weight"] = (1000, 512 * exp)
+    keys["fc.bias"] = (1000,)
+    return keys
+
+
+def _vgg_keys(cfg):
+    """torchvision.models.vgg (no batch norm): features = conv3x3 + ReLU per entry, 'M' = max-pool; the index in the
+    Sequential advances by 2 per conv and 1 per pool; classifier Linear at 0, 3, 6"""
+    keys, idx, cin = {}, 0, 3
+    for v in cfg:
+        if v == "M":
+            idx += 1
+            continue
+        keys["features.%d.weight" % idx] = (v, cin, 3, 3)
+        keys["features.%d.bias" % idx] = (v,)
+        idx += 2
+        cin = v
+    for i, (o, c) in zip((0, 3, 6), ((4096, 512 * 7 * 7), (4096, 4096), (1000, 4096))):
+        keys["classifier.%d.weight" % i] = (o, c)
+        keys["classifier.%d.bias" % i] = (o,)
+    return keys
+
+
+def _mobilenet_v2_keys():
+    """torchvision.models.mobilenet_v2: features.0 = ConvBNReLU(3, 32, s2); inverted residuals (t, c, n, s);
+    features.18 = ConvBNReLU(320, 1280, k1); classifier.1"""
+    keys = {"features.0.0.weight": (32, 3, 3, 3)}
+    keys.update(_bn("features.0.1", 32))
+    cin, idx = 32, 1
+    for t, c, n, _s in ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2),
+                        (6, 320, 1, 1)):
+        for _ in range(n):
+            p = "features.%d.conv" % idx
+            hidden = cin * t
+            k = 0
+            if t != 1:                                   # pointwise expansion
+                keys["%s.%d.0.weight" % (p, k)] = (hidden, cin, 1, 1)
+                keys.update(_bn("%s.%d.1" % (p, k), hidden))
+                k += 1
+            keys["%s.%d.0.weight" % (p, k)] = (hidden, 1, 3, 3)          # depthwise
+            keys.update(_bn("%s.%d.1" % (p, k), hidden))
+            keys["%s.%d.weight" % (p, k + 1)] = (c, hidden, 1, 1)        # linear projection
+            keys.update(_bn("%s.%d" % (p, k + 2), c))
+            cin = c
+            idx += 1
+    keys["features.18.0.weight"] = (1280, 320, 1, 1)
+    keys.update(_bn("features.18.1", 1280))
+    keys["classifier.1.weight"] = (1000, 1280)
+    keys["classifier.1.bias"] = (1000,)
+    return keys
+
+
+def _vit_keys(dim=768, depth=12, patch=16, tokens=197, ratio=4):
+    """timm vision_transformer: cls_token, pos_embed, patch_embed.proj, blocks.N.{norm1, attn.qkv, attn.proj, norm2,
+    mlp.fc1, mlp.fc2}, norm, head"""
+    keys = {"cls_token": (1, 1, dim), "pos_embed": (1, tokens, dim),
+            "patch_embed.proj.weight": (dim, 3, patch, patch), "patch_embed.proj.bias": (dim,)}
+    for n in range(depth):
+        p = "blocks.%d." % n
+        for name, shape in (("norm1", (dim,)), ("norm2", (dim,))):
+            keys[p + name + ".weight"] = shape
+            keys[p + name + ".bias"] = shape
+        for name, (o, i) in (("attn.qkv", (3 * dim, dim)), ("attn.proj", (dim, dim)), ("mlp.fc1", (ratio * dim, dim)),
+                             ("mlp.fc2", (dim, ratio * dim))):
+            keys[p + name + ".weight"] = (o, i)
+            keys[p + name + ".bias"] = (o,)
+    keys.update({"norm.weight": (dim,), "norm.bias": (dim,), "head.weight": (1000, dim), "head.bias": (1000,)})
+    return keys
+
+
+def _inception_conv(prefix, cout, cin, kh, kw):
+    keys = {prefix + ".conv.weight": (cout, cin, kh, kw)}
+    keys.update(_bn(prefix + ".bn", cout))
+    return keys
+
+
+def _inception_v3_keys():
+    """torchvision.models.inception_v3 (aux_logits=True, the layout of the published checkpoint): BasicConv2d =
+    conv (no bias) + bn; InceptionA/B/C/D/E blocks and the auxiliary head, named as torchvision names them"""
+    k = {}
+    c = _inception_conv
+    for name, co, ci, kk in (("Conv2d_1a_3x3", 32, 3, 3), ("Conv2d_2a_3x3", 32, 32, 3), ("Conv2d_2b_3x3", 64, 32, 3),
+                             ("Conv2d_3b_1x1", 80, 64, 1), ("Conv2d_4a_3x3", 192, 80, 3)):
+        k.update(c(name, co, ci, kk, kk))
+    for name, ci, pool in (("Mixed_5b", 192, 32), ("Mixed_5c", 256, 64), ("Mixed_5d", 288, 64)):           # InceptionA
+        k.update(c(name + ".branch1x1", 64, ci, 1, 1))
+        k.update(c(name + ".branch5x5_1", 48, ci, 1, 1))
+        k.update(c(name + ".branch5x5_2", 64, 48, 5, 5))
+        k.update(c(name + ".branch3x3dbl_1", 64, ci, 1, 1))
+        k.update(c(name + ".branch3x3dbl_2", 96, 64, 3, 3))
+        k.update(c(name + ".branch3x3dbl_3", 96, 96, 3, 3))
+        k.update(c(name + ".branch_pool", pool, ci, 1, 1))
+    k.update(c("Mixed_6a.branch3x3", 384, 288, 3, 3))                                                       # InceptionB
+    k.update(c("Mixed_6a.branch3x3dbl_1", 64, 288, 1, 1))
+    k.update(c("Mixed_6a.branch3x3dbl_2", 96, 64, 3, 3))
+    k.update(c("Mixed_6a.branch3x3dbl_3", 96, 96, 3, 3))
+    for name, c7 in (("Mixed_6b", 128), ("Mixed_6c", 160), ("Mixed_6d", 160), ("Mixed_6e", 192)):          # InceptionC
+        k.update(c(name + ".branch1x1", 192, 768, 1, 1))
+        k.update(c(name + ".branch7x7_1", c7, 768, 1, 1))
+        k.update(c(name + ".branch7x7_2", c7, c7, 1, 7))
+        k.update(c(name + ".branch7x7_3", 192, c7, 7, 1))
+        k.update(c(name + ".branch7x7dbl_1", c7, 768, 1, 1))
+        k.update(c(name + ".branch7x7dbl_2", c7, c7, 7, 1))
+        k.update(c(name + ".branch7x7dbl_3", c7, c7, 1, 7))
+        k.update(c(name + ".branch7x7dbl_4", c7, c7, 7, 1))
+        k.update(c(name + ".branch7x7dbl_5", 192, c7, 1, 7))
+        k.update(c(name + ".branch_pool", 192, 768, 1, 1))
+    k.update(c("AuxLogits.conv0", 128, 768, 1, 1))                                                          # InceptionAux
+    k.update(c("AuxLogits.conv1", 768, 128, 5, 5))
+    k["AuxLogits.fc.weight"] = (1000, 768)
+    k["AuxLogits.fc.bias"] = (1000,)
+    k.update(c("Mixed_7a.branch3x3_1", 192, 768, 1, 1))                                                     # InceptionD
+    k.update(c("Mixed_7a.branch3x3_2", 320, 192, 3, 3))
+    k.update(c("Mixed_7a.branch7x7x3_1", 192, 768, 1, 1))
+    k.update(c("Mixed_7a.branch7x7x3_2", 192, 192, 1, 7))
+    k.update(c("Mixed_7a.branch7x7x3_3", 192, 192, 7, 1))
+    k.update(c("Mixed_7a.branch7x7x3_4", 192, 192, 3, 3))
+    for name, ci in (("Mixed_7b", 1280), ("Mixed_7c", 2048)):                                               # InceptionE
+        k.update(c(name + ".branch1x1", 320, ci, 1, 1))
+        k.update(c(name + ".branch3x3_1", 384, ci, 1, 1))
+        k.update(c(name + ".branch3x3_2a", 384, 384, 1, 3))
+        k.update(c(name + ".branch3x3_2b", 384, 384, 3, 1))
+        k.update(c(name + ".branch3x3dbl_1", 448, ci, 1, 1))
+        k.update(c(name + ".branch3x3dbl_2", 384, 448, 3, 3))
+        k.update(c(name + ".branch3x3dbl_3a", 384, 384, 1, 3))
+        k.update(c(name + ".branch3x3dbl_3b", 384, 384, 3, 1))
+        k.update(c(name + ".branch_pool", 192, ci, 1, 1))
+    k["fc.weight"] = (1000, 2048)
+    k["fc.bias"] = (1000,)
+    return k
+
+
+VGG16 = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+VGG19 = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+# name -> (expected state dict, published parameter count)
+CONTRACT = {
+    "resnet18": (lambda: _resnet_keys("basic", (2, 2, 2, 2)), 11_689_512),
+    "resnet34": (lambda: _resnet_keys("basic", (3, 4, 6, 3)), 21_797_672),
+    "resnet50": (lambda: _resnet_keys("bottleneck", (3, 4, 6, 3)), 25_557_032),
+    "resnet101": (lambda: _resnet_keys("bottleneck", (3, 4, 23, 3)), 44_549_160),
+    "vgg16": (lambda: _vgg_keys(VGG16), 138_357_544),
+    "vgg19": (lambda: _vgg_keys(VGG19), 143_667_240),
+    "mobilenet_v2": (_mobilenet_v2_keys, 3_504_872),
+    "inception_v3": (_inception_v3_keys, 27_161_264),
+    "vit_base_patch16_224": (_vit_keys, 86_567_656),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONTRACT))
+def test_state_dict_contract(name):
+    """every key a torchvision / timm checkpoint of this architecture holds, with its shape -- and no others"""
+    expected, total = CONTRACT[name]
+    expected = expected()
+    model = backbones.create(name, verbose=False)
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert set(got) == set(expected), sorted(set(got) ^ set(expected))[:10]
+    wrong = {k: (got[k], expected[k]) for k in got if got[k] != tuple(expected[k])}
+    assert not wrong, list(wrong.items())[:5]
+    assert sum(p.numel() for p in model.parameters()) == total
+    # a checkpoint saved under the upstream names loads (strict) and reproduces the function
+    clone = backbones.create(name, seed=1, verbose=False)
+    clone.load_state_dict({k: v.clone() for k, v in model.state_dict().items()}, strict=True)
+    x = torch.rand(1, 3, 299 if name == "inception_v3" else 224, 299 if name == "inception_v3" else 224)
+    with torch.no_grad():
+        assert torch.equal(model(x), clone(x))
+
+
+def test_weights_dir_is_honoured(tmp_path, monkeypatch):
+    """attack.py:48-60 loads published weights; here ``$TA_WEIGHTS_DIR/<name>.pth`` (a plain state_dict) plays that role"""
+    src = backbones.create("resnet18", seed=7, verbose=False)
+    torch.save(src.state_dict(), tmp_path / "resnet18.pth")
+    monkeypatch.setenv("TA_WEIGHTS_DIR", str(tmp_path))
+    loaded = backbones.create("resnet18", seed=0, verbose=False)
+    for (k, a), (_, b) in zip(src.state_dict().items(), loaded.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_preprocessing_statistics():
+    """wrap_model's choice of resize / mean / std (utils.py:37-60): ImageNet statistics, Inception 299 px with 0.5 / 0.5,
+    timm default_cfg for the ViT (0.5 / 0.5 for the augreg weights of vit_base_patch16_224)"""
+    import fgsm_oracle as O
+    assert O.preprocess_cfg(backbones.create("resnet50", verbose=False)) == (224, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    size, mean, std = O.preprocess_cfg(backbones.create("inception_v3", verbose=False))
+    assert (size, list(mean), list(std)) == (299, [0.5] * 3, [0.5] * 3)
+    size, mean, std = O.preprocess_cfg(backbones.create("vit_base_patch16_224", verbose=False))
+    assert (size, list(mean), list(std)) == (224, [0.5] * 3, [0.5] * 3)
+
+
+FOLDABLE = ["resnet18", "resnet50", "mobilenet_v2", "inception_v3"]        # the zoo's networks with BatchNorm
+
+
+@pytest.mark.parametrize("name", FOLDABLE + ["vgg16", "vit_base_patch16_224"])
+def test_fold_batchnorm_is_the_same_function(name):
+    """bench.py runs the surrogate with eval-mode BatchNorm folded into the convolutions (TA_FOLD_BN=1).  In fp64 the
+    folded network's logits and input-gradient equal the unfolded network's to ~1e-12 relative -- the folding is an
+    identity on the function, only fp32 rounding can differ (bounded on the device by the GPU tier)."""
+    size = 299 if name == "inception_v3" else 224
+    n = 1 if name in ("vgg16", "vit_base_patch16_224") else 2
+    ref = backbones.create(name, seed=3, verbose=False).double()
+    folded = backbones.create(name, seed=3, verbose=False).double()
+    count = backbones.fold_batchnorm(folded)
+    bns = [m for m in ref.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert count == len(bns), "fold_batchnorm folded %d of %d BatchNorm layers" % (count, len(bns))
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in folded.modules())
+    assert [k for k, _ in folded.named_modules()] == [k for k, _ in ref.named_modules()]     # hook names survive
+    x = torch.rand(n, 3, size, size, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    label = torch.arange(n) % 1000
+    outs = []
+    for m in (ref, folded):
+        xin = x.clone().requires_grad_(True)
+        logits = m(xin)
+        g = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xin)[0]
+        outs.append((logits.detach(), g))
+    (l0, g0), (l1, g1) = outs
+    assert float((l0 - l1).abs().max() / l0.abs().max()) < 1e-10
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-9

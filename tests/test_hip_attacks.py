@@ -254,8 +254,16 @@ def test_main_cli_roundtrip(tmp_path, monkeypatch):
     monkeypatch.setattr(cli, "cnn_model_paper", ["resnet18"])
     monkeypatch.setattr(cli, "vit_model_paper", [])
     monkeypatch.setattr(sys, "argv", ["main.py", "--input_dir", str(inp), "--output_dir", str(out), "--eval"])
+    monkeypatch.delenv("TA_WEIGHTS_DIR", raising=False)
+    with pytest.raises(SystemExit, match="pretrained weights"):          # no silent ASR against random-init victims
+        cli.main()
+    monkeypatch.setenv("TA_ALLOW_RANDOM_INIT", "1")                      # plumbing test: explicitly allowed
     cli.main()
     assert "|" in open(tmp_path / "results_eval.txt").read()
+    monkeypatch.setenv("TA_WEIGHTS_DIR", str(tmp_path))                  # weights directory without the file: refuse
+    monkeypatch.delenv("TA_ALLOW_RANDOM_INIT")
+    with pytest.raises(FileNotFoundError):
+        backbones.create("resnet18", verbose=False)
 
 
 @pytest.mark.parametrize("name", ["svre", "cwa"])

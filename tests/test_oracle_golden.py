@@ -164,6 +164,30 @@ def test_config1_ifgsm_resnet18(golden):
     assert np.array_equal(O.quantize_u8(x + delta), g["adv_u8"])
 
 
+CONFIG_CASES = [
+    # (golden file, key, attack, surrogates, images, oracle overrides)        BASELINE.json configs[1..4] in miniature
+    ("config2_mifgsm_resnet50_n4", "adv_u8", "mifgsm", ["resnet50"], 4, {}),
+    ("config3_dts_resnet50_n2", "adv_u8", "dts", ["resnet50"], 2, {}),
+    ("config4_vmifgsm_n2", "adv_u8_vit", "vmifgsm", ["vit_base_patch16_224"], 2, dict(num_neighbor=4, epoch=3)),
+    ("config4_vmifgsm_n2", "adv_u8_resnet18", "vmifgsm", ["resnet18"], 2, dict(num_neighbor=20, epoch=3)),
+    ("config5_ens4_n2", "adv_u8", "ens", ["resnet50", "vgg16", "inception_v3", "vit_base_patch16_224"], 2, dict(epoch=3)),
+]
+
+
+@pytest.mark.parametrize("file,key,name,models,n,kw", CONFIG_CASES, ids=[c[0] + ":" + c[1] for c in CONFIG_CASES])
+def test_config_size_loops(golden, file, key, name, models, n, kw):
+    """The oracle pinned to the REAL reference at the sizes and on the surrogates BASELINE.json names: 224 x 224,
+    ResNet-50 (MI-FGSM, DTS), ViT-B/16 and ResNet-18 (VMI-FGSM), the four-member ensemble with the 299-pixel Inception
+    branch -- final uint8 images identical to the bytes the reference's own classes wrote (oracle/gen_golden.py)."""
+    g = golden(file)
+    x = u8_images(n, 224, int(g["seed_images"])).float() / 255
+    nets = [backbones.create(m, seed=int(g["seed_weights"]), verbose=False) for m in models]
+    if "seed_draws" in g.files:
+        torch.manual_seed(int(g["seed_draws"]))
+    delta = O.run_attack(name, nets if len(nets) > 1 else nets[0], x, t(g["label"]), **kw)
+    assert np.array_equal(O.quantize_u8(x + delta), g[key])
+
+
 def test_c_oracle_copies_and_normalize(golden):
     """plain-C restatements of the SIM / Admix stacks (forward and autograd-ordered backward), the preprocessing
     Normalize and the VMI variance against the reference's golden tensors / the torch expressions."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, probes, rocprof.  Everything lands in gpurun_out/<tag>/.
-# usage: tools/gpu_check.sh <tag> [steps...]   steps: tests smoke bench probe rocprof pmc dimvariants widened ...
-TAG=${1:-r1}; shift
+# usage: tools/gpu_check.sh <tag> [steps...]   steps: tests smoke bench kernels configs pmc timpmc k2sweep rocprof ...
+TAG=${1:-r2}; shift
 STEPS=${@:-tests smoke bench rocprof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,41 +11,35 @@ lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket" > $OUT/host.txt
 for step in $STEPS; do
 case $step in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
+  timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
   grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -30 ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 bench)
-  timeout 900 python bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
-  timeout 600 python bench.py --steps 6 --warmup 2 --single-launch 1 --cpu-images 0 --kernel-sweep 0 > $OUT/bench_single.json 2>> $OUT/bench.err; cat $OUT/bench_single.json ;;
+  timeout 900 python bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
 batches)
-  for b in 64 125 250; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+  for b in 32 64 250; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+literal)
+  # the reference's literal arrangement: batches of 32, NCHW, separate BatchNorm
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --fold-bn 0 --channels-last 0 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_literal_b32.json ;;
 kernels)
   timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
-timvariants)
-  for v in 0 1 2 3; do TA_TIM_VARIANT=$v timeout 300 python tools/kernel_bench.py 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print('variant=$v', {k:v for k,v in d.items() if 'tim' in k or 'dim' in k})"; done | tee $OUT/tim_variants.txt
-  for v in 2 3; do TA_TIM_VARIANT=$v timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -k "tim or dim" -p no:cacheprovider 2>&1 | tail -2; done ;;
-dimvariants)
-  # first thing to run next round: parity of the lane-per-column DIM kernels on the device, then their timing
-  TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 300 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -k "dim or dts" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/dim_variants_pytest.txt
-  for v in "0 0" "2 0" "0 1" "2 1"; do set -- $v; TA_DIM_FWD_VARIANT=$1 TA_DIM_BWD_VARIANT=$2 timeout 120 python tools/dim_time.py; done 2>&1 | tee $OUT/dim_variants.txt
-  TA_XCD_MAJOR_TILES=1 TA_DIM_FWD_VARIANT=2 TA_DIM_BWD_VARIANT=1 timeout 120 python tools/dim_time.py 2>&1 | sed "s/^/xcd-major /" | tee -a $OUT/dim_variants.txt ;;
-widened)
-  timeout 300 python tools/tim_microbench.py 2>&1 | tail -5 | tee $OUT/tim_separable.txt
-  timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider 2>&1 | tail -12 | tee $OUT/widened_pytest.txt ;;
 freq)
   # SSM (20 spectrum views per iteration) with the rocFFT DCT pair and with the GEMM form
-  for v in 0 1; do TA_DCT_GEMM=$v timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | sed "s/^/TA_DCT_GEMM=$v /" | tee -a $OUT/bench_ssm_b16.txt; done ;;
+  for v in 0 1; do TA_DCT_GEMM=$v timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | sed "s/^/TA_DCT_GEMM=$v /" | tee -a $OUT/bench_ssm_b16.txt; done ;;
 k2sweep)
+  mkdir -p tools/bin; [ -x tools/bin/k2_sweep ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/k2_sweep.hip -o tools/bin/k2_sweep
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
-fast)
-  TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 4 --warmup 2 --batch 125 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast125.json
-  TA_FOLD_BN=1 TA_CHANNELS_LAST=1 timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fast32.json ;;
 configs)
-  timeout 600 python bench.py --attack sia --batch 16 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_sia_b16.json
   timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json
-  timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32.json
-  timeout 600 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32.json ;;
+  timeout 600 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32.json
+  timeout 600 python bench.py --attack sia --batch 16 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_sia_b16.json ;;
+vmi)
+  timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32.json ;;
+gpus1)
+  # the self-launch path of bench.py --gpus N on a one-GPU box: N = 1 under torch.distributed.run (RCCL world of 1)
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_torchrun_n1.json
+  timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 2>&1 | tail -1 | tee $OUT/bench_gpus2_refused.txt ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
 rocprof)
@@ -57,7 +51,12 @@ pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/tools/update_microbench.py > $R/$OUT/pmc_$c.log 2>&1 )
   done
-  python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
+  python tools/pmc_summary.py $OUT 125 --json $OUT/pmc_update_kernel.json > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
+  find $OUT -name "*.db" -delete ;;
+timpmc)
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/$OUT/timpmc -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/timpmc.log 2>&1 )
+  python tools/pmc_kernels.py $OUT/timpmc | tee $OUT/timpmc_summary.txt
+  find $OUT -name "*.db" -delete ;;
 esac
 done
 du -sh $OUT

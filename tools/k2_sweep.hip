@@ -126,6 +126,22 @@ __global__ __launch_bounds__(256) void copy4(const float* __restrict__ a, const 
     }
 }
 
+// ceilings of the memory system for other traffic shapes: 1-in/1-out float4 copy, and a pure 4-stream read
+template <bool NT>
+__global__ __launch_bounds__(256) void copy1(const float* __restrict__ a, float* o, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) st<NT>(o + i * 4, ld<NT>(a + i * 4));
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void read4(const float* __restrict__ a, const float* __restrict__ b,
+                                             const float* __restrict__ c, const float* __restrict__ d, float* o, long n4) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 va = ld<NT>(a + i * 4), vb = ld<NT>(b + i * 4), vc = ld<NT>(c + i * 4), vd = ld<NT>(d + i * 4);
+        acc += va.x + vb.y + vc.z + vd.w;
+    }
+    if (acc == 12345.678f) o[0] = acc;
+}
+
 struct Set { float *g, *m, *d, *x; };
 
 int main() {
@@ -178,6 +194,21 @@ int main() {
             snprintf(name, sizeof name, "copy 4in/2out %d blocks nt", blocks);
             run(name, [&](Set& s) { hipLaunchKernelGGL((copy4<true>), dim3(blocks), dim3(256), 0, 0, s.g, s.m, s.d, s.x, s.m, s.d, numel / 4); });
         }
+        auto run_bytes = [&](const char* name, double bytes_per_elem, auto launch) {
+            for (int i = 0; i < 4; ++i) launch(sets[i % 4]);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < REPS; ++i) launch(sets[i % 4]);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / REPS;
+            printf("n=%-4d %-34s %8.2f us  %7.1f GB/s (at %.0f B/element)\n", n, name, us, bytes_per_elem * numel / us / 1e3, bytes_per_elem);
+        };
+        run_bytes("copy 1in/1out 8192 blocks", 8.0, [&](Set& s) { hipLaunchKernelGGL((copy1<false>), dim3(8192), dim3(256), 0, 0, s.g, s.m, numel / 4); });
+        run_bytes("copy 1in/1out 8192 blocks nt", 8.0, [&](Set& s) { hipLaunchKernelGGL((copy1<true>), dim3(8192), dim3(256), 0, 0, s.g, s.m, numel / 4); });
+        run_bytes("read 4 streams 8192 blocks", 16.0, [&](Set& s) { hipLaunchKernelGGL((read4<false>), dim3(8192), dim3(256), 0, 0, s.g, s.m, s.d, s.x, ws, numel / 4); });
+        run_bytes("read 4 streams 8192 blocks nt", 16.0, [&](Set& s) { hipLaunchKernelGGL((read4<true>), dim3(8192), dim3(256), 0, 0, s.g, s.m, s.d, s.x, ws, numel / 4); });
         for (auto& s : sets) for (float* p : {s.g, s.m, s.d, s.x}) CHECK(hipFree(p));
         CHECK(hipFree(ws));
     }

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/update_microbench.py: bytes per launch per
 kernel, calibrated on the known-size copy kernel of the same run (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
-reports half of a wide coalesced read -- the copy kernel measures that factor instead of assuming it)."""
+reports half of a wide coalesced read -- the copy kernel measures that factor instead of assuming it).
+    python tools/pmc_summary.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> [N] [--json profiles/pmc_update_kernel.json]"""
 import csv
 import glob
+import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -18,25 +21,44 @@ def load(out, counter):
             for r in csv.DictReader(fh):
                 if r.get("Counter_Name") != counter:
                     continue
-                grid = int(r.get("Grid_Size", "0") or 0)
-                rows[(r["Kernel_Name"], grid)].append(float(r["Counter_Value"]))
+                rows[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return rows
 
 
 def main():
     out = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 125
+    per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         rows = load(out, counter)
-        print("== %s (KiB per launch, mean over launches)" % counter)
-        for (name, grid), vals in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
-            short = name.split("(")[0][-70:]
+        print("== %s (KiB per launch, mean over launches; N = %d)" % (counter, n))
+        for name, vals in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            short = re.sub(r"\(.*", "", name)[-90:]
             mean_kib = sum(vals) / len(vals)
-            n_img = None
-            for n in (32, 250):
-                if grid in (49 * n * 256,):
-                    n_img = n
-            per_elem = "  = %.2f B/elem" % (mean_kib * 1024 / (E * n_img)) if n_img else ""
-            print("%-72s grid %-10d launches %-4d mean %.1f KiB%s" % (short, grid, len(vals), mean_kib, per_elem))
+            b_per_elem = mean_kib * 1024 / (E * n)
+            per.setdefault(short, {})[counter] = b_per_elem
+            print("%-92s launches %-4d mean %.1f KiB = %.3f B/elem" % (short, len(vals), mean_kib, b_per_elem))
+    copy = [k for k in per if "elementwise" in k or "copy" in k.lower()]
+    factor = None
+    if copy:
+        c = per[copy[0]]
+        if c.get("FETCH_SIZE"):
+            factor = 4.0 / c["FETCH_SIZE"]                # the copy reads 4 B/elem
+            print("calibration on %s: reported fetch %.3f B/elem for 4 B/elem read -> correction x%.3f; write %.3f for 4"
+                  % (copy[0][-40:], c["FETCH_SIZE"], factor, c.get("WRITE_SIZE", float("nan"))))
+    if "--json" in sys.argv and factor:
+        dst = sys.argv[sys.argv.index("--json") + 1]
+        doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/update_microbench.py, "
+                         "N = %d; summary by tools/pmc_summary.py" % n,
+               "fetch_correction": round(factor, 4), "kernels": {}}
+        for name, c in per.items():
+            if "ta::" not in name and "ta2" not in name:
+                continue
+            doc["kernels"][name] = {"fetch_B_per_elem_reported": round(c.get("FETCH_SIZE", 0.0), 3),
+                                    "fetch_B_per_elem_corrected": round(c.get("FETCH_SIZE", 0.0) * factor, 3),
+                                    "write_B_per_elem": round(c.get("WRITE_SIZE", 0.0), 3)}
+        json.dump(doc, open(dst, "w"), indent=1)
+        print("wrote", dst)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""TIM smoothing alone: event timing of the direct convolution (the TA_TIM_VARIANT in the environment) and of the opt-in
-separable form, at N = 32 and 160 images; also the launch set for rocprofv3 --pmc runs (TA_N picks one size)."""
+"""TIM smoothing and the DIM kernels alone: event timing at N = 32 and 160 images; also the launch set for rocprofv3 --pmc
+runs (TA_N picks one size)."""
 import os
 import sys
 
@@ -16,11 +16,9 @@ for n in sizes:
     o = torch.empty_like(g[0])
     w = torch.rand(15, 15, device="cuda")
     w = (w / w.sum()).contiguous()
-    f = torch.rand(15, device="cuda")
-    f = (f / f.sum()).contiguous()
-    for name, call in (("direct (variant %s)" % os.environ.get("TA_TIM_VARIANT", "default"),
-                        lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                       ("separable", lambda i: _hip.depthwise_conv2d_same_separable(g[i % 3], o, f, f))):
+    for name, call in (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
+                       ("dim_fwd", lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)),
+                       ("dim_bwd", lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5))):
         for i in range(6):
             call(i)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,6 +30,6 @@ for n in sizes:
         torch.cuda.synchronize()
         us = start.elapsed_time(end) * 1e3 / 20
         elems = n * 3 * 224 * 224
-        print("n=%d %s: %.2f us  (%.2f TB/s at 8 B/element; direct-form FLOPs %.1f TFLOP/s)"
-              % (n, name, us, elems * 8 / us / 1e6, elems * 450 / us / 1e6))
+        print("n=%d %s: %.2f us  (%.2f TB/s at 8 B/element%s)"
+              % (n, name, us, elems * 8 / us / 1e6, "; %.1f TFLOP/s" % (elems * 450 / us / 1e6) if "tim" in name else ""))
 print("done")

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Stand-alone driver of the fused update kernels for profiling (rocprofv3 --pmc / --kernel-trace).
-Runs, for N in {32, 250}: a known-size device copy (calibration of the byte counters), the two-launch update and
-the single-launch update, rotating over 4 operand sets so the 256 MiB Infinity Cache cannot serve them."""
+Runs at N = TA_MICRO_N (default 125, the bench's launch shape): a known-size device copy (calibration of the byte
+counters), then the shipped update in the three shapes the loop issues -- steady state (24 B/element + 4 for x_adv),
+first iteration (no momentum read), and K1 + K2 (no producer-side sums) -- rotating over 4 operand sets so the
+256 MiB Infinity Cache cannot serve them."""
 import os
 import sys
 
@@ -11,25 +13,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transferattack_amd import _hip  # noqa: E402
 
 REPS = int(os.environ.get("TA_MICRO_REPS", "8"))
+N = int(os.environ.get("TA_MICRO_N", "125"))
 
 
 def main():
     _hip.load()
-    for n in (32, 250):
-        sets = []
-        for _ in range(4):
-            g = torch.randn(n, 3, 224, 224, device="cuda") * 1e-4
-            sets.append((g, torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g)))
-        dst = torch.empty_like(sets[0][0])
-        for i in range(REPS):
-            dst.copy_(sets[i % 4][1])                       # calibration: reads 4 B/elem, writes 4 B/elem
-        for single in (False, True):
-            for i in range(REPS):
-                g, m, d, x = sets[i % 4]
-                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, single_launch=single)
-        torch.cuda.synchronize()
-        del sets, dst
-    print("microbench done")
+    sets = []
+    for _ in range(4):
+        g = torch.randn(N, 3, 224, 224, device="cuda") * 1e-4
+        sets.append((g, torch.randn_like(g), torch.zeros_like(g), torch.rand_like(g), torch.empty_like(g)))
+    dst = torch.empty_like(sets[0][0])
+    for i in range(REPS):
+        dst.copy_(sets[i % 4][1])                       # calibration: reads 4 B/elem, writes 4 B/elem
+    for i in range(REPS):                               # K1 + K2 (24 B/elem + 4 for K1's pass)
+        g, m, d, x, xa = sets[i % 4]
+        _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255)
+    for i in range(REPS):                               # steady state of the loop: sums ready, x_adv written (28 B/elem)
+        g, m, d, x, xa = sets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa)
+    for i in range(REPS):                               # first iteration: no momentum read (24 B/elem with x_adv)
+        g, m, d, x, xa = sets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, None, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa)
+    for i in range(REPS):                               # decay 0: no momentum at all (20 B/elem with x_adv)
+        g, m, d, x, xa = sets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, None, None, d, x, 0.0, 1.6 / 255, 16 / 255, x_adv=xa)
+    torch.cuda.synchronize()
+    print("microbench done N=%d" % N)
 
 
 if __name__ == "__main__":

@@ -3,8 +3,9 @@
 The reference pulls these from torchvision / timm with downloaded weights
 (transferattack/attack.py:48-60); neither package nor network exists here, so the engine carries
 its own definitions with the upstream parameter names.  ``create(name)`` loads
-``$TA_WEIGHTS_DIR/<name>.pth`` (a plain ``state_dict``) when present and otherwise initialises
-deterministically from ``seed`` -- the attack arithmetic does not depend on which.
+``$TA_WEIGHTS_DIR/<name>.pth`` (a plain ``state_dict``); without ``TA_WEIGHTS_DIR`` it initialises deterministically
+from ``seed`` (the attack arithmetic does not depend on which).  If ``TA_WEIGHTS_DIR`` is set but the file is missing it
+raises instead of silently attacking / evaluating a random network (``TA_ALLOW_RANDOM_INIT=1`` overrides).
 """
 import os
 
@@ -140,6 +141,9 @@ def create(name, seed=0, verbose=True, **kw):
         model.load_state_dict(torch.load(path, map_location="cpu"))
         if verbose:
             print('=> Loading model {} ({}) with weights {}'.format(name, origin, path))
+    elif path and name not in LOCAL_ZOO and os.environ.get("TA_ALLOW_RANDOM_INIT", "0") != "1":
+        raise FileNotFoundError("TA_WEIGHTS_DIR is set but {} does not exist: refusing to fall back to a randomly "
+                                "initialised {} (set TA_ALLOW_RANDOM_INIT=1 to allow it)".format(path, name))
     else:
         calibrate_batchnorm(model, seed)
         if verbose:
