@@ -335,16 +335,30 @@ def main():
         full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")
-        if os.path.isfile(pmc_path):            # HBM bytes per launch from the committed rocprofv3 PMC passes
-            pmc = json.load(open(pmc_path))
-            k2 = pmc["mi_update_kernel"]
-            per_elem = k2["fetch_B_per_elem_corrected"] + k2["write_B_per_elem"]
-            # the counters were taken on the steady-state launch shape; scale to the mean algorithmic bytes of the loop's
-            # launches (first-iteration launches move one operand less)
-            per_elem *= mean_bytes / (n_ * e_) / k2.get("algorithmic_B_per_elem", BYTES_PER_ELEM)
-            if _hip.stats["k1_passes"] > 0:
-                per_elem += pmc["abs_sum_partials_kernel"]["fetch_B_per_elem_corrected"]
-            traffic = int(per_elem * e_ * n_)
+        if os.path.isfile(pmc_path):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes over the SHIPPED kernel (tools/gpu_check.sh pmc,
+            # N = 125): each launch of the timed region is priced with the counters of its own kernel instantiation
+            # (steady state / first iteration / decay 0 differ in the operands they move)
+            kernels = json.load(open(pmc_path))["kernels"]
+
+            per_shape = {}
+            for name, c in kernels.items():
+                if "mi_update_kernel<" not in name:
+                    continue
+                flags = [f.strip() for f in name[name.index("<") + 1:name.rindex(">")].split(",")]
+                # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV>
+                key = tuple(f == "true" for f in flags[4:8])
+                per_shape[key] = c["fetch_B_per_elem_corrected"] + c["write_B_per_elem"]
+            k1 = next((c["fetch_B_per_elem_corrected"] for name, c in kernels.items() if "abs_sum_partials" in name), 4.0)
+            total, priced = 0.0, 0
+            for _, _, n_l, e_l, b_l in sink:
+                # bytes/element -> which operands moved: 12 (g, d, x read; d written... ) + 4 each for m_in, m_out, x_adv
+                shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k)) == b_l and not k[0]]
+                if shapes:
+                    total += per_shape[shapes[0]] * n_l * e_l
+                    priced += 1
+            if priced == len(sink):
+                traffic = int(total / len(sink) + (k1 * e_ * n_ if _hip.stats["k1_passes"] > 0 else 0))
         result = {
             "metric": "adversarial images/sec (1000-img set, K=10)",
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,

@@ -35,11 +35,11 @@ const char* ta_last_error(void);
 int64_t ta_l1_workspace_floats(int64_t n, int64_t e);
 /* |g| tile sums ("partials"): K1 and every elementwise producer below cut an image of e elements into
  * ta_update_tiles(e) = ceil(e/3072) tiles and write one fp32 sum of |.| per tile, ws[img*S + tile].  The tile kernels
- * (TIM convolution, DIM backward) write one sum per workgroup tile: ws[plane*T + tile], T = ta_conv_tiles(h, w) /
+ * (TIM convolution, DIM backward) write one sum per workgroup tile: ws[plane*T + tile], T = ta_conv_tiles(k, h, w) /
  * ta_dim_bwd_tiles(size, resize), i.e. C*T consecutive sums per image.  ta_mi_update takes either layout through
  * `ws_slots` = sums per image.  All sums are in a fixed order (no atomics). */
 int64_t ta_update_tiles(int64_t e);
-int64_t ta_conv_tiles(int h, int w);
+int64_t ta_conv_tiles(int k, int h, int w);
 int64_t ta_dim_bwd_tiles(int size, int resize);
 
 /* ---- update stack ------------------------------------------------------------------------------
@@ -88,7 +88,7 @@ int ta_init_delta_uniform(float* delta, const float* x, const float* noise, floa
 /* ---- TIM: TIM.get_grad  input_transformation/tim.py:72-74 ------------------------------------------
  * depthwise k x k 'same' zero-padded correlation of every (n,c) plane with ONE k x k kernel `w`
  * (device pointer, k*k fp32, row-major).  Tap order is row-major FMA chain == the reference CPU path.
- * k <= 31; in and out must not alias.  ws (nullable): |out| sums, ta_conv_tiles(h, w_) per plane (TIM.get_grad is the
+ * k <= 31; in and out must not alias.  ws (nullable): |out| sums, ta_conv_tiles(k, h, w_) per plane (TIM.get_grad is the
  * last kernel that writes the gradient the update consumes).
  */
 int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, float* ws, int k, int64_t planes,

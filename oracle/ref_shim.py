@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- import shim for the *real* reference (read-only, /root/reference).
 
-Only used by ``oracle/gen_golden.py`` (golden-vector generation in the build container) and by
-``tests/test_oracle_vs_reference.py`` (skipped when /root/reference is absent, e.g. on the GPU box).
+Only used by ``oracle/gen_golden.py`` (golden-vector generation in the build container) and by the
+``cpu_baseline`` leg of ``bench.py`` (kind "reference", only where /root/reference exists -- not on the GPU box).
 Nothing in the product package may import this file.
 
 The reference cannot be imported as shipped: ``transferattack/utils.py:3-4,9`` import
@@ -55,6 +55,49 @@ class _Normalize(nn.Module):
         return (x - mean) / std
 
 
+class InterpolationMode:
+    """torchvision.transforms.InterpolationMode: only the members the in-scope reference files name"""
+    NEAREST = "nearest"
+    BILINEAR = "bilinear"
+
+
+def rotate_tensor(img, angle, mode="bilinear"):
+    """torchvision.transforms.functional.rotate for a float NCHW tensor, expand=False, center=None, fill=None -- the
+    tensor path of torchvision 0.13 (the reference's pin, requirements.txt:3), restated because torchvision is absent:
+    functional.rotate builds the INVERSE affine matrix of a rotation by -angle about the image centre
+    (_get_inverse_affine_matrix), functional_tensor.rotate turns it into a sampling grid (_gen_affine_grid: base grid of
+    pixel centres relative to the image centre, times theta^T / (w/2, h/2)) and samples with
+    grid_sample(mode, padding_mode='zeros', align_corners=False)."""
+    import math
+    rot = math.radians(-angle)
+    a, b, c, d = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
+    matrix = [d, -b, 0.0, -c, a, 0.0]                      # inverted rotation, centre (0, 0), no translation
+    h, w = img.shape[-2], img.shape[-1]
+    theta = torch.tensor(matrix, dtype=img.dtype).reshape(1, 2, 3)
+    base = torch.empty(1, h, w, 3, dtype=img.dtype)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=img.dtype)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
+    return F.grid_sample(img, grid.expand(img.shape[0], h, w, 2), mode=mode, padding_mode="zeros", align_corners=False)
+
+
+class RandomRotation(nn.Module):
+    """torchvision.transforms.RandomRotation(degrees=(lo, hi), interpolation=...): one angle per call from torch's
+    default generator (``torch.empty(1).uniform_(lo, hi)``), applied to the whole batch"""
+
+    def __init__(self, degrees, interpolation=InterpolationMode.NEAREST, expand=False, center=None, fill=0):
+        super().__init__()
+        self.degrees = [float(d) for d in degrees]
+        self.interpolation = interpolation
+        assert not expand and center is None
+
+    def forward(self, img):
+        angle = float(torch.empty(1).uniform_(self.degrees[0], self.degrees[1]).item())
+        return rotate_tensor(img, angle, self.interpolation)
+
+
 def _install_stubs():
     if "torchvision" not in sys.modules:
         tv = types.ModuleType("torchvision")
@@ -62,6 +105,8 @@ def _install_stubs():
         tv_tf = types.ModuleType("torchvision.transforms")
         tv_tf.Resize = _Resize
         tv_tf.Normalize = _Normalize
+        tv_tf.RandomRotation = RandomRotation
+        tv_tf.InterpolationMode = InterpolationMode
         tv.models = tv_models
         tv.transforms = tv_tf
         sys.modules["torchvision"] = tv

@@ -29,7 +29,7 @@ SIGNATURES = {
     "ta_last_error": (ctypes.c_char_p, []),
     "ta_l1_workspace_floats": (_i64, [_i64, _i64]),
     "ta_update_tiles": (_i64, [_i64]),
-    "ta_conv_tiles": (_i64, [_int, _int]),
+    "ta_conv_tiles": (_i64, [_int, _int, _int]),
     "ta_dim_bwd_tiles": (_i64, [_int, _int]),
     "ta_abs_sum_partials": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "ta_momentum": (_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _vp]),
@@ -312,7 +312,7 @@ def depthwise_conv2d_same(inp, out, weight2d):
     h, w = inp.shape[-2:]
     planes = inp.numel() // (h * w)
     per_image = inp[0].numel() // (h * w) if inp.dim() == 4 else 0
-    tiles = load().ta_conv_tiles(h, w)
+    tiles = load().ta_conv_tiles(k, h, w)
     ws = _new_ws(inp, planes * tiles) if per_image else None
     _call("ta_depthwise_conv2d_same", inp, _ptr(inp, name="grad"), _ptr(out, name="out"), _ptr(weight2d, name="kernel"),
           _ptr(ws), k, planes, h, w)

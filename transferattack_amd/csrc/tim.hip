@@ -9,11 +9,13 @@
 // Tiling: one workgroup = 16 rows x 224 columns of one plane (224 = the image side the path is defined
 // on, utils.py:12; wider images take several column tiles).  The (16+k-1) x (224+k-1) input window is
 // staged in LDS once, the interior starting at a 16-byte aligned column (ds_write_b128, conflict-free);
-// each lane produces 14 consecutive outputs of one row as 7 packed pairs and re-uses one register window
-// per kernel row: 15 aligned 8-byte LDS reads give the pairs (W[2j], W[2j+1]); the pairs shifted by one
-// element, which every second tap needs (v_pk_fma_f32 reads even-aligned register pairs), are built once
-// per row with one v_pk_mov_b32 each -> every FMA of every row is a packed one (105 v_pk_fma_f32 + 14
-// v_pk_mov_b32 per kernel row and wave).  The LDS row stride is == 32 (mod 64) dwords, the only residue
+// each lane produces 14 consecutive outputs of TWO consecutive rows as 2 x 7 packed pairs and keeps one
+// register window per LDS row: 15 aligned 8-byte LDS reads give the pairs (W[2j], W[2j+1]); the pairs
+// shifted by one element, which every second tap needs (v_pk_fma_f32 reads even-aligned register pairs),
+// are built once per window row with one v_pk_mov_b32 each.  Window row w serves kernel row w of the
+// lane's first output row and kernel row w-1 of its second, so the 15 LDS reads and 14 moves of a window
+// row are shared by 2 x 105 packed FMAs (224 moves per 3150 FMAs and lane; with one output row per lane it
+// was 210 per 1575, and the kernel is bound by VALU issue: PMC in profiles/r02/).  The LDS row stride is == 32 (mod 64) dwords, the only residue
 // for which the 32 lanes of a ds_read_b64 group (16 column groups x 2 rows, 14-dword pitch) fall on
 // distinct bank pairs.  Weights are wave-uniform -> scalar loads.
 //
@@ -30,7 +32,9 @@
 
 namespace ta {
 
-constexpr int kConvTH = 16;        // output rows per workgroup
+constexpr int kConvRG = 16;        // row groups (lanes down a tile)
+constexpr int kConvRPL = 2;        // output rows per lane
+constexpr int kConvTH = kConvRG * kConvRPL;   // 32 output rows per workgroup
 constexpr int kConvPT = 14;        // outputs per lane
 constexpr int kConvXG = 16;        // lanes across a row
 constexpr int kConvTW = kConvPT * kConvXG;   // 224
@@ -63,7 +67,7 @@ __device__ __forceinline__ void pin_schedule() {
 }
 
 template <int K, bool FAST_LOAD>
-__global__ __launch_bounds__(kConvTH * kConvXG) void dwconv_same_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(kConvRG * kConvXG) void dwconv_same_kernel(const float* __restrict__ in,
                                                                        float* __restrict__ out,
                                                                        const float* __restrict__ w,
                                                                        float* __restrict__ ws, int h, int wd,
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(kConvTH * kConvXG) void dwconv_same_kernel(const fl
     constexpr int TH = kConvTH;
     constexpr int LO = (K - 1) / 2;
     constexpr int LH = TH + K - 1;
-    constexpr int NT = TH * kConvXG;                   // lanes of the workgroup
+    constexpr int NT = kConvRG * kConvXG;              // lanes of the workgroup
     constexpr int LS = kConvLS;
     constexpr int D = kConvOff - LO;                   // window element i = r + kx + D feeds output r at tap kx
     constexpr int J0 = D / 2;                          // first aligned pair a lane reads
@@ -131,75 +135,100 @@ __global__ __launch_bounds__(kConvTH * kConvXG) void dwconv_same_kernel(const fl
     __syncthreads();
 
     const int xg = threadIdx.x % kConvXG;
-    const int row = threadIdx.x / kConvXG;
-    v2f acc2[NC];
+    const int row = (threadIdx.x / kConvXG) * kConvRPL;      // the lane's first output row, relative to the tile
+    v2f acc_a[NC], acc_b[NC];                               // output rows row, row + 1
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc2[c] = v2f{0.0f, 0.0f};
+    for (int c = 0; c < NC; ++c) acc_a[c] = acc_b[c] = v2f{0.0f, 0.0f};
     const v2f* lane_tile = reinterpret_cast<const v2f*>(&tile[row * LS + xg * kConvPT + 2 * J0]);
-    auto load_pairs = [&](v2f (&win)[NE], int ky) {
-        const v2f* lp = lane_tile + ky * (LS / 2);
+    auto load_pairs = [&](v2f (&win)[NE], int w_row) {
+        const v2f* lp = lane_tile + w_row * (LS / 2);
 #pragma unroll
         for (int j = 0; j < NE; ++j) win[j] = lp[j];
     };
-    auto load_row_weights = [&](float (&wk)[K], int ky) {
+    // weight rows ky and ky - 1 (the second only where it exists): what window row ky multiplies
+    auto load_weights = [&](float (&cur)[K], float (&prev)[K], int ky) {
+        const int kc = ky < K ? ky : K - 1, kp = ky > 0 ? ky - 1 : 0;
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) wk[kx] = w[ky * K + kx];
+        for (int kx = 0; kx < K; ++kx) {
+            cur[kx] = w[kc * K + kx];
+            prev[kx] = w[kp * K + kx];
+        }
     };
-    // every accumulator sees its taps in (ky, kx) order: bit-identical to the reference chain
-    auto fma_pairs = [&](const v2f (&winE)[NE], const float (&wk)[K]) {
-        v2f winO[NE - 1];
+    auto shifted = [&](v2f (&winO)[NE - 1], const v2f (&winE)[NE]) {
 #pragma unroll
         for (int j = 0; j < NE - 1; ++j) winO[j] = shifted_pair(winE[j], winE[j + 1]);
+    };
+    // every accumulator sees its taps in (ky, kx) order: bit-identical to the reference chain
+    auto fma_pairs = [&](v2f (&acc)[NC], const v2f (&winE)[NE], const v2f (&winO)[NE - 1], const float (&wk)[K]) {
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const v2f wv = v2f{wk[kx], wk[kx]};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int start = 2 * c + kx + D;                 // window element of the pair's first half
-                acc2[c] = __builtin_elementwise_fma(wv, (start & 1) ? winO[(start - 1) / 2 - J0] : winE[start / 2 - J0],
-                                                    acc2[c]);
+                acc[c] = __builtin_elementwise_fma(wv, (start & 1) ? winO[(start - 1) / 2 - J0] : winE[start / 2 - J0], acc[c]);
             }
         }
     };
-    v2f win_a[NE], win_b[NE];
-    float wk_a[K], wk_b[K];
+    v2f win_a[NE], win_b[NE], odd[NE - 1];
+    float cur_a[K], prev_a[K], cur_b[K], prev_b[K];
+    // window row 0: kernel row 0 of the first output row only
     load_pairs(win_a, 0);
-    load_row_weights(wk_a, 0);
+    load_weights(cur_a, prev_a, 0);
+    wait_lgkm_all();
+    load_pairs(win_b, 1);
+    load_weights(cur_b, prev_b, 1);
+    pin_schedule();
+    shifted(odd, win_a);
+    fma_pairs(acc_a, win_a, odd, cur_a);
+    pin_schedule();
+    // window rows 1 .. K - 1, two per trip: kernel row wr of the first output row, wr - 1 of the second
 #pragma unroll 1
-    for (int ky = 0; ky + 1 < K; ky += 2) {
-        wait_lgkm_all();                                // row ky: requested a full row ago (or just above, once)
-        load_pairs(win_b, ky + 1);
-        load_row_weights(wk_b, ky + 1);
+    for (int wr = 1; wr + 1 < K; wr += 2) {
+        wait_lgkm_all();                                // row wr: requested a full row ago
+        load_pairs(win_a, wr + 1);
+        load_weights(cur_a, prev_a, wr + 1);
         pin_schedule();
-        fma_pairs(win_a, wk_a);
+        shifted(odd, win_b);
+        fma_pairs(acc_a, win_b, odd, cur_b);
+        fma_pairs(acc_b, win_b, odd, prev_b);
         pin_schedule();
-        wait_lgkm_all();                                // row ky + 1
-        load_pairs(win_a, ky + 2);                      // K odd: row ky + 2 <= K - 1 always exists
-        load_row_weights(wk_a, ky + 2);
+        wait_lgkm_all();                                // row wr + 1
+        load_pairs(win_b, wr + 2);                      // K odd: wr + 2 <= K, the last window row
+        load_weights(cur_b, prev_b, wr + 2);
         pin_schedule();
-        fma_pairs(win_b, wk_b);
+        shifted(odd, win_a);
+        fma_pairs(acc_a, win_a, odd, cur_a);
+        fma_pairs(acc_b, win_a, odd, prev_a);
         pin_schedule();
     }
-    fma_pairs(win_a, wk_a);                             // the last row
+    // window row K: kernel row K - 1 of the second output row only
+    wait_lgkm_all();
+    shifted(odd, win_b);
+    fma_pairs(acc_b, win_b, odd, prev_b);
 
-    const int oy = y0 + row;
     float asum = 0.0f;
-    if (oy < h) {
-        float* op = out + plane * static_cast<int64_t>(h) * wd + static_cast<int64_t>(oy) * wd;
-        const int ox = x0 + xg * kConvPT;
-        if (FAST_LOAD) {                                // wd % 4 == 0 and aligned planes: 8-byte stores
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (ox + 2 * c < wd) {
-                    *reinterpret_cast<v2f*>(op + ox + 2 * c) = acc2[c];
-                    asum += fabsf(acc2[c].x);
-                    asum += fabsf(acc2[c].y);
+    for (int r = 0; r < kConvRPL; ++r) {
+        const v2f (&acc)[NC] = r == 0 ? acc_a : acc_b;
+        const int oy = y0 + row + r;
+        if (oy < h) {
+            float* op = out + plane * static_cast<int64_t>(h) * wd + static_cast<int64_t>(oy) * wd;
+            const int ox = x0 + xg * kConvPT;
+            if (FAST_LOAD) {                            // wd % 4 == 0 and aligned planes: 8-byte stores
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (ox + 2 * c < wd) {
+                        *reinterpret_cast<v2f*>(op + ox + 2 * c) = acc[c];
+                        asum += fabsf(acc[c].x);
+                        asum += fabsf(acc[c].y);
+                    }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (ox + 2 * c < wd) { op[ox + 2 * c] = acc[c].x; asum += fabsf(acc[c].x); }
+                    if (ox + 2 * c + 1 < wd) { op[ox + 2 * c + 1] = acc[c].y; asum += fabsf(acc[c].y); }
                 }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (ox + 2 * c < wd) { op[ox + 2 * c] = acc2[c].x; asum += fabsf(acc2[c].x); }
-                if (ox + 2 * c + 1 < wd) { op[ox + 2 * c + 1] = acc2[c].y; asum += fabsf(acc2[c].y); }
             }
         }
     }
@@ -207,7 +236,8 @@ __global__ __launch_bounds__(kConvTH * kConvXG) void dwconv_same_kernel(const fl
     if (ws != nullptr && threadIdx.x == 0) ws[tid] = total;
 }
 
-// any k <= 31: weights and window in dynamic LDS, runtime loops (fallback for unusual kernel sizes)
+// any k <= 31: weights and window in dynamic LDS, runtime loops, one output row per lane (fallback for unusual kernel sizes)
+constexpr int kConvGenTH = 16;
 __global__ __launch_bounds__(kBlock) void dwconv_same_generic_kernel(const float* __restrict__ in,
                                                                      float* __restrict__ out,
                                                                      const float* __restrict__ w,
@@ -216,14 +246,14 @@ __global__ __launch_bounds__(kBlock) void dwconv_same_generic_kernel(const float
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[kBlock / kWave];
     const int lo = (k - 1) / 2;
-    const int lw = kConvTW + k - 1, lh = kConvTH + k - 1;
+    const int lw = kConvTW + k - 1, lh = kConvGenTH + k - 1;
     float* tile = smem;
     float* wl = smem + lh * ls;
     const int tiles = tiles_x * tiles_y;
     const unsigned tid = blockIdx.x;
     const int64_t plane = tid / tiles;
     const int t = tid % tiles;
-    const int y0 = (t / tiles_x) * kConvTH;
+    const int y0 = (t / tiles_x) * kConvGenTH;
     const int x0 = (t % tiles_x) * kConvTW;
     const float* ip = in + plane * static_cast<int64_t>(h) * wd;
     for (int idx = threadIdx.x; idx < k * k; idx += kBlock) wl[idx] = w[idx];
@@ -271,9 +301,11 @@ constexpr int conv_generic_stride(int k) {
 
 using namespace ta;
 
-extern "C" int64_t ta_conv_tiles(int h, int w_) {
+static bool conv_fixed_size(int k) { return k == 3 || k == 5 || k == 7 || k == 15; }
+
+extern "C" int64_t ta_conv_tiles(int k, int h, int w_) {
     if (h <= 0 || w_ <= 0) return 0;
-    return ceil_div(w_, kConvTW) * ceil_div(h, kConvTH);
+    return ceil_div(w_, kConvTW) * ceil_div(h, conv_fixed_size(k) ? kConvTH : kConvGenTH);
 }
 
 extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, float* ws, int k, int64_t planes,
@@ -282,7 +314,7 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
     TA_REQUIRE(k >= 1 && k <= 31 && planes > 0 && h > 0 && w_ > 0, "bad shape (k=%d)", k);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tiles_x = static_cast<int>(ceil_div(w_, kConvTW));
-    const int tiles_y = static_cast<int>(ceil_div(h, kConvTH));
+    const int tiles_y = static_cast<int>(ceil_div(h, conv_fixed_size(k) ? kConvTH : kConvGenTH));
     const int64_t blocks = planes * tiles_x * tiles_y;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
     const dim3 grid(static_cast<unsigned>(blocks));
@@ -292,17 +324,17 @@ extern "C" int ta_depthwise_conv2d_same(const float* in, float* out, const float
 #define TA_CONV(KK)                                                                                               \
     case KK:                                                                                                      \
         if (fast)                                                                                                 \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, true>), grid, dim3(kConvTH * kConvXG), 0, st, in, out, w, ws, h, \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, true>), grid, dim3(kConvRG * kConvXG), 0, st, in, out, w, ws, h, \
                                w_, tiles_x, tiles_y);                                                             \
         else                                                                                                      \
-            hipLaunchKernelGGL((dwconv_same_kernel<KK, false>), grid, dim3(kConvTH * kConvXG), 0, st, in, out, w, ws, h, \
+            hipLaunchKernelGGL((dwconv_same_kernel<KK, false>), grid, dim3(kConvRG * kConvXG), 0, st, in, out, w, ws, h, \
                                w_, tiles_x, tiles_y);                                                             \
         break;
         TA_CONV(3) TA_CONV(5) TA_CONV(7) TA_CONV(15)
 #undef TA_CONV
         default: {
             const int ls = conv_generic_stride(k);
-            const size_t smem = sizeof(float) * (static_cast<size_t>(kConvTH + k - 1) * ls + k * k);
+            const size_t smem = sizeof(float) * (static_cast<size_t>(kConvGenTH + k - 1) * ls + k * k);
             hipLaunchKernelGGL(dwconv_same_generic_kernel, grid, dim3(kBlock), smem, st, in, out, w, ws, k, h, w_, tiles_x,
                                tiles_y, ls);
         }

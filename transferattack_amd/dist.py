@@ -40,10 +40,11 @@ def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Join the job torch.distributed.run started (nccl == RCCL on ROCm; gloo for the CPU tests)."""
+def init(backend=None, single_rank_group=False):
+    """Join the job torch.distributed.run started (nccl == RCCL on ROCm; gloo for the CPU tests).  A world of one rank
+    needs no process group and gets none, unless ``single_rank_group`` asks for it (RCCL smoke test on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or dist.is_initialized():
+    if (world <= 1 and not single_rank_group) or dist.is_initialized():
         return rank_world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
