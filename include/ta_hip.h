@@ -36,7 +36,7 @@ int64_t ta_l1_workspace_floats(int64_t n, int64_t e);
 /* |g| tile sums ("partials"): K1 and every elementwise producer below cut an image of e elements into
  * ta_update_tiles(e) = ceil(e/3072) tiles and write one fp32 sum of |.| per tile, ws[img*S + tile].  The tile kernels
  * (TIM convolution, DIM backward) write one sum per workgroup tile: ws[plane*T + tile], T = ta_conv_tiles(k, h, w) /
- * ta_dim_bwd_tiles(size, resize), i.e. C*T consecutive sums per image.  ta_mi_update takes either layout through
+ * ta_dim_bwd_tiles(size, resize) / ta_bsr_tiles(h), i.e. C*T consecutive sums per image.  ta_mi_update takes either layout through
  * `ws_slots` = sums per image.  All sums are in a fixed order (no atomics). */
 int64_t ta_update_tiles(int64_t e);
 int64_t ta_conv_tiles(int k, int h, int w);
@@ -69,7 +69,7 @@ int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, fl
  * ws_slots == 0: K1 runs first (ws = scratch of ta_l1_workspace_floats(n, e) floats).
  * ws_slots  > 0: ws already holds ws_slots sums of |g| per image, written by the kernel that produced g
  * (ta_normalize_bwd, ta_depthwise_conv2d_same, ta_dim_bwd, ta_scale_copies_bwd, ta_admix_bwd, ta_sum_copies_bwd,
- * ta_sum_members), so the K1 pass over g is skipped and g is read exactly once. */
+ * ta_sum_members, ta_bsr_bwd), so the K1 pass over g is skipped and g is read exactly once. */
 int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
                  const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
                  float eps, int64_t n, int64_t e, void* stream);
@@ -137,6 +137,21 @@ int ta_sia_fwd(const float* x, const int32_t* plan, const float* noise, float* y
 int ta_sia_bwd(const float* gy, const int32_t* plan, const float* x, const float* noise, float* gx,
                int64_t planes, int h, int w, int copies, int nb, float noise_radius, uint64_t seed,
                uint64_t offset, void* stream);
+
+/* ---- BSR block shuffle + rotation: BSR.shuffle / transform  input_transformation/bsr.py:41-67 --------------
+ * Every copy of the batch is cut into nb strips along one axis (lengths drawn on the host), the strips are shuffled, each
+ * strip is rotated about its centre (torchvision RandomRotation(+-24 deg, BILINEAR): affine grid + grid_sample with zero
+ * fill, align_corners=False), cut into nb blocks along the other axis and shuffled again.  `plan` (device int32, per copy
+ * 1 + 7*nb + 3*nb*nb words, strips / blocks in OUTPUT order): first axis (0 rows, 1 columns); per strip: src_start,
+ * length, out_start and the four entries of theta^T / (w/2, h/2) as float bits; per block: src_start, length, out_start.
+ * `planes` = N*C; y / gy are [copies][planes][h][w].
+ * fwd: one gather kernel.  bwd: gx = sum over the copies (descending = autograd's order) of the exact adjoint, gather
+ * form, no atomics; ws (nullable): |gx| sums, ta_bsr_tiles(h) per plane. */
+int64_t ta_bsr_tiles(int h);
+int ta_bsr_fwd(const float* x, const int32_t* plan, float* y, int64_t planes, int h, int w, int copies, int nb,
+               void* stream);
+int ta_bsr_bwd(const float* gy, const int32_t* plan, float* gx, float* ws, int64_t planes, int h, int w, int copies,
+               int nb, void* stream);
 
 /* ---- VMI-FGSM: VMIFGSM.get_variance  gradient/vmifgsm.py:42-58 --------------------------------------
  * neighbour: out = x + d + U(-radius, radius)   (Philox (seed, offset) or caller `noise`)

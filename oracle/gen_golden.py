@@ -286,6 +286,31 @@ def gen_sia():
     save("sia", **out)
 
 
+def gen_bsr():
+    """BSR.transform (bsr.py:41-67) by the reference's own class: the stack of shuffled-and-rotated copies, its backward
+    (autograd), and a whole loop on the toy CNN.  Three host generators feed it (python ``random``, numpy, torch): all
+    seeded.  The rotation inside is torchvision's RandomRotation, restated in oracle/fgsm_oracle.py::rotate_tensor
+    (torchvision is not installed); everything else is the reference's code."""
+    import random
+    atk = ref_shim.make_reference_attack("bsr", backbones.create("toy_cnn", seed=3, verbose=False), num_scale=4)
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 48, 64, generator=g)
+    out = dict(x=x, num_scale=4, num_block=3, seed=77)
+    random.seed(77); np.random.seed(77); torch.manual_seed(77)
+    xin = x.clone().requires_grad_(True)
+    y = atk.transform(xin)
+    gy = torch.randn(y.shape, generator=g)
+    out.update(y=y.detach(), gy=gy, gx=torch.autograd.grad(y, xin, gy)[0])
+    n, size = 4, 32
+    xl = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    atk = ref_shim.make_reference_attack("bsr", backbones.create("toy_cnn", seed=3, verbose=False), num_scale=5)
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    out["delta_bsr"] = atk(xl, label)
+    out["loop_scale"] = 5
+    save("bsr", **out)
+
+
 def gen_config1():
     """BASELINE.json configs[0]: I-FGSM on ResNet-18, 16 images, eps=16/255, K=10, CPU reference path."""
     n = 16
@@ -370,6 +395,6 @@ ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "config1", "config2", "config3", "config4", "config5"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
     for w in which:
         globals()["gen_" + w]()

@@ -62,25 +62,9 @@ class InterpolationMode:
 
 
 def rotate_tensor(img, angle, mode="bilinear"):
-    """torchvision.transforms.functional.rotate for a float NCHW tensor, expand=False, center=None, fill=None -- the
-    tensor path of torchvision 0.13 (the reference's pin, requirements.txt:3), restated because torchvision is absent:
-    functional.rotate builds the INVERSE affine matrix of a rotation by -angle about the image centre
-    (_get_inverse_affine_matrix), functional_tensor.rotate turns it into a sampling grid (_gen_affine_grid: base grid of
-    pixel centres relative to the image centre, times theta^T / (w/2, h/2)) and samples with
-    grid_sample(mode, padding_mode='zeros', align_corners=False)."""
-    import math
-    rot = math.radians(-angle)
-    a, b, c, d = math.cos(rot), -math.sin(rot), math.sin(rot), math.cos(rot)
-    matrix = [d, -b, 0.0, -c, a, 0.0]                      # inverted rotation, centre (0, 0), no translation
-    h, w = img.shape[-2], img.shape[-1]
-    theta = torch.tensor(matrix, dtype=img.dtype).reshape(1, 2, 3)
-    base = torch.empty(1, h, w, 3, dtype=img.dtype)
-    base[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
-    base[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
-    base[..., 2].fill_(1)
-    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=img.dtype)
-    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
-    return F.grid_sample(img, grid.expand(img.shape[0], h, w, 2), mode=mode, padding_mode="zeros", align_corners=False)
+    """torchvision.transforms.functional.rotate, tensor path of torchvision 0.13 -- restated in oracle/fgsm_oracle.py"""
+    import fgsm_oracle
+    return fgsm_oracle.rotate_tensor(img, angle, mode)
 
 
 class RandomRotation(nn.Module):

@@ -158,6 +158,18 @@ def sum_members(grads, gx):
     gx.copy_(acc)
 
 
+def bsr_fwd(x, plan, y, copies, num_block):
+    calls.append("bsr_fwd")
+    y.copy_(O.bsr_apply_table(x, plan.cpu().numpy(), num_block))
+
+
+def bsr_bwd(gy, plan, gx, copies, num_block):
+    calls.append("bsr_bwd")
+    with torch.enable_grad():
+        xin = torch.zeros_like(gx, requires_grad=True)
+        gx.copy_(torch.autograd.grad(O.bsr_apply_table(xin, plan.cpu().numpy(), num_block), xin, gy)[0])
+
+
 def _sia_plans(plan, num_block, n, noise):
     """decode the int32 plan table of transforms.sia_draw back into the oracle's per-copy dictionaries"""
     import struct
@@ -192,7 +204,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
         gx.copy_(torch.autograd.grad(y, xin, gy)[0])
 
 
-_NAMES = ["sia_fwd", "sia_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+_NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd"]

@@ -90,6 +90,13 @@ def test_ssm_through_kernels(golden, monkeypatch):
     W.test_ssm_attack(golden)
 
 
+def test_bsr_loop(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0)
+    W.test_bsr_attack(golden)
+
+
 def test_main_cli_roundtrip(tmp_path, monkeypatch):
     """main.py end to end (decode -> attack -> quantise -> PNG -> --eval) with the kernels' own code on the host"""
     A.test_main_cli_roundtrip(tmp_path, monkeypatch)

@@ -148,6 +148,16 @@ def test_sia_kernels_random(widened_on_host, shape, nb, copies):
     W.test_sia_kernels_random(shape, nb, copies)
 
 
+def test_bsr_kernels_golden(golden, widened_on_host, monkeypatch):
+    W.test_bsr_kernels_golden(golden, monkeypatch)
+
+
+@pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 4), ((1, 3, 37, 41), 3, 3), ((2, 1, 16, 100), 2, 3),
+                                             ((1, 2, 64, 64), 5, 2), ((1, 1, 9, 300), 1, 2), ((2, 2, 40, 40), 8, 2)])
+def test_bsr_kernels_random(widened_on_host, monkeypatch, shape, nb, copies):
+    W.test_bsr_kernels_random(shape, nb, copies, monkeypatch)
+
+
 def test_full_size_property_tests_at_reduced_size(widened_on_host, monkeypatch):
     """the BASELINE-size property tests of the GPU tier, with the sizes cut to what the stand-in finishes quickly"""
     monkeypatch.setattr(W, "FULL_N", 12)

@@ -226,6 +226,28 @@ def test_sia_block_transform(golden):
     assert same(torch.autograd.grad(y, xin, gy)[0].numpy(), g["gx"])
 
 
+def test_bsr_block_shuffle_rotation(golden):
+    """BSR (bsr.py:41-67): the oracle's draw order over the three host generators (python random, numpy, torch), its
+    split / shuffle / rotate / split / shuffle restatement and its restatement of torchvision's rotate reproduce the
+    stack the reference's own class builds, the gradient autograd returns through it, and a whole loop -- bit for bit."""
+    import random
+    g = golden("bsr")
+    x, gy = t(g["x"]), t(g["gy"])
+    seed = int(g["seed"])
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    plans = O.bsr_draw(tuple(x.shape), int(g["num_block"]), int(g["num_scale"]))
+    assert {tuple(p["dims"]) for p in plans} == {(2, 3), (3, 2)}                       # both axis orders occur
+    xin = x.clone().requires_grad_(True)
+    y = O.bsr_apply(xin, plans)
+    assert same(y.detach().numpy(), g["y"])
+    assert same(torch.autograd.grad(y, xin, gy)[0].numpy(), g["gx"])
+    base = golden("loops_toy")
+    xl, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    delta = O.run_attack("bsr", backbones.create("toy_cnn", seed=3, verbose=False), xl, label, num_scale=int(g["loop_scale"]))
+    assert same(delta.numpy(), g["delta_bsr"])
+
+
 def test_sia_c_restatement(golden):
     """the plain-C restatement of the SIA stack and its backward (integer index maps, one multiply, one add + clip),
     driven by the product's plan table, against the reference's own tensors"""

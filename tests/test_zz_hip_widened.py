@@ -17,7 +17,7 @@ from transferattack_amd.utils import EnsembleModel, quantize_images, wrap_model
 pytestmark = pytest.mark.gpu
 EPS = 16 / 255
 DEV = "cuda"
-BOUND = 0.05            # uint8 mismatch vs the reference's golden images, as for the other end-to-end GPU tests
+BOUND = 0.005           # uint8 mismatch vs the reference's golden images (measured on MI355X: <= 0.3 %, profiles/r02)
 
 
 def t(a):
@@ -165,6 +165,104 @@ def _with_noise(plans, stream, n):
             blocks.append((op, step, scale, nz))
         out.append(dict(rows=rows, cols=cols, blocks=blocks))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------- BSR
+def test_bsr_kernels_golden(golden, monkeypatch):
+    """ta_bsr_fwd / ta_bsr_bwd against the stack the reference's own BSR class builds and the gradient autograd returns
+    through it (tests/golden/bsr.npz).  Forward: bit-exact (the fused operations sit where the reference's build puts
+    them).  Backward: the sum of <= 9 products per pixel and copy -- in raster order within 2e-6 of max|gx|, in the
+    order of the reference that wrote the goldens (TA_ATEN_SUM_LANES=8) bit-exact."""
+    import random
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import bsr_draw
+    g = golden("bsr")
+    nb, copies, seed = int(g["num_block"]), int(g["num_scale"]), int(g["seed"])
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    plan = _dev(bsr_draw(tuple(g["x"].shape), nb, copies))
+    x, gy = _dev(g["x"]), _dev(g["gy"])
+    y = torch.empty(g["y"].shape, device=DEV)
+    _hip.bsr_fwd(x, plan, y, copies, nb)
+    assert np.array_equal(y.cpu().numpy(), g["y"])
+    gx = torch.empty_like(x)
+    _hip.bsr_bwd(gy, plan, gx, copies, nb)
+    assert float(np.abs(gx.cpu().numpy() - g["gx"]).max()) <= 2e-6 * float(np.abs(g["gx"]).max())
+    monkeypatch.setenv("TA_ATEN_SUM_LANES", "8")
+    _hip.bsr_bwd(gy, plan, gx, copies, nb)
+    monkeypatch.delenv("TA_ATEN_SUM_LANES")
+    assert np.array_equal(gx.cpu().numpy(), g["gx"])
+
+
+@pytest.mark.parametrize("shape,nb,copies", [((2, 3, 224, 224), 3, 4), ((1, 3, 37, 41), 3, 3), ((2, 1, 16, 100), 2, 3),
+                                             ((1, 2, 64, 64), 5, 2), ((1, 3, 299, 299), 3, 2), ((1, 1, 9, 300), 1, 2),
+                                             ((2, 2, 40, 40), 8, 2)])
+def test_bsr_kernels_random(shape, nb, copies, monkeypatch):
+    """other sizes, block counts (1 .. 8) and both axis orders against the oracle on THIS host: forward <= 1e-6 (bit-exact
+    where the host's ATen contracts like the build container's -- reported), backward within 2e-6 of max|gx| in raster
+    order and bit-exact in this host's ATen order; the backward is the adjoint of the forward; the |gx| tile sums are
+    registered."""
+    import random
+    import fgsm_oracle as O
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import bsr_draw
+    gen = torch.Generator().manual_seed(sum(shape) + nb)
+    x = torch.rand(shape, generator=gen)
+    seed = sum(shape)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    plans = O.bsr_draw(shape, nb, copies)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    plan = bsr_draw(shape, nb, copies)
+    xin = x.clone().requires_grad_(True)
+    y_ref = O.bsr_apply(xin, plans)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    gx_ref = torch.autograd.grad(y_ref, xin, gy)[0]
+    assert torch.equal(O.bsr_apply_table(x, plan, nb), y_ref.detach())                  # the table says what the draws said
+    plan_d, x_d, gy_d = _dev(plan), x.to(DEV), gy.to(DEV)
+    y = torch.empty(y_ref.shape, device=DEV)
+    _hip.bsr_fwd(x_d, plan_d, y, copies, nb)
+    diff = float((y.cpu() - y_ref.detach()).abs().max())
+    assert diff <= 1e-6, diff
+    gx = torch.empty(shape, device=DEV)
+    _hip.bsr_bwd(gy_d, plan_d, gx, copies, nb)
+    assert _hip._partials is not None and _hip._partials[0].data_ptr() == gx.data_ptr()
+    sums = _hip._partials[2][:shape[0] * _hip._partials[3]].view(shape[0], -1).double().sum(1).cpu()
+    np.testing.assert_allclose(sums.numpy(), gx.double().abs().flatten(1).sum(1).cpu().numpy(), rtol=2e-6)
+    assert float((gx.cpu() - gx_ref).abs().max()) <= 2e-6 * float(gx_ref.abs().max())
+    lhs, rhs = float((y.double() * gy_d.double()).sum()), float((x_d.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float((y.double() * gy_d.double()).abs().sum())    # <fwd(x), g> = <x, bwd(g)>
+    exact = []
+    for lanes in (8, 16):
+        monkeypatch.setenv("TA_ATEN_SUM_LANES", str(lanes))
+        _hip.bsr_bwd(gy_d, plan_d, gx, copies, nb)
+        exact.append(bool(torch.equal(gx.cpu(), gx_ref)))
+    monkeypatch.delenv("TA_ATEN_SUM_LANES")
+    print("bsr %s nb=%d: forward max|diff| vs this host's ATen %.1e; backward bit-exact in the 8-lane order: %s, 16-lane: %s"
+          % (shape, nb, diff, exact[0], exact[1]))
+    assert any(exact), "backward matches neither ATen visiting order"
+
+
+def test_bsr_attack(golden):
+    """the whole BSR loop on the device against the reference's golden loop (5 copies, toy surrogate)"""
+    import random
+    g, base = golden("bsr"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    cls = ta.load_attack_class("bsr")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("DevBSR", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})(
+        model_name="injected", num_scale=int(g["loop_scale"]))
+    random.seed(1234); np.random.seed(1234); torch.manual_seed(1234)
+    before = _hip_stats()["partials_reused"]
+    delta = atk(x, label).cpu()
+    assert _hip_stats()["partials_reused"] == before + 10        # ta_bsr_bwd is the last writer of the gradient
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    rate = mismatch(x, delta, g["delta_bsr"])
+    print("bsr: uint8 mismatch vs the reference's golden loop %.4f%%" % (100 * rate))
+    assert rate <= BOUND
+
+
+def _hip_stats():
+    from transferattack_amd import _hip
+    return _hip.stats
 
 
 def test_sia_attack(golden):

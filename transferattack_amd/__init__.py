@@ -34,6 +34,7 @@ attack_zoo = {
     'sim': ('.input_transformation.sim', 'SIM'),
     'admix': ('.input_transformation.admix', 'Admix'),
     'sia': ('.input_transformation.sia', 'SIA'),
+    'bsr': ('.input_transformation.bsr', 'BSR'),
     'ssm': ('.input_transformation.ssm', 'SSM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
     # ensemble

@@ -50,6 +50,9 @@ SIGNATURES = {
     "ta_sum_members": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _vp]),
     "ta_sia_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
     "ta_sia_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _u64, _u64, _vp]),
+    "ta_bsr_tiles": (_i64, [_int]),
+    "ta_bsr_fwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
+    "ta_bsr_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
     "ta_vmi_neighbor": (_int, [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_grad_accumulate": (_int, [_vp, _vp, _int, _i64, _vp]),
     "ta_variance_finalize": (_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
@@ -404,6 +407,27 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
     _call("ta_sia_bwd", gy, _ptr(gy, name="gy"), _ptr(plan, torch.int32, "plan"), _ptr(x, name="x"),
           _ptr(noise, name="noise"), _ptr(gx, name="gx"), x.numel() // (h * w), h, w, copies, num_block,
           float(noise_radius), seed, offset)
+
+
+def bsr_fwd(x, plan, y, copies, num_block):
+    h, w = x.shape[-2:]
+    _wrote(y)
+    _call("ta_bsr_fwd", x, _ptr(x, name="x"), _ptr(plan, torch.int32, "plan"), _ptr(y, name="y"), x.numel() // (h * w), h, w,
+          copies, num_block)
+
+
+def bsr_bwd(gy, plan, gx, copies, num_block):
+    h, w = gx.shape[-2:]
+    planes = gx.numel() // (h * w)
+    per_image = gx[0].numel() // (h * w) if gx.dim() == 4 else 0
+    tiles = load().ta_bsr_tiles(h)
+    ws = _new_ws(gx, planes * tiles) if per_image else None
+    _call("ta_bsr_bwd", gy, _ptr(gy, name="gy"), _ptr(plan, torch.int32, "plan"), _ptr(gx, name="gx"), _ptr(ws), planes, h, w,
+          copies, num_block)
+    if ws is not None:
+        _register_partials(gx, ws, per_image * tiles)
+    else:
+        _wrote(gx)
 
 
 # ---------------------------------------------------------------------------------------------- VMI / NI

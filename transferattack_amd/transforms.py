@@ -6,6 +6,8 @@ backward are single HIP kernels (the reference builds them from 3-20 ATen ops in
     AdmixCopies    Admix.transform input_transformation/admix.py:40-45
     LookAhead      NIFGSM.transform gradient/nifgsm.py:35-39
     Neighbor       VMI sampling    gradient/vmifgsm.py:50
+    SiaBlocks      SIA.transform   input_transformation/sia.py:86-100
+    BsrBlocks      BSR.transform   input_transformation/bsr.py:57-67
 
 The random draws stay on the host, on torch's CPU default generator, in the reference's order, so a seeded
 run makes the same choices as the reference on any device.
@@ -177,3 +179,86 @@ class SiaBlocks(torch.autograd.Function):
         gx = torch.empty_like(x)
         _hip.sia_bwd(gy.contiguous(), plan, x, gx, copies, num_block, SIA_NOISE, seed, offset, noise)
         return gx, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ BSR
+BSR_DEGREES = 24.0           # bsr.py:54: RandomRotation(degrees=(-24, 24))
+
+
+def _bsr_lengths(length, num_block):
+    """BSR.get_length (bsr.py:41-45)"""
+    rand = np.random.uniform(2, size=num_block)
+    rand_norm = np.round(rand / rand.sum() * length).astype(np.int32)
+    rand_norm[rand_norm.argmax()] += length - rand_norm.sum()
+    return [int(v) for v in rand_norm]
+
+
+def bsr_draw(shape, num_block, num_copies):
+    """The random choices of ``num_copies`` calls of BSR.shuffle on a batch of ``shape`` (bsr.py:47-61), drawn in the
+    reference's order from the reference's three host generators: python ``random`` -- the order of the two axes and the
+    strip / block permutations; numpy -- the strip lengths; torch (CPU) -- one rotation angle per strip
+    (``torch.empty(1).uniform_(-24, 24)``, what torchvision's RandomRotation draws).  Returns the int32 plan table
+    ``ta_bsr_fwd`` reads ([copies, 1 + 7*nb + 3*nb*nb], strips and blocks in OUTPUT order); the rotation enters as the
+    four entries of theta^T / (w/2, h/2) in fp32 (torchvision's _gen_affine_grid), computed like the reference computes
+    them: the matrix in double precision, rounded to fp32, divided in fp32."""
+    import math
+    import random
+    _, _, height, width = shape
+    size = (height, width)
+    nb = num_block
+    stride = 1 + 7 * nb + 3 * nb * nb
+    plan = np.zeros((num_copies, stride), dtype=np.int32)
+    as_bits = lambda v: int(np.float32(v).view(np.int32))         # noqa: E731
+    for k in range(num_copies):
+        dims = [2, 3]
+        random.shuffle(dims)
+        first, second = dims[0] - 2, dims[1] - 2                   # 0 = rows, 1 = columns
+        lengths0 = _bsr_lengths(size[first], nb)
+        order0 = list(range(nb))
+        random.shuffle(order0)
+        starts0 = np.concatenate([[0], np.cumsum(lengths0)[:-1]])
+        plan[k, 0] = first
+        out0 = 0
+        for pos, src in enumerate(order0):
+            angle = float(torch.empty(1).uniform_(-BSR_DEGREES, BSR_DEGREES).item())
+            lengths1 = _bsr_lengths(size[second], nb)
+            order1 = list(range(nb))
+            random.shuffle(order1)
+            h = lengths0[src] if first == 0 else height           # the strip tensor is h x w
+            w = width if first == 0 else lengths0[src]
+            rot = math.radians(-angle)                             # functional.rotate inverts the angle
+            m = np.array([math.cos(rot), math.sin(rot), -math.sin(rot), math.cos(rot)], dtype=np.float32)
+            half_w, half_h = np.float32(0.5 * w), np.float32(0.5 * h)
+            rt = (m[0] / half_w, m[1] / half_w, m[2] / half_h, m[3] / half_h)          # rt00, rt10, rt01, rt11
+            base = 1 + 7 * pos
+            plan[k, base:base + 3] = (starts0[src], lengths0[src], out0)
+            plan[k, base + 3:base + 7] = [as_bits(v) for v in rt]
+            out0 += lengths0[src]
+            starts1 = np.concatenate([[0], np.cumsum(lengths1)[:-1]])
+            out1 = 0
+            for j, blk in enumerate(order1):
+                cell = 1 + 7 * nb + 3 * (nb * pos + j)
+                plan[k, cell:cell + 3] = (starts1[blk], lengths1[blk], out1)
+                out1 += lengths1[blk]
+    return plan
+
+
+class BsrBlocks(torch.autograd.Function):
+    """cat of ``copies`` shuffled-and-rotated clones of x: one gather kernel each way (``ta_bsr_fwd/bwd``)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, copies, num_block):
+        x = x.contiguous()
+        y = torch.empty((copies * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _hip.bsr_fwd(x, plan, y, copies, num_block)
+        ctx.save_for_backward(plan)
+        ctx.cfg = (copies, num_block, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (plan,) = ctx.saved_tensors
+        copies, num_block, shape = ctx.cfg
+        gx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        _hip.bsr_bwd(gy.contiguous(), plan, gx, copies, num_block)
+        return gx, None, None, None
