@@ -213,6 +213,42 @@ def test_state_dict_contract(name):
         assert torch.equal(model(x), clone(x))
 
 
+def test_evaluation_row_victims():
+    """utils.py:15-17: the reference evaluates on 4 CNNs + 4 ViTs built by timm / torchvision.  The three that are only
+    ever victims (PiT-B, Visformer-S, Swin-T) are restated with timm 0.6 module names; what can be pinned offline: the
+    parameter totals of the published model cards (Swin-T exactly, the other two to the printed digits), a few key /
+    shape facts of each layout, eval-mode determinism, and that ``wrap_model`` picks timm's ImageNet statistics."""
+    import fgsm_oracle as O
+    from transferattack_amd.utils import cnn_model_paper, vit_model_paper
+    assert all(n in backbones.available() for n in cnn_model_paper + vit_model_paper)     # the whole ASR row is buildable
+    facts = {
+        "swin_tiny_patch4_window7_224": (28_288_354, 0, {
+            "patch_embed.proj.weight": (96, 3, 4, 4), "layers.0.blocks.1.attn_mask": (64, 49, 49),
+            "layers.0.blocks.0.attn.relative_position_bias_table": (169, 3), "layers.0.downsample.reduction.weight": (192, 384),
+            "layers.3.blocks.1.attn.relative_position_index": (49, 49), "head.weight": (1000, 768)}),
+        "pit_b_224": (73_760_000, 10_000, {
+            "pos_embed": (1, 256, 31, 31), "patch_embed.conv.weight": (256, 3, 14, 14), "cls_token": (1, 1, 256),
+            "transformers.0.pool.conv.weight": (512, 1, 3, 3), "transformers.1.pool.fc.weight": (1024, 512),
+            "transformers.2.blocks.3.attn.qkv.weight": (3072, 1024), "head.weight": (1000, 1024)}),
+        "visformer_small": (40_220_000, 10_000, {
+            "stem.0.weight": (32, 3, 7, 7), "patch_embed1.proj.weight": (192, 32, 4, 4), "pos_embed2": (1, 384, 14, 14),
+            "stage1.0.mlp.conv2.weight": (384, 48, 3, 3), "stage2.0.attn.qkv.weight": (1152, 384, 1, 1),
+            "stage3.3.mlp.conv3.weight": (768, 3072, 1, 1), "norm.running_mean": (768,), "head.weight": (1000, 768)}),
+    }
+    x = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    for name, (total, slack, shapes) in facts.items():
+        model = backbones.create(name, verbose=False)
+        sd = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        assert abs(sum(p.numel() for p in model.parameters()) - total) <= slack, name
+        for key, shape in shapes.items():
+            assert sd.get(key) == shape, (name, key, sd.get(key))
+        assert "stage1.0.attn.qkv.weight" not in sd                               # Visformer: no attention in stage 1
+        with torch.no_grad():
+            assert torch.equal(model(x), model(x)) and model(x).shape == (1, 1000)
+        size, mean, std = O.preprocess_cfg(model)
+        assert (size, list(mean), list(std)) == (224, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+
+
 def test_weights_dir_is_honoured(tmp_path, monkeypatch):
     """attack.py:48-60 loads published weights; here ``$TA_WEIGHTS_DIR/<name>.pth`` (a plain state_dict) plays that role"""
     src = backbones.create("resnet18", seed=7, verbose=False)

@@ -17,6 +17,7 @@ from .vgg import vgg16, vgg19
 from .inception import inception_v3
 from .mobilenet import mobilenet_v2
 from .vit import vit_base_patch16_224, vit_tiny_patch16_224
+from .timm_victims import pit_b_224, visformer_small, swin_tiny_patch4_window7_224
 
 
 class ToyCNN(nn.Module):
@@ -46,6 +47,9 @@ TORCHVISION_ZOO = {
 }
 TIMM_ZOO = {
     "vit_base_patch16_224": vit_base_patch16_224, "vit_tiny_patch16_224": vit_tiny_patch16_224,
+    # victims of the evaluation row only (utils.py:16-17)
+    "pit_b_224": pit_b_224, "visformer_small": visformer_small,
+    "swin_tiny_patch4_window7_224": swin_tiny_patch4_window7_224,
 }
 LOCAL_ZOO = {"toy_cnn": toy_cnn}
 
