@@ -6,7 +6,9 @@
 
 Same behaviour as the reference: the hyper-parameter flags --epoch/--eps/--alpha/--momentum/--random_start are
 parsed but, as in the reference (main.py:41), not forwarded -- every attack runs with its class defaults.
-Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches).  With several processes the
+Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches).
+Input pipeline: threaded PNG decode -> page-locked staging buffer -> asynchronous upload on a side stream while the previous
+batch runs; output: GPU quantiser -> uint8 download -> threaded PNG encode, also overlapped.  With several processes the
 dataset is sharded by whole batches (transferattack_amd.dist.shard_batches); for ``--attack ens`` every group of
 len(models) ranks holds one surrogate each and exchanges logits / input-gradients over RCCL.
 """
@@ -61,8 +63,12 @@ def main():
     num_batches = (len(dataset) + args.batchsize - 1) // args.batchsize
 
     decoders = ThreadPoolExecutor(max_workers=args.io_threads)        # PNG decode (PIL releases the GIL)
+    device = default_device()
+    copy_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
 
     def batch(idx):
+        """decode one reference batch on the host threads and start its upload: page-locked staging buffer, asynchronous
+        copy on a side stream (runs under the previous batch's kernels); returns the event the consumer waits for"""
         lo, hi = idx * args.batchsize, min((idx + 1) * args.batchsize, len(dataset))
         items = list(decoders.map(dataset.__getitem__, range(lo, hi)))
         images = torch.stack([it[0] for it in items])
@@ -70,7 +76,15 @@ def main():
             labels = [torch.tensor([it[1][0] for it in items]), torch.tensor([it[1][1] for it in items])]
         else:
             labels = torch.tensor([it[1] for it in items])
-        return images, labels, [it[2] for it in items]
+        ready = None
+        if copy_stream is not None:
+            with torch.cuda.device(device), torch.cuda.stream(copy_stream):        # the device is thread-local state
+                staged = images.pin_memory()
+                images = staged.to(device, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+                images._ta_staging = staged                                       # keep the pinned buffer until consumed
+        return images, labels, [it[2] for it in items], ready
 
     if not args.eval:
         if args.ensemble or len(args.model.split(',')) > 1:
@@ -99,7 +113,9 @@ def main():
         io = ThreadPoolExecutor(max_workers=2)
         pending_write, next_batch = None, io.submit(batch, mine[0]) if mine else None
         for pos, batch_idx in enumerate(tqdm.tqdm(mine, disable=rank != 0)):
-            images, labels, filenames = next_batch.result()
+            images, labels, filenames, ready = next_batch.result()
+            if ready is not None:
+                torch.cuda.current_stream(device).wait_event(ready)
             if pos + 1 < len(mine):
                 next_batch = io.submit(batch, mine[pos + 1])
             tadist.seed_batch(args.seed, batch_idx)
@@ -120,7 +136,7 @@ def main():
             model = wrap_model(model.eval().to(default_device()))
             for p in model.parameters():
                 p.requires_grad = False
-            asr = evaluate(model, (batch(i) for i in range(num_batches)), args.targeted)
+            asr = evaluate(model, (batch(i)[:3] for i in range(num_batches)), args.targeted)
             print(f'{model_name}: {asr:.1f}')
             res += f' {asr:.1f} |'
         print(res)
@@ -136,7 +152,7 @@ def evaluate(model, batches, is_targeted):
         for images, labels, _ in batches:
             if is_targeted:
                 labels = labels[1]
-            pred = model(images.to(dev))
+            pred = model(images.to(dev))                      # already there when the pipeline uploaded it
             correct += int((labels.numpy() == pred.argmax(dim=1).cpu().numpy()).sum())
             total += labels.shape[0]
     return (correct / total) * 100 if is_targeted else (1 - correct / total) * 100

@@ -103,26 +103,7 @@ def test_main_cli_roundtrip(tmp_path, monkeypatch):
 
 
 def test_main_cli_resume(tmp_path, monkeypatch):
-    """--resume: an interrupted run (outputs of one batch missing) recomputes exactly the missing batch, and what it
-    writes equals the uninterrupted run (per-batch seeding)"""
-    import sys
-    from PIL import Image
-    import main as cli
-    import test_distributed as T
-    T._write_dataset(str(tmp_path / "data"), 5)
-    argv = ["main.py", "--input_dir", str(tmp_path / "data"), "--output_dir", str(tmp_path / "adv"), "--attack", "dim",
-            "--model", "toy_cnn", "--batchsize", "2", "--seed", "5"]
-    monkeypatch.setattr(sys, "argv", argv)
-    cli.main()
-    full = {i: np.array(Image.open(tmp_path / "adv" / ("%d.png" % i))) for i in range(5)}
-    stamp = {i: (tmp_path / "adv" / ("%d.png" % i)).stat().st_mtime_ns for i in range(5)}
-    (tmp_path / "adv" / "2.png").unlink()                                   # batch 1 = images 2, 3 becomes incomplete
-    monkeypatch.setattr(sys, "argv", argv + ["--resume"])
-    cli.main()
-    for i in range(5):
-        assert np.array_equal(np.array(Image.open(tmp_path / "adv" / ("%d.png" % i))), full[i])
-    after = {i: (tmp_path / "adv" / ("%d.png" % i)).stat().st_mtime_ns for i in range(5)}
-    assert [i for i in range(5) if after[i] != stamp[i]] == [2, 3]          # only the incomplete batch was redone
+    A.test_main_cli_resume(tmp_path, monkeypatch)
 
 
 def test_config1_end_to_end_through_kernels(golden):
