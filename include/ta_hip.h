@@ -153,6 +153,15 @@ int ta_bsr_fwd(const float* x, const int32_t* plan, float* y, int64_t planes, in
 int ta_bsr_bwd(const float* gy, const int32_t* plan, float* gx, float* ws, int64_t planes, int h, int w, int copies,
                int nb, void* stream);
 
+/* ---- SSM / FGSRA spectrum transform: SSM.transform  input_transformation/ssm.py:41-54 (dct_2d / idct_2d :101-209),
+ * FGSRA neighbour sampling gradient/fgsra.py:125-140 ------------------------------------------------------------------
+ * out[p] = ( L . (in[p] + add[p]) . R^T ) * mul[p]  for every n x n plane p (n a multiple of 32, <= 256); `add` and
+ * `mul` nullable; L, R: row-major n x n fp32 on the device.  With C the DCT-II matrix (C[k][m] = 2 cos(pi (2m+1) k / 2n))
+ * and D = C^-1:  y = IDCT2(DCT2(x + noise) * mask) = ta_dct_pair(ta_dct_pair(x, noise, mask; C, C), -, -; D, D), and its
+ * backward is the same two launches with D^T and C^T.  fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32, fixed k order). */
+int ta_dct_pair(const float* in, const float* add, const float* mul, float* out, const float* lmat, const float* rmat,
+                int64_t planes, int n, void* stream);
+
 /* ---- VMI-FGSM: VMIFGSM.get_variance  gradient/vmifgsm.py:42-58 --------------------------------------
  * neighbour: out = x + d + U(-radius, radius)   (Philox (seed, offset) or caller `noise`)
  * accumulate: acc (+)= g  (first!=0 -> acc = g);  finalize: var = acc / count - cur_grad

@@ -210,8 +210,18 @@ _NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum",
           "normalize_bwd"]
 
 
+def _fft_spectrum_view(x, noise, mask):
+    """the reference's own arithmetic (Makhoul FFT factorisation on torch's CPU path): what the host-logic tier pins"""
+    from transferattack_amd.spectrum import MakhoulDct
+    calls.append("spectrum_view")
+    pair = MakhoulDct()
+    return pair.idct_2d(pair.dct_2d(x + noise) * mask)
+
+
 def install(monkeypatch):
     del calls[:]
+    from transferattack_amd import spectrum
+    monkeypatch.setattr(spectrum, "spectrum_view", _fft_spectrum_view)
     for name in _NAMES:
         assert hasattr(_hip, name), name
         monkeypatch.setattr(_hip, name, globals()[name])

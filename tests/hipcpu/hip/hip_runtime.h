@@ -10,6 +10,7 @@
 // side; `__shared__` arrays are thread_local statics (one workgroup per OS thread at a time).  Only what the csrc
 // kernels use is provided.
 #pragma once
+#define TA_HOST_STANDIN 1
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -73,7 +74,17 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only used on wave-uniform values */
 #define __builtin_assume(cond) ((void)0)
-namespace hipcpu { int wave_any(int pred); }
+namespace hipcpu { int wave_any(int pred); void mfma_f32_16x16x4(float a, float b, float (&c)[4]); }
+struct f32x4 {                                   /* clang's ext_vector_type(4) float: .x/.y/.z/.w and [] */
+    float x, y, z, w;
+    float& operator[](int i) { return (&x)[i]; }
+    float operator[](int i) const { return (&x)[i]; }
+};
+static inline f32x4 hipcpu_mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    float d[4] = {c.x, c.y, c.z, c.w};
+    hipcpu::mfma_f32_16x16x4(a, b, d);
+    return f32x4{d[0], d[1], d[2], d[3]};
+}
 static inline int __any(int pred) { return hipcpu::wave_any(pred); }
 template <class V> static inline V __builtin_elementwise_fma(V a, V b, V c) {     /* clang's vector fma, per element */
     return V{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};

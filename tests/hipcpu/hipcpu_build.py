@@ -20,10 +20,11 @@ def _host_text(text):
     # clang's ext_vector_type has no g++ counterpart with .x/.y members
     text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
     text = text.replace("typedef float v2f __attribute__((ext_vector_type(2)));", "struct alignas(8) v2f { float x, y; };")
+    text = text.replace("typedef float f32x4 __attribute__((ext_vector_type(4)));", "/* f32x4: tests/hipcpu/hip/hip_runtime.h */")
     return text
 
 
-HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip")
+HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip", "spectrum.hip")
 
 
 # HIPCPU_SANITIZE=1: AddressSanitizer build (one worker thread, `__shared__` arrays as plain statics).  Every load /

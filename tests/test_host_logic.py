@@ -345,48 +345,20 @@ def test_ssm_matches_reference(golden, monkeypatch):
     assert "grad_accumulate" in fake_hip.calls
 
 
-def test_dct_as_gemm_matches_fft_form(monkeypatch):
-    """TA_DCT_GEMM=1: the dense-matrix DCT pair is the same transform as the FFT factorisation the reference carries
-    (fgsra.py:49-123) up to fp32 rounding, inverts it, and lets autograd through."""
-    from transferattack_amd.spectrum import MakhoulDct
+def test_dct_matrices_are_the_reference_transform():
+    """the matrices ta_dct_pair multiplies with: C is the reference's unnormalised DCT-II (fgsra.py:49-123 as a matrix),
+    D its inverse -- checked against the FFT factorisation the reference carries, in fp64-built fp32"""
+    from transferattack_amd.spectrum import MakhoulDct, dct_matrices
     fft = MakhoulDct()
-    monkeypatch.setenv("TA_DCT_GEMM", "1")
-    gemm = MakhoulDct()
-    assert gemm.use_gemm and not fft.use_gemm
     gen = torch.Generator().manual_seed(3)
-    for shape in ((2, 3, 224, 224), (1, 2, 7, 10), (1, 1, 32, 40)):
-        x = torch.rand(shape, generator=gen)
-        a, b = fft.dct_2d(x), gemm.dct_2d(x)
-        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
-        ia, ib = fft.idct_2d(a), gemm.idct_2d(a)
-        assert float((ia - ib).abs().max()) <= 1e-5 * float(ia.abs().max())
-        assert float((gemm.idct_2d(gemm.dct_2d(x)) - x).abs().max()) <= 2e-5
-    xg = torch.rand(1, 1, 16, 16, generator=gen).requires_grad_(True)
-    g1 = torch.autograd.grad(gemm.idct_2d(gemm.dct_2d(xg) * 1.5).sum(), xg)[0]
-    assert torch.allclose(g1, torch.full_like(g1, 1.5), atol=1e-4)
-
-
-def test_frequency_attacks_with_gemm_dct(golden, monkeypatch):
-    """SSM / FGSRA with TA_DCT_GEMM=1 against the reference's golden loops: the transform differs by rounding only, so
-    the perturbations differ in at most the few pixels whose momentum sign that decides"""
-    from conftest import u8_images
-    fake_hip.install(monkeypatch)
-    monkeypatch.setenv("TA_DCT_GEMM", "1")
-    g, base = golden("sia"), golden("loops_toy")
-    x224 = u8_images(1, 224, 23).float() / 255
-    atk = make("ssm", num_spectrum=3, epoch=3)
-    assert atk._dct.use_gemm
-    atk.noise_source = lambda shape, lo, hi: torch.randn(shape) if lo is None else torch.rand(shape)
-    torch.manual_seed(4321)
-    d = atk(x224, t(base["label"])[:1]).numpy()
-    assert float((d != g["delta_ssm"]).mean()) <= 0.01
-    e = golden("loops_ens")
-    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
-    atk = make("fgsra", max_iter=4)
-    atk.noise_source = lambda shape, lo, hi: torch.rand(shape)
-    torch.manual_seed(1234)
-    d = atk(x, label).numpy()
-    assert float((d != e["delta_fgsra"]).mean()) <= 0.01
+    for n in (32, 64, 224):
+        c, d, ct, dt = dct_matrices(n, "cpu")
+        assert torch.equal(ct, c.t()) and torch.equal(dt, d.t())
+        x = torch.rand(2, 1, n, n, generator=gen)
+        a = fft.dct_2d(x)
+        assert float((c @ x @ ct - a).abs().max()) <= 2e-6 * float(a.abs().max())
+        assert float((d @ a @ dt - fft.idct_2d(a)).abs().max()) <= 1e-5 * float(x.abs().max())
+        assert float((d.double() @ c.double() - torch.eye(n, dtype=torch.float64)).abs().max()) <= 1e-6
 
 
 def test_config2_miniature_matches_reference(golden, monkeypatch):

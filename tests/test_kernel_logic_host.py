@@ -311,5 +311,6 @@ def test_reference_sum_order_gpu_test_on_host(golden, monkeypatch, widened_on_ho
 
 
 
-def test_dct_forms_gpu_test_on_host(monkeypatch, widened_on_host):
-    W.test_dct_forms_agree_on_device(monkeypatch)
+@pytest.mark.parametrize("shape", [(1, 1, 224, 224), (2, 1, 32, 32), (1, 2, 64, 64)])
+def test_spectrum_kernel(widened_on_host, shape):
+    W.test_spectrum_kernel(shape)

@@ -25,8 +25,9 @@ literal)
 kernels)
   timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
 freq)
-  # SSM (20 spectrum views per iteration) with the rocFFT DCT pair and with the GEMM form
-  for v in 0 1; do TA_DCT_GEMM=$v timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | sed "s/^/TA_DCT_GEMM=$v /" | tee -a $OUT/bench_ssm_b16.txt; done ;;
+  # SSM (20 spectrum views per iteration): the transform is two launches of the fp32-MFMA kernel ta_dct_pair
+  timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ssm_b16.json
+  timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -8 | tee $OUT/spectrum_microbench.txt ;;
 k2sweep)
   mkdir -p tools/bin; [ -x tools/bin/k2_sweep ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/k2_sweep.hip -o tools/bin/k2_sweep
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ta_bsr_tiles": (_i64, [_int]),
     "ta_bsr_fwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
     "ta_bsr_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
+    "ta_dct_pair": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "ta_vmi_neighbor": (_int, [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_grad_accumulate": (_int, [_vp, _vp, _int, _i64, _vp]),
     "ta_variance_finalize": (_int, [_vp, _vp, _vp, _f32, _i64, _vp]),
@@ -428,6 +429,14 @@ def bsr_bwd(gy, plan, gx, copies, num_block):
         _register_partials(gx, ws, per_image * tiles)
     else:
         _wrote(gx)
+
+
+def dct_pair(inp, add, mul, out, lmat, rmat):
+    """out = (L . (inp + add) . R^T) * mul on every n x n plane (add / mul may be None)"""
+    n = inp.shape[-1]
+    _wrote(out)
+    _call("ta_dct_pair", inp, _ptr(inp, name="in"), _ptr(add, name="add"), _ptr(mul, name="mul"), _ptr(out, name="out"),
+          _ptr(lmat, name="L"), _ptr(rmat, name="R"), inp.numel() // (n * n), n)
 
 
 # ---------------------------------------------------------------------------------------------- VMI / NI

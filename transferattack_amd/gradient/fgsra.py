@@ -8,6 +8,7 @@ factorisation, unnormalised), :163-215 (loop).  HIP: momentum, ``ta_update_delta
 the FFTs are rocFFT through torch.fft, differentiable, as in the reference."""
 import torch
 
+from .. import spectrum
 from ..attack import Attack
 from ..spectrum import MakhoulDct
 
@@ -54,9 +55,8 @@ class FGSRA(Attack):
     def spectrum_neighbor(self, x):
         radius = self.epsilon * self.beta
         jitter = self._unit_uniform(x) * 2 * radius - radius
-        coeffs = self.dct_2d(x + jitter)
         mask = self._unit_uniform(x) * 2 * self.rho + 1 - self.rho
-        return self.idct_2d(coeffs * mask)
+        return spectrum.spectrum_view(x, jitter, mask)         # idct_2d(dct_2d(x + jitter) * mask)
 
     def forward(self, data, label, **kwargs):
         data, label = self._to_device(data, label)

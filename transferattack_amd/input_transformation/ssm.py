@@ -1,12 +1,12 @@
 """SSM / SSA (Long et al., ECCV 2022) -- spectrum simulation: each iteration averages the gradients of
 ``num_spectrum`` spectrum-perturbed views idct2(dct2(x + N(0, eps^2)) * U(1 - rho, 1 + rho)), taken with respect to
 the VIEW itself (not back through the transform), then runs the MI-FGSM update.
-Mirror of transferattack/input_transformation/ssm.py:34-99.  HIP: gradient accumulation, momentum + projected step;
-the DCT pair is torch.fft = rocFFT (``spectrum.MakhoulDct``).  The reference hard-codes a 3 x 224 x 224 Gaussian
-(ssm.py:48); so does the shape check here."""
+Mirror of transferattack/input_transformation/ssm.py:34-99.  HIP: the spectrum view itself (``spectrum.spectrum_view``:
+two launches of the fp32-MFMA kernel ``ta_dct_pair`` instead of ~60 FFT-path launches), gradient accumulation, momentum +
+projected step.  The reference hard-codes a 3 x 224 x 224 Gaussian (ssm.py:48); so does the shape check here."""
 import torch
 
-from .. import _hip
+from .. import _hip, spectrum
 from ..gradient.mifgsm import MIFGSM
 from ..spectrum import MakhoulDct
 
@@ -28,9 +28,8 @@ class SSM(MIFGSM):
 
     def transform(self, x, **kwargs):
         gauss = (self._draw((x.size()[0], 3, 224, 224), True) * self.epsilon).to(self.device)
-        spectrum = self._dct.dct_2d(x + gauss)
         mask = (self._draw(tuple(x.shape), False) * 2 * self.rho + 1 - self.rho).to(self.device)
-        return self._dct.idct_2d(spectrum * mask)
+        return spectrum.spectrum_view(x, gauss, mask)          # idct_2d(dct_2d(x + gauss) * mask), ssm.py:48-52
 
     def forward(self, data, label, **kwargs):
         data, label = self._to_device(data, label)
