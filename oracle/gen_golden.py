@@ -225,6 +225,24 @@ def gen_loops_more():
     save("loops_more", **out)
 
 
+TAIL = (("mig", dict(s_factor=5)), ("aifgtm", {}), ("mef", dict(num_neighbor=4, epoch=6)), ("gaa", dict(N=3, epoch=5)),
+        ("dem", {}))
+
+
+def gen_loops_tail():
+    """the long tail of SURVEY.md 2.2 that rides on the same hooks: MIG (mig.py:41-84), AI-FGTM (aifgtm.py:53-95), MEF
+    (mef.py:69-128), GAA (gaa.py:44-100), DEM (dem.py:52-117) -- whole loops by the reference's own classes on the toy CNN"""
+    n, size = 4, 32
+    x = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    out = {}
+    for name, kw in TAIL:
+        atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False), **kw)
+        torch.manual_seed(1234)
+        out["delta_" + name] = atk(x, label)
+    save("loops_tail", **out)
+
+
 def gen_loops_ens():
     """SURVEY.md 8(f) rank 4, continued: AdaEA and SMER by the reference's own classes on three toy members
     (Gaussian / uniform start from the CPU generator; SMER's member order from the numpy generator).  SMER's member
@@ -395,6 +413,6 @@ ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_tail", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
     for w in which:
         globals()["gen_" + w]()

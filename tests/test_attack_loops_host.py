@@ -55,6 +55,12 @@ def test_more_gradient_attacks_vs_reference(golden, name, kw):
     A.test_more_gradient_attacks_gpu_vs_reference(golden, name, kw)
 
 
+@pytest.mark.parametrize("name,kw", [("mig", dict(s_factor=5)), ("aifgtm", {}), ("mef", dict(num_neighbor=4, epoch=6)),
+                                     ("gaa", dict(N=3, epoch=5)), ("dem", {})])
+def test_long_tail_attacks_vs_reference(golden, name, kw):
+    A.test_long_tail_attacks_gpu_vs_reference(golden, name, kw)
+
+
 @pytest.mark.parametrize("name", _subset(["svre", "cwa"], {"cwa"}))
 def test_per_member_ensemble_attacks(golden, name):
     A.test_per_member_ensemble_attacks_gpu(golden, name)

@@ -155,6 +155,21 @@ def test_more_gradient_attacks_gpu_vs_reference(golden, name, kw):
     assert mismatch <= 0.001
 
 
+@pytest.mark.parametrize("name,kw", [("mig", dict(s_factor=5)), ("aifgtm", {}), ("mef", dict(num_neighbor=4, epoch=6)),
+                                     ("gaa", dict(N=3, epoch=5)), ("dem", {})])
+def test_long_tail_attacks_gpu_vs_reference(golden, name, kw):
+    """MIG / AI-FGTM / MEF / GAA / DEM end to end on the GPU against the reference's golden loops"""
+    g, base = golden("loops_tail"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    atk = make(name, **kw)
+    torch.manual_seed(1234)
+    delta = atk(x, label).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-7
+    mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
+    print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
+    assert mismatch <= 0.005
+
+
 def test_variants_run_on_gpu(golden):
     g = golden("loops_toy")
     x, label = t(g["x_u8"]).float() / 255, t(g["label"])

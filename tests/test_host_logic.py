@@ -193,6 +193,26 @@ def test_more_gradient_attacks_match_reference(golden, monkeypatch, name, kw):
         assert np.array_equal(d.numpy(), g["delta_mpifgsm"])
 
 
+TAIL = [("mig", dict(s_factor=5)), ("aifgtm", {}), ("mef", dict(num_neighbor=4, epoch=6)), ("gaa", dict(N=3, epoch=5)),
+        ("dem", {})]
+
+
+@pytest.mark.parametrize("name,kw", TAIL)
+def test_long_tail_attacks_match_reference(golden, monkeypatch, name, kw):
+    """MIG, AI-FGTM, MEF, GAA, DEM: the product's loops reproduce the REAL reference's perturbations bit for bit on the
+    host-logic tier (draw order incl. GAA's discarded rand_like tensor, DEM's per-rate geometries, step schedules)"""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    torch.manual_seed(1234)
+    delta = make(name, **kw)(x, label)
+    assert np.array_equal(delta.numpy(), g["delta_" + name])
+    if name in ("mig", "mef", "dem"):
+        assert "mi_update" in fake_hip.calls
+    if name == "dem":
+        assert fake_hip.calls.count("dim_fwd") == 50          # five views per iteration, always applied
+
+
 @pytest.mark.parametrize("name", ["svre", "cwa"])
 def test_per_member_ensemble_attacks_match_reference(golden, monkeypatch, name):
     """SVRE / CWA index EnsembleModel.models[k]; random start and member choice follow the

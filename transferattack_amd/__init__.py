@@ -28,6 +28,10 @@ attack_zoo = {
     'pcifgsm': ('.gradient.pcifgsm', 'PCIFGSM'),
     'smifgrm': ('.gradient.smifgrm', 'SMIFGRM'),
     'fgsra': ('.gradient.fgsra', 'FGSRA'),
+    'mig': ('.gradient.mig', 'MIG'),
+    'aifgtm': ('.gradient.aifgtm', 'AIFGTM'),
+    'mef': ('.gradient.mef', 'MEF'),
+    'gaa': ('.gradient.gaa', 'GAA'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
@@ -35,6 +39,7 @@ attack_zoo = {
     'admix': ('.input_transformation.admix', 'Admix'),
     'sia': ('.input_transformation.sia', 'SIA'),
     'bsr': ('.input_transformation.bsr', 'BSR'),
+    'dem': ('.input_transformation.dem', 'DEM'),
     'ssm': ('.input_transformation.ssm', 'SSM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
     # ensemble
