@@ -67,6 +67,18 @@ def main():
                                                                         0.006, 0.06, sets[i % 3][3])), 16)
         rec("mi_update_two_launch", timed(lambda i: _hip.mi_update(sets[i % 3][0], sets[i % 3][1], sets[i % 3][1],
                                                                    sets[i % 3][2], sets[i % 3][3], 1.0, 0.006, 0.06)), 24)
+        if n == 32:
+            import random
+            import numpy as np
+            from transferattack_amd.transforms import bsr_draw
+            random.seed(1); np.random.seed(1); torch.manual_seed(1)
+            plan = torch.from_numpy(bsr_draw((n, 3, 224, 224), 3, 20)).to(DEV)
+            stack = torch.empty(20 * n, 3, 224, 224, device=DEV)
+            rec("bsr_fwd_x20", timed(lambda i: _hip.bsr_fwd(sets[i % 3][0], plan, stack, 20, 3), reps=6), 4 + 4 * 20)
+            rec("bsr_bwd_x20", timed(lambda i: _hip.bsr_bwd(stack, plan, sets[i % 3][1], 20, 3), reps=6), 4 * 20 + 4)
+            del stack
+            members = [sets[k][0] for k in range(3)] + [sets[0][1]]
+            rec("sum_members_x4", timed(lambda i: _hip.sum_members(members, sets[i % 3][2])), 20)
         if big is not None:
             rec("sim_fwd_x5", timed(lambda i: _hip.scale_copies_fwd(sets[i % 3][0], big[i % 2], 5)), 24)
             rec("sim_bwd_x5", timed(lambda i: _hip.scale_copies_bwd(big[i % 2], sets[i % 3][0], 5)), 24)
