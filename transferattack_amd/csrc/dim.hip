@@ -645,7 +645,9 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
         const int rows = static_cast<int>(ceil((kDimLaneRows - 1) * ratio)) + 4;       // window rows + 1 row of x
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
-            const int pp = planes % 3 == 0 ? 3 : 1;           // the planes of an RGB image share the tile's taps
+            // planes per workgroup: the forward's taps are cheap to build, sharing them over the three planes of an image
+            // only costs parallelism (measured r2e: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480) -> one plane each
+            const int pp = 1;
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
@@ -686,7 +688,9 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
-            const int pp = planes % 3 == 0 ? 3 : 1;           // the planes of an RGB image share the tile tables
+            // the three planes of an RGB image share one workgroup's hit tables (a quarter of the backward's instructions)
+            // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
+            const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));

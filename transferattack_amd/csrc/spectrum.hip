@@ -16,8 +16,9 @@
 // chunk of R are staged in LDS (row stride 34 dwords: the 16 rows x 2 k-values a 32-lane read group touches fall on 32
 // distinct banks), each wave keeps n/32 accumulator tiles (7 at n = 224: 16 x 16 each, one B operand read serves them
 // all).  P goes to LDS transposed (stride n + 2: conflict-free as the B operand of step 2), step 2 streams L through the
-// same chunk buffer and leaves OUT[:, cb] in the accumulators; the mask multiply is the epilogue.  64 KB of LDS ->
-// two workgroups per CU.  Results are deterministic (fixed k order, no atomics) and agree with the FFT form to fp32
+// same chunk buffer and leaves OUT[:, cb] in the accumulators; the mask multiply is the epilogue.  Every chunk's global
+// loads are issued back to back one chunk ahead (registers), so they fly while the current chunk is multiplied.  70 KB
+// of LDS -> two workgroups per CU.  Results are deterministic (fixed k order, no atomics) and agree with the FFT form to fp32
 // rounding (tests: <= 2e-6 of max|y|).
 #include "ta_common.h"
 
@@ -42,20 +43,40 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 #endif
 }
 
-// stage rows [0, n) x columns [c0, c0 + 32) of a row-major n x n matrix (plus `add`) into chunk[r * kSpecLD + c]
+// One K chunk of an n x n row-major operand on its way to LDS: a thread owns n / 32 float4 (row q >> 3, columns
+// 4 * (q & 7) .., q = thread + 256 * u).  `fetch` issues all loads of the thread back to back (one memory round trip
+// per chunk, in flight while the previous chunk is multiplied); `commit` adds the second operand and writes LDS.
+struct ChunkRegs {
+    float4 v[kSpecMaxTiles];
+    float4 a[kSpecMaxTiles];
+};
+
 template <bool HAS_ADD>
-__device__ __forceinline__ void stage_chunk(float* __restrict__ chunk, const float* __restrict__ src,
-                                            const float* __restrict__ add, int n, int c0) {
-    for (int q = threadIdx.x; q < n * (kSpecKC / 4); q += kBlock) {
-        const int r = q >> 3, c4 = (q & 7) * 4;
-        float4 v = *reinterpret_cast<const float4*>(src + static_cast<int64_t>(r) * n + c0 + c4);
-        if (HAS_ADD) {
-            const float4 a = *reinterpret_cast<const float4*>(add + static_cast<int64_t>(r) * n + c0 + c4);
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+__device__ __forceinline__ void fetch_chunk(ChunkRegs& regs, const float* __restrict__ src, const float* __restrict__ add,
+                                            int n, int c0) {
+#pragma unroll
+    for (int u = 0; u < kSpecMaxTiles; ++u) {
+        const int q = threadIdx.x + kBlock * u;
+        if (u < n / 32) {
+            const int64_t off = static_cast<int64_t>(q >> 3) * n + c0 + (q & 7) * 4;
+            regs.v[u] = *reinterpret_cast<const float4*>(src + off);
+            if (HAS_ADD) regs.a[u] = *reinterpret_cast<const float4*>(add + off);
         }
-        float2* dst = reinterpret_cast<float2*>(chunk + r * kSpecLD + c4);      // rows are 8-byte aligned (stride 34)
-        dst[0] = float2{v.x, v.y};
-        dst[1] = float2{v.z, v.w};
+    }
+}
+
+template <bool HAS_ADD>
+__device__ __forceinline__ void commit_chunk(float* __restrict__ chunk, const ChunkRegs& regs, int n) {
+#pragma unroll
+    for (int u = 0; u < kSpecMaxTiles; ++u) {
+        const int q = threadIdx.x + kBlock * u;
+        if (u < n / 32) {
+            float4 v = regs.v[u];
+            if (HAS_ADD) { v.x += regs.a[u].x; v.y += regs.a[u].y; v.z += regs.a[u].z; v.w += regs.a[u].w; }
+            float2* dst = reinterpret_cast<float2*>(chunk + (q >> 3) * kSpecLD + (q & 7) * 4);   // rows 8-byte aligned
+            dst[0] = float2{v.x, v.y};
+            dst[1] = float2{v.z, v.w};
+        }
     }
 }
 
@@ -77,30 +98,42 @@ __global__ __launch_bounds__(kBlock) void dct_pair_kernel(const float* __restric
     const int ldp = n + 2;
     const float* inp = in + plane * n * n;
     const float* addp = HAS_ADD ? add + plane * n * n : nullptr;
+    const float* rrow = rmat + static_cast<int64_t>(cb * kSpecCB + (threadIdx.x >> 3)) * n + (threadIdx.x & 7) * 4;
 
     f32x4 acc[kSpecMaxTiles];
 #pragma unroll
     for (int i = 0; i < kSpecMaxTiles; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    // ---- step 1: P[r][k] = sum_m A[r][m] * R[cb * 32 + k][m]
-    for (int m0 = 0; m0 < n; m0 += kSpecKC) {
-        __syncthreads();                                 // the previous chunk has been consumed
-        stage_chunk<HAS_ADD>(chunk, inp, addp, n, m0);
-        {
-            const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;          // 32 rows x 8 float4: one per thread
-            const float4 v = *reinterpret_cast<const float4*>(rmat + static_cast<int64_t>(cb * kSpecCB + r) * n + m0 + c4);
-            float2* dst = reinterpret_cast<float2*>(rch + r * kSpecLD + c4);
-            dst[0] = float2{v.x, v.y};
-            dst[1] = float2{v.z, v.w};
-        }
-        __syncthreads();
+    auto multiply = [&](const float* __restrict__ bsrc, int bstride, int b0) {
 #pragma unroll
         for (int s = 0; s < kSpecKC / 4; ++s) {
-            const float b = rch[(ct * 16 + li) * kSpecLD + 4 * s + lk];
+            const float b = bsrc[(ct * 16 + li) * bstride + b0 + 4 * s + lk];
 #pragma unroll
             for (int i = 0; i < kSpecMaxTiles; ++i)
                 if (i < cnt) acc[i] = mfma_16x16x4(chunk[((rt0 + 2 * i) * 16 + li) * kSpecLD + 4 * s + lk], b, acc[i]);
         }
+    };
+
+    // ---- step 1: P[r][k] = sum_m A[r][m] * R[cb * 32 + k][m]
+    ChunkRegs regs;
+    float4 rreg;
+    fetch_chunk<HAS_ADD>(regs, inp, addp, n, 0);
+    rreg = *reinterpret_cast<const float4*>(rrow);
+    for (int m0 = 0; m0 < n; m0 += kSpecKC) {
+        commit_chunk<HAS_ADD>(chunk, regs, n);
+        {
+            float2* dst = reinterpret_cast<float2*>(rch + (threadIdx.x >> 3) * kSpecLD + (threadIdx.x & 7) * 4);
+            dst[0] = float2{rreg.x, rreg.y};
+            dst[1] = float2{rreg.z, rreg.w};
+        }
+        __syncthreads();
+        if (m0 + kSpecKC < n) {                           // the next chunk's loads fly while this one is multiplied
+            fetch_chunk<HAS_ADD>(regs, inp, addp, n, m0 + kSpecKC);
+            rreg = *reinterpret_cast<const float4*>(rrow + m0 + kSpecKC);
+        } else {
+            fetch_chunk<false>(regs, lmat, nullptr, n, 0);                   // ... or the first chunk of L for step 2
+        }
+        multiply(rch, kSpecLD, 0);
+        __syncthreads();                                  // the chunk has been consumed
     }
     // ---- P to LDS, transposed: pt[k][r]
 #pragma unroll
@@ -113,16 +146,11 @@ __global__ __launch_bounds__(kBlock) void dct_pair_kernel(const float* __restric
         }
     // ---- step 2: OUT[j][k] = sum_r L[j][r] * P[r][k]
     for (int r0 = 0; r0 < n; r0 += kSpecKC) {
-        __syncthreads();                                 // pt complete (first trip) / previous chunk consumed
-        stage_chunk<false>(chunk, lmat, nullptr, n, r0);
+        commit_chunk<false>(chunk, regs, n);
+        __syncthreads();                                  // chunk (and, on the first trip, pt) complete
+        if (r0 + kSpecKC < n) fetch_chunk<false>(regs, lmat, nullptr, n, r0 + kSpecKC);
+        multiply(pt, ldp, r0);
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < kSpecKC / 4; ++s) {
-            const float b = pt[(ct * 16 + li) * ldp + r0 + 4 * s + lk];
-#pragma unroll
-            for (int i = 0; i < kSpecMaxTiles; ++i)
-                if (i < cnt) acc[i] = mfma_16x16x4(chunk[((rt0 + 2 * i) * 16 + li) * kSpecLD + 4 * s + lk], b, acc[i]);
-        }
     }
     // ---- epilogue: (* mask), 64-byte row segments per 16 lanes
     const int k = cb * kSpecCB + ct * 16 + li;
