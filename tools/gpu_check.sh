@@ -41,6 +41,9 @@ gpus1)
   # the self-launch path of bench.py --gpus N on a one-GPU box: N = 1 under torch.distributed.run (RCCL world of 1)
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_torchrun_n1.json
   timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 2>&1 | tail -1 | tee $OUT/bench_gpus2_refused.txt ;;
+spec)
+  timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -10 | tee $OUT/spectrum_microbench.txt
+  timeout 300 python -m pytest tests/test_zz_hip_widened.py tests/test_hip_kernels.py -q -m gpu -k "spectrum or dim or ssm or fgsra" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/spec_pytest.txt ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
 rocprof)

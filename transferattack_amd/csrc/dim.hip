@@ -129,7 +129,7 @@ template <int RPW>                      // rows per wave of the LDS rectangles: 
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int pp) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
     __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
@@ -141,11 +141,13 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
     const int tiles = tiles_x * tiles_y;
     const int tid = static_cast<int>(blockIdx.x);
-    const int group = tid / tiles;                                     // `pp` consecutive planes share this tile's taps
-    const int t = tid - group * tiles;
+    const int plane = tid / tiles;                                     // grid < 2^31 (host-checked)
+    const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
     const int oy0 = tyi * kDimLaneRows, ox0 = (t - tyi * tiles_x) * tw;
     const int th = min(kDimLaneRows, size - oy0), twc = min(tw, size - ox0);    // rows / columns of this tile
+    const float* xp = x + static_cast<int64_t>(plane) * size * size;
+    float* yp = y + static_cast<int64_t>(plane) * size * size;
 
     // -- taps that do not depend on the window origin
     Tap tx2{0, 0, 0.f, 0.f};
@@ -171,10 +173,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int sr_lo = any_rows ? ty1[p_a].i0 : 0;
     const int sh = any_rows ? ty1[p_b].i1 - sr_lo + 1 : 0;             // <= ROWS
 
-    for (int q = 0; q < pp; ++q) {
-    if (q > 0) __syncthreads();                                        // V2 of the previous plane has read u (= T)
-    const float* xp = x + static_cast<int64_t>(group * pp + q) * size * size;
-    float* yp = y + static_cast<int64_t>(group * pp + q) * size * size;
     // -- H1: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1]); all loads of the lane first, 32-bit element offsets
     {
         float a[RPW], b[RPW];
@@ -239,7 +237,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
             }
         }
     }
-    }   // planes of the group
 }
 
 // --------------------------------------------------------------------------------------- backward
@@ -440,12 +437,13 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     return acc;
 }
 
-template <int RPW, int SB>              // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels)
+template <int RPW, int SB, int PP>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
+                                        // PP: planes per workgroup (they share the tile's hit tables)
 __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                float* __restrict__ ws, int size, int resize, int rnd,
                                                                int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int pp) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
     __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
@@ -458,8 +456,8 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = tiles_x * tiles_y;
     const int tid = static_cast<int>(blockIdx.x);
-    const int group = tid / tiles;                      // `pp` consecutive planes share this tile's tables (the geometry
-    const int t = tid - group * tiles;                  // is the same for every plane: built once, used pp times)
+    const int group = tid / tiles;                      // PP consecutive planes share this tile's tables (the geometry
+    const int t = tid - group * tiles;                  // is the same for every plane: built once, used PP times)
     const int tyi = t / tiles_x;
     const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
     const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
@@ -479,8 +477,9 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     }
     __syncthreads();
 
-    for (int q = 0; q < pp; ++q) {
-    const int plane = group * pp + q;
+#pragma unroll 1
+    for (int q = 0; q < PP; ++q) {
+    const int plane = group * PP + q;
     const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
     char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
     // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c]
@@ -645,18 +644,17 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
         const int rows = static_cast<int>(ceil((kDimLaneRows - 1) * ratio)) + 4;       // window rows + 1 row of x
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
-            // planes per workgroup: the forward's taps are cheap to build, sharing them over the three planes of an image
-            // only costs parallelism (measured r2e: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480) -> one plane each
-            const int pp = 1;
-            const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
-            TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
+            // (one plane per workgroup: sharing the forward's taps over the three planes of an image was measured slower at
+            // every size, r2e / r2f: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480)
+            const int64_t lane_blocks = planes * tiles_x * tiles_y;
+            TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, pp);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             else
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, pp);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -695,9 +693,15 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
-#define TA_DIM_BWD(RPW, SB)                                                                                          \
-    hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
-                       left, scale1, scale2, tw, tiles_x, tiles_y, pp)
+#define TA_DIM_BWD(RPW, SB)                                                                                              \
+    do {                                                                                                                 \
+        if (pp == 3)                                                                                                     \
+            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize,  \
+                               rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                                    \
+        else                                                                                                             \
+            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize,  \
+                               rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                                    \
+    } while (0)
             if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }
             else { if (three) TA_DIM_BWD(17, 3); else TA_DIM_BWD(17, 4); }
 #undef TA_DIM_BWD
