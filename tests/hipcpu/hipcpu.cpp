@@ -244,14 +244,3 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 }
 
 }  // namespace hipcpu
-
-// entry points of fused_update.hip: the single-launch exchange needs concurrently resident workgroups that can see
-// each other's progress, which this model (a workgroup runs to completion on its OS thread) does not provide
-namespace ta { void set_error(const char* fmt, ...); }
-extern "C" int64_t ta_fused_sync_bytes(int64_t, int64_t) { return 8; }
-extern "C" int ta_mi_update_fused(const float*, const float*, const float*, float*, float*, const float*, float*, void*,
-                                  float, float, float, int64_t, int64_t, void*) {
-    ta::set_error("ta_mi_update_fused is not available in the host stand-in");
-    return -1;
-}
-extern "C" int ta_fused_sync_error(void*, int64_t, int64_t, void*) { return 0; }

@@ -1,4 +1,4 @@
-// Device helpers shared by the two-launch (update.hip) and single-launch (fused_update.hip) update paths.
+// Device helpers of the update stack (update.hip).
 #pragma once
 #include "ta_common.h"
 
