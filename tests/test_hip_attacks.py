@@ -130,7 +130,7 @@ def test_end_to_end_gpu_vs_reference(golden, name):
     u8_ref = O.quantize_u8(x + ref)
     mismatch = float((u8_gpu != u8_ref).mean())
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
-    assert mismatch <= 0.001
+    assert mismatch <= 0.002          # measured on MI355X: <= 0.033 % (profiles/r02/pytest_gpu_summary_r2e.txt)
     cpu_models = [m.cpu() for m in models]
     victims = cpu_models if name == "ens" else cpu_models[0]
     victim = O.logits_of(victims, t(u8_gpu).permute(0, 3, 1, 2).float() / 255)
@@ -152,7 +152,7 @@ def test_more_gradient_attacks_gpu_vs_reference(golden, name, kw):
     assert float(delta.abs().max()) <= EPS + 1e-7
     mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
-    assert mismatch <= 0.001
+    assert mismatch <= 0.002          # measured on MI355X: <= 0.033 % (profiles/r02/pytest_gpu_summary_r2e.txt)
 
 
 @pytest.mark.parametrize("name,kw", [("mig", dict(s_factor=5)), ("aifgtm", {}), ("mef", dict(num_neighbor=4, epoch=6)),
@@ -323,4 +323,4 @@ def test_per_member_ensemble_attacks_gpu(golden, name):
     assert float(delta.abs().max()) <= EPS + 1e-7
     mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
-    assert mismatch <= 0.001
+    assert mismatch <= 0.002          # measured on MI355X: <= 0.033 % (profiles/r02/pytest_gpu_summary_r2e.txt)
