@@ -117,6 +117,9 @@ KERNEL_BYTES = {
     "admix_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
     "sia_fwd": lambda x, plan, y, *a, **k: _NB(x) + _NB(y),
     "sia_bwd": lambda gy, plan, x, gx, *a, **k: _NB(gy) + 2 * _NB(x),
+    "bsr_fwd": lambda x, plan, y, *a: _NB(x) + _NB(y),
+    "bsr_bwd": lambda gy, plan, gx, *a: _NB(gy) + _NB(gx),
+    "dct_pair": lambda inp, add, mul, out, *a: _NB(inp) * (2 + (add is not None) + (mul is not None)),
     "vmi_neighbor": lambda data, delta, out, *a, **k: 3 * _NB(data),
     "grad_accumulate": lambda acc, grad, first: _NB(acc) * (2 if first else 3),
     "variance_finalize": lambda acc, cur, out, *a: 3 * _NB(acc),
@@ -291,6 +294,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _hip.profile_sink = []
+    timing_note = None
+    try:
+        _hip.timing_begin(args.steps * 64 + 64)     # events on the update kernels' own dispatch packets
+    except _hip.HipExtensionError as exc:
+        timing_note = str(exc)[:200]
     _hip.stats["partials_reused"] = _hip.stats["k1_passes"] = 0
     kernel_records, restore_kernels = (instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
                                        if args.kernel_times else ({}, lambda: None))
@@ -304,6 +312,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sink, _hip.profile_sink = _hip.profile_sink, None
+    dispatch_ms = []
+    if timing_note is None:
+        try:
+            dispatch_ms = _hip.timing_end()
+        except _hip.HipExtensionError as exc:
+            timing_note = str(exc)[:200]
     restore_kernels()
     per_rank = [round(args.steps * args.batch / mine, 2)]
     observed_world, backend = 1, "none (single process)"
@@ -322,11 +336,20 @@ def main():
             x0 = batches[0][0]
             g0, m0, d0 = torch.randn_like(x0) * 1e-4, torch.randn_like(x0), torch.zeros_like(x0)
             _hip.profile_sink = sink = []
+            _hip.timing_begin(32)
             for _ in range(20):
                 _hip.mi_update(g0, m0, m0, d0, x0, 1.0, 1.6 / 255, 16 / 255)
             torch.cuda.synchronize()
             _hip.profile_sink = None
-        durs_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
+            dispatch_ms = _hip.timing_end()
+        # two clocks over the same launches: hipEventRecord markers before / after each call (they include the ~3 us the
+        # command processor spends between a marker and a dependent kernel) and events bound to the kernels' own dispatch
+        # packets (begin of the call's first kernel -> end of the update kernel: what rocprofv3 --kernel-trace reports).
+        # The roofline figure uses the dispatch clock when it is sane, and always reports the marker clock beside it.
+        marker_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
+        durs_us, clock = marker_us, "hipEventRecord markers around each call"
+        if len(dispatch_ms) == len(sink) and all(0.0 < 1e3 * d <= m + 1.0 for d, m in zip(dispatch_ms, marker_us)):
+            durs_us, clock = [1e3 * d for d in dispatch_ms], "HIP events bound to the kernels' dispatch packets"
         launch_bytes = [n_ * e_ * b_ for _, _, n_, e_, b_ in sink]
         n_, e_ = sink[0][2], sink[0][3]
         mean_us = sum(durs_us) / len(durs_us)
@@ -379,6 +402,9 @@ def main():
                                                     "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "clock": clock if timing_note is None else clock + " (dispatch clock unavailable: %s)" % timing_note,
+                         "marker_clock": {"mean_us": round(sum(marker_us) / len(marker_us), 2),
+                                          "frac": round(sum(launch_bytes) / sum(marker_us) / 1e3 / HBM_PEAK_GBS, 4)},
                          "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
                          "algorithmic_bytes_per_launch": int(mean_bytes),
                          "steady_state_launch": {"bytes": int(max(launch_bytes)),

@@ -26,11 +26,18 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 5
+#define TA_ABI_VERSION 6
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
 const char* ta_last_error(void);
+/* Launch timing (bench.py's roofline figure): between ta_timing_begin(capacity) and ta_timing_end, each ta_mi_update
+ * call (up to `capacity`) carries a pair of HIP events on the dispatch packets of its own kernels -- start on its first
+ * kernel (K1 when the |g| sums are not handed over, else the update kernel), stop on the update kernel.  ta_timing_end
+ * waits for them and writes begin->end milliseconds per call, in call order; *count = calls timed.  Not for use inside
+ * hipGraph capture.  One timing session per process at a time. */
+int ta_timing_begin(int capacity);
+int ta_timing_end(float* ms, int capacity, int* count);
 /* number of floats of scratch the l1-mean reduction needs for an (n, e) batch (>= n*ceil(e/3072)) */
 int64_t ta_l1_workspace_floats(int64_t n, int64_t e);
 /* |g| tile sums ("partials"): K1 and every elementwise producer below cut an image of e elements into

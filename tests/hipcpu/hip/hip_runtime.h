@@ -33,6 +33,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -124,6 +124,43 @@ def test_update_without_momentum():
             assert torch.equal(d_full, d_lean) and torch.equal(xa, x + d_lean)
 
 
+def test_launch_timing():
+    """ta_timing_begin / ta_timing_end: the fused update carries HIP events on its own dispatch packets -- same results
+    as an untimed call, one positive duration per call (two-launch and handed-over forms), never longer than the
+    hipEventRecord markers around the same call, and the session ends cleanly when fewer calls than capacity were made"""
+    gen = torch.Generator().manual_seed(5)
+    shape = (32, 3, 224, 224)
+    x = (torch.randint(0, 256, shape, generator=gen).float() / 255).to(DEV)
+    grad = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+    m0 = torch.randn(shape, generator=gen).to(DEV)
+    want_m, want_d = torch.empty_like(m0), torch.zeros(shape, device=DEV)
+    _hip.mi_update(grad, m0, want_m, want_d, x, 1.0, ALPHA, EPS)
+    torch.cuda.synchronize()
+    _hip.timing_begin(8)
+    markers, outs = [], []
+    for handed_over in (False, True, False):
+        got_m, got_d = torch.empty_like(m0), torch.zeros(shape, device=DEV)
+        if handed_over:
+            _hip.abs_sum_partials(grad)                     # registers the |g| sums: the timed call is the update kernel alone
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        _hip.mi_update(grad, m0, got_m, got_d, x, 1.0, ALPHA, EPS)
+        end.record()
+        markers.append((start, end))
+        outs.append((got_m, got_d))
+    torch.cuda.synchronize()
+    ms = _hip.timing_end()
+    assert len(ms) == 3
+    for (got_m, got_d), (start, end), t in zip(outs, markers, ms):
+        assert torch.equal(got_m, want_m) and torch.equal(got_d, want_d)
+        assert 0.005 < t <= start.elapsed_time(end) + 0.001, (t, start.elapsed_time(end))      # > 5 us: 135 MB moved
+    assert ms[1] < ms[0] and ms[1] < ms[2]                  # without the K1 pass
+    with pytest.raises(_hip.HipExtensionError):
+        _hip.timing_end()                                   # not armed any more
+    _hip.mi_update(grad, m0, got_m, got_d, x, 1.0, ALPHA, EPS)          # untimed launches keep working
+    torch.cuda.synchronize()
+
+
 def _k1_sums(t):
     """per-image sum|t| the way K1 adds it: [n] float32 (the fixed-order total the fused update divides by E)"""
     n, e = t.shape[0], t[0].numel()

@@ -27,6 +27,8 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "ta_abi_version": (_int, []),
     "ta_last_error": (ctypes.c_char_p, []),
+    "ta_timing_begin": (_int, [_int]),
+    "ta_timing_end": (_int, [_vp, _int, _vp]),
     "ta_l1_workspace_floats": (_i64, [_i64, _i64]),
     "ta_update_tiles": (_i64, [_i64]),
     "ta_conv_tiles": (_i64, [_int, _int, _int]),
@@ -61,7 +63,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipExtensionError(RuntimeError):
@@ -242,8 +244,31 @@ def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
           float(alpha), float(epsilon), _ptr(delta_out, name="delta_out"), _ptr(ws), n, e)
 
 
-# bench.py sets this to a list to time every fused-update launch with HIP events on the launch stream
+# bench.py sets this to a list to time every fused-update launch with HIP events on the launch stream: marker events
+# (hipEventRecord before / after the call) recorded here, and -- between timing_begin() and timing_end() -- events bound
+# to the dispatch packets of the call's own kernels (ta_timing_begin, include/ta_hip.h)
 profile_sink = None
+_timing_capacity = 0
+
+
+def timing_begin(capacity):
+    global _timing_capacity
+    rc = load().ta_timing_begin(int(capacity))
+    if rc != 0:
+        raise HipExtensionError("ta_timing_begin: %s" % load().ta_last_error().decode())
+    _timing_capacity = int(capacity)
+
+
+def timing_end():
+    """Milliseconds (first kernel's begin -> update kernel's end) of every fused update since timing_begin, in call order."""
+    global _timing_capacity
+    buf = (ctypes.c_float * max(_timing_capacity, 1))()
+    count = ctypes.c_int(0)
+    rc = load().ta_timing_end(ctypes.cast(buf, _vp), _timing_capacity, ctypes.cast(ctypes.pointer(count), _vp))
+    _timing_capacity = 0
+    if rc != 0:
+        raise HipExtensionError("ta_timing_end: %s" % load().ta_last_error().decode())
+    return [float(buf[i]) for i in range(count.value)]
 
 
 def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None):

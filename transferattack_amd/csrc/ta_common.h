@@ -1,6 +1,9 @@
 // Shared helpers for the gfx950 kernels of libta_hip.so (wave64, 256-thread workgroups).
 #pragma once
 #include <hip/hip_runtime.h>
+#if !defined(TA_HOST_STANDIN)
+#include <hip/hip_ext.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/ta_hip.h"
@@ -15,6 +18,14 @@ constexpr int kTile = kBlock * kVec * kUnroll;   // 3072 elements per workgroup 
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// Launch timing (ta_timing_begin / ta_timing_end, runtime.hip): while armed, every fused update claims a pair of HIP
+// events that ride on the dispatch packets of its own kernels (hipExtLaunchKernelGGL), so the elapsed time is the
+// kernels' begin -> end as the command processor stamps it, without the marker packets of hipEventRecord in between.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchEvents claim_launch_events();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -45,6 +56,20 @@ __device__ __forceinline__ float sign_of(float m) {   // torch.sign: NaN -> 0, +
 }
 
 }  // namespace ta
+
+// a launch that carries timing events when it is the first (start) / last (stop) kernel of a timed call
+#if defined(TA_HOST_STANDIN)
+#define TA_LAUNCH_TIMED(kernel, grid, block, st, ev_start, ev_stop, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__)
+#else
+#define TA_LAUNCH_TIMED(kernel, grid, block, st, ev_start, ev_stop, ...)                                 \
+    do {                                                                                                 \
+        if ((ev_start) != nullptr || (ev_stop) != nullptr)                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, __VA_ARGS__);        \
+        else                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                 \
+    } while (0)
+#endif
 
 #define TA_REQUIRE(cond, ...)                 \
     do {                                      \

@@ -451,7 +451,8 @@ static bool vec_ok(int64_t e, std::initializer_list<const void*> ptrs) {
 }
 
 static int launch_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e, bool square,
-                           hipStream_t st) {
+                           hipStream_t st, hipEvent_t ev_start = nullptr) {
+    const hipEvent_t no_event = nullptr;
     const int tiles = static_cast<int>(ceil_div(e, kTile));
     if (const int lanes = square ? 0 : aten_sum_lanes()) {
         const int cols = lanes * kAtenIlp;
@@ -461,17 +462,17 @@ static int launch_partials(const float* g, const float* v, float* ws, int64_t n,
         TA_REQUIRE(floats <= kAtenMaxLdsFloats && steps <= (1ll << 19),
                    "TA_ATEN_SUM_LANES: images of %lld elements exceed what the reference-order sum stages in LDS", (long long)e);
         if (v)
-            hipLaunchKernelGGL(aten_order_abs_sum_kernel<true>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, st, g, v, ws,
-                               e, tiles, lanes);
+            TA_LAUNCH_TIMED(aten_order_abs_sum_kernel<true>, dim3(static_cast<unsigned>(n)), dim3(kBlock), st, ev_start,
+                            no_event, g, v, ws, e, tiles, lanes);
         else
-            hipLaunchKernelGGL(aten_order_abs_sum_kernel<false>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, st, g, v,
-                               ws, e, tiles, lanes);
+            TA_LAUNCH_TIMED(aten_order_abs_sum_kernel<false>, dim3(static_cast<unsigned>(n)), dim3(kBlock), st, ev_start,
+                            no_event, g, v, ws, e, tiles, lanes);
         return check_launch("aten_order_abs_sum");
     }
     const dim3 grid(tiles, static_cast<unsigned>(n));
     const bool vec = vec_ok(e, {g, v});
 #define TA_K1(VEC, HV, SQ) \
-    hipLaunchKernelGGL((abs_sum_partials_kernel<VEC, HV, SQ>), grid, dim3(kBlock), 0, st, g, v, ws, e, tiles)
+    TA_LAUNCH_TIMED((abs_sum_partials_kernel<VEC, HV, SQ>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws, e, tiles)
     if (vec) {
         if (square) { TA_K1(4, false, true); }
         else if (v) { TA_K1(4, true, false); }
@@ -616,8 +617,10 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
     TA_REQUIRE(!(ws_slots && aten_sum_lanes() != 0),
                "TA_ATEN_SUM_LANES: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const LaunchEvents timed = claim_launch_events();          // null unless ta_timing_begin armed them
     if (ws_slots == 0)
-        if (int rc = launch_partials(g, v, ws, n, e, false, st)) return rc;
+        if (int rc = launch_partials(g, v, ws, n, e, false, st, timed.start)) return rc;
+    const hipEvent_t k2_start = ws_slots == 0 ? nullptr : timed.start;
     const int tiles_ws = ws_slots > 0 ? ws_slots : static_cast<int>(ceil_div(e, kTile));
     const StepParams p{decay, alpha, -eps, eps};
     const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
@@ -625,9 +628,9 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
     const bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
 #define TA_MI(VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA)                                                         \
-    hipLaunchKernelGGL((mi_update_kernel<VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA>),                            \
-                       dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),  \
-                       dim3(BLOCK), 0, st, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws)
+    TA_LAUNCH_TIMED((mi_update_kernel<VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA>),                               \
+                    dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),     \
+                    dim3(BLOCK), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws)
 #define TA_MI_CASES(VEC, BLOCK, SLOTS, NT)                                   \
     switch (key) {                                                           \
         case 0: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, false, false); break; \
