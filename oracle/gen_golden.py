@@ -243,6 +243,46 @@ def gen_loops_tail():
     save("loops_tail", **out)
 
 
+TAIL2 = (("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
+         ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
+         ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
+         ("anda", dict(n_ens=4, epoch=3)))
+
+
+def gen_loops_tail2():
+    """more of SURVEY.md 2.2 / 2.3 on the same hooks, whole loops by the reference's own classes on the toy CNN: I-FGS2M
+    (ifgssm.py:32-63), VA-I-FGSM (vaifgsm.py:31-126; its class count set to the toy's 10), AdaMSI-FGM
+    (adamsi_fgm.py:31-82), the MI-FGSM tricks (mifgsm_with_tricks.py:15-266), MaskBlock (maskblock.py:34-57), US-MM
+    (usmm.py:34-99), ANDA (anda.py:45-210, one image)"""
+    ref_shim.neutralise_cuda_calls()
+    n, size = 4, 32
+    x = u8_images(n, size, 20).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    out = {}
+    for name, kw in TAIL2:
+        atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False), **kw)
+        if name == "vaifgsm":
+            atk.num_classes = 10
+        torch.manual_seed(1234)
+        first = 1 if name == "anda" else n
+        out["delta_" + name] = atk(x[:first], label[:first]).detach()
+    # SSM with tricks (ssm_with_tricks.py:17-470): the Gaussian is hard-coded 3 x 224 x 224 -> 224-pixel input
+    x224 = u8_images(1, 224, 23).float() / 255
+    ref_shim.import_reference()
+    import importlib
+    from transferattack.utils import wrap_model
+    tricks = importlib.import_module("transferattack.input_transformation.ssm_with_tricks")
+    for name, kw in (("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))):
+        # (the reference's zoo entry for ssm_p names a class that does not exist, __init__.py:62 -> take the classes directly)
+        base = {"ssm_h": tricks.SSM_H, "ssm_p": tricks.SSM_P}[name]
+        toy = backbones.create("toy_cnn", seed=3, verbose=False)
+        atk = type("Ref_" + name, (base,), {"load_model": lambda self, mn: wrap_model(toy.eval())})(model_name="injected", **kw)
+        np.random.seed(7)
+        torch.manual_seed(4321)
+        out["delta_" + name] = atk(x224, label[:1]).detach()
+    save("loops_tail2", **out)
+
+
 def gen_loops_ens():
     """SURVEY.md 8(f) rank 4, continued: AdaEA and SMER by the reference's own classes on three toy members
     (Gaussian / uniform start from the CPU generator; SMER's member order from the numpy generator).  SMER's member
@@ -413,6 +453,6 @@ ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_tail", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_tail", "loops_tail2", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
     for w in which:
         globals()["gen_" + w]()

@@ -103,6 +103,27 @@ def test_bsr_loop(golden, monkeypatch):
     W.test_bsr_attack(golden)
 
 
+@pytest.mark.parametrize("name,kw", [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
+                                     ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
+                                     ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)),
+                                     ("usmm", dict(num_scale=3, num_mix=2)), ("anda", dict(n_ens=4, epoch=3))])
+def test_more_attacks_through_kernels(golden, monkeypatch, name, kw):
+    """the not-yet-measured GPU test of these attacks, run through the kernels' own code on the host"""
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.0005)               # the kernels' fixed-order sum|g| vs ATen's: a few signs near zero
+    W.test_more_attacks_gpu_vs_reference(golden, name, kw)
+
+
+@pytest.mark.parametrize("name,kw", [("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))])
+def test_ssm_tricks_through_kernels(golden, monkeypatch, name, kw):
+    """... and of SSM_H / SSM_P: every view through the MFMA kernel's code (forward and backward) on the host"""
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.002)
+    W.test_ssm_tricks_gpu_vs_reference(golden, name, kw)
+
+
 def test_main_cli_roundtrip(tmp_path, monkeypatch):
     """main.py end to end (decode -> attack -> quantise -> PNG -> --eval) with the kernels' own code on the host"""
     A.test_main_cli_roundtrip(tmp_path, monkeypatch)

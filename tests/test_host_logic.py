@@ -213,6 +213,34 @@ def test_long_tail_attacks_match_reference(golden, monkeypatch, name, kw):
         assert fake_hip.calls.count("dim_fwd") == 50          # five views per iteration, always applied
 
 
+TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
+         ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
+         ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
+         ("anda", dict(n_ens=4, epoch=3))]
+
+
+@pytest.mark.parametrize("name,kw", TAIL2)
+def test_more_attacks_match_reference(golden, monkeypatch, name, kw):
+    """I-FGS2M, VA-I-FGSM, AdaMSI-FGM, the three MI-FGSM tricks, MaskBlock, US-MM, ANDA: the product's loops reproduce the
+    REAL reference's perturbations bit for bit on the host-logic tier -- draw order (random starts, auxiliary labels,
+    mix permutations), the single-quantile form of the staircase sign, US-MM's ascending copy sum"""
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    x, label = t(base["x_u8"]).float() / 255, t(base["label"])
+    first = 1 if name == "anda" else len(x)
+    atk = make(name, **kw)
+    if name == "vaifgsm":
+        atk.num_classes = 10
+    torch.manual_seed(1234)
+    delta = atk(x[:first], label[:first])
+    assert not delta.requires_grad
+    assert np.array_equal(delta.numpy(), g["delta_" + name])
+    if name in ("maskblock", "usmm"):
+        assert "mi_update" in fake_hip.calls
+    if name == "usmm":
+        assert fake_hip.calls.count("sum_members") == 10          # six copies: one call per iteration
+
+
 @pytest.mark.parametrize("name", ["svre", "cwa"])
 def test_per_member_ensemble_attacks_match_reference(golden, monkeypatch, name):
     """SVRE / CWA index EnsembleModel.models[k]; random start and member choice follow the
@@ -363,6 +391,23 @@ def test_ssm_matches_reference(golden, monkeypatch):
     torch.manual_seed(4321)
     assert np.array_equal(atk(x224, t(base["label"])[:1]).numpy(), g["delta_ssm"])
     assert "grad_accumulate" in fake_hip.calls
+
+
+@pytest.mark.parametrize("name,kw", [("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))])
+def test_ssm_tricks_match_reference(golden, monkeypatch, name, kw):
+    """SSM_H / SSM_P (ssm_with_tricks.py:17-470): every spectrum edit of the reference (masked high frequencies; scale /
+    uniform mask / channel drop-out on three blocks) folded into ONE multiplier of the spectrum -- same perturbation bit
+    for bit, draw by draw (host Gaussian, numpy operation choice, per-block draws in the reference's block order)"""
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    x224 = u8_images(1, 224, 23).float() / 255
+    atk = make(name, **kw)
+    atk.noise_source = lambda shape, lo, hi: torch.randn(shape) if lo is None else torch.rand(shape)
+    np.random.seed(7)
+    torch.manual_seed(4321)
+    assert np.array_equal(atk(x224, t(base["label"])[:1]).numpy(), g["delta_" + name])
+    assert "mi_update" in fake_hip.calls
 
 
 def test_dct_matrices_are_the_reference_transform():

@@ -32,6 +32,13 @@ attack_zoo = {
     'aifgtm': ('.gradient.aifgtm', 'AIFGTM'),
     'mef': ('.gradient.mef', 'MEF'),
     'gaa': ('.gradient.gaa', 'GAA'),
+    'ifgssm': ('.gradient.ifgssm', 'IFGSSM'),
+    'vaifgsm': ('.gradient.vaifgsm', 'VAIFGSM'),
+    'adamsi_fgm': ('.gradient.adamsi_fgm', 'AdaMSI_FGM'),
+    'rgmifgsm': ('.gradient.mifgsm_with_tricks', 'RGMIFGSM'),
+    'dual_mifgsm': ('.gradient.mifgsm_with_tricks', 'DualMIFGSM'),
+    'ens_mifgsm': ('.gradient.mifgsm_with_tricks', 'Ens_FGSM_MIFGSM'),
+    'anda': ('.gradient.anda', 'ANDA'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
@@ -41,6 +48,10 @@ attack_zoo = {
     'bsr': ('.input_transformation.bsr', 'BSR'),
     'dem': ('.input_transformation.dem', 'DEM'),
     'ssm': ('.input_transformation.ssm', 'SSM'),
+    'ssm_h': ('.input_transformation.ssm_with_tricks', 'SSM_H'),
+    'ssm_p': ('.input_transformation.ssm_with_tricks', 'SSM_P'),
+    'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
+    'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
     # ensemble
     'ens': ('.ensemble.ens', 'ENS'),
