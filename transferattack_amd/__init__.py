@@ -39,6 +39,7 @@ attack_zoo = {
     'dual_mifgsm': ('.gradient.mifgsm_with_tricks', 'DualMIFGSM'),
     'ens_mifgsm': ('.gradient.mifgsm_with_tricks', 'Ens_FGSM_MIFGSM'),
     'anda': ('.gradient.anda', 'ANDA'),
+    'rap': ('.gradient.rap', 'RAP'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
@@ -50,6 +51,7 @@ attack_zoo = {
     'ssm': ('.input_transformation.ssm', 'SSM'),
     'ssm_h': ('.input_transformation.ssm_with_tricks', 'SSM_H'),
     'ssm_p': ('.input_transformation.ssm_with_tricks', 'SSM_P'),
+    'decowa': ('.input_transformation.decowa', 'DeCowA'),
     'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
     'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
