@@ -112,7 +112,7 @@ def test_more_attacks_through_kernels(golden, monkeypatch, name, kw):
     """the not-yet-measured GPU test of these attacks, run through the kernels' own code on the host"""
     import test_zz_hip_widened as W
     monkeypatch.setattr(W, "DEV", "cpu")
-    monkeypatch.setattr(W, "BOUND", 0.0005)               # the kernels' fixed-order sum|g| vs ATen's: a few signs near zero
+    monkeypatch.setattr(W, "BOUND", 0.0025)               # half the GPU bounds: only the kernels' fixed-order sum|g| differs
     W.test_more_attacks_gpu_vs_reference(golden, name, kw)
 
 

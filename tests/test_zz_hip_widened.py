@@ -1,10 +1,8 @@
 """GPU (-m gpu), collected last: the widened rows of SURVEY.md 8(f) -- AdaEA / SMER / FGSRA / SIA / BSR / SSM against the
 reference's golden loops, the SIA / BSR / spectrum kernels against the reference's stacks and the oracle, the
-BASELINE-size property tests (all green on MI355X in r2e / r2g, profiles/r02/pytest_gpu_r2g.log) -- and, at the very end,
-whatever was written after the GPU minutes of its round were spent and has therefore NOT run on MI355X yet (marked
-there).  For those the evidence is the CPU tiers: tests/test_host_logic.py (bit for bit against the reference's golden
-loops on the host-logic tier).  The file sorts last, and the unmeasured tests last within it, so that a surprise there
-cannot mask anything else."""
+BASELINE-size property tests, and the long tail of gradient/ and input_transformation/ attacks (all green on MI355X:
+profiles/r02/pytest_gpu_r2g.log, pytest_gpu_new_attacks_r2i.log).  Whatever is written after the GPU minutes of a round
+are spent goes to the END of this file and says so: the file sorts last, so a surprise there cannot mask anything else."""
 import numpy as np
 import pytest
 import torch
@@ -492,7 +490,7 @@ def test_spectrum_kernel(shape):
     assert float((out.cpu().double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
 
 
-# ------------------------------------------------------------------ written after round 2's GPU minutes were spent
+# ------------------------------------------------------------------ added late in round 2 (ran on MI355X in session r2i)
 TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
          ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
          ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
@@ -502,9 +500,12 @@ TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
 
 @pytest.mark.parametrize("name,kw", TAIL2)
 def test_more_attacks_gpu_vs_reference(golden, name, kw):
-    """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA end to end on the GPU against the
-    reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  NOT YET RUN ON MI355X: the
-    bound is the widened tier's 0.5 % doubled, to be tightened to the measured value next round."""
+    """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA / RAP / DeCoWA end to end on the GPU
+    against the reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  Measured on MI355X
+    (profiles/r02/pytest_gpu_new_attacks_r2i.log): 0.000 % for eight of them, dual MI-FGSM 0.008 %, AdaMSI-FGM 0.024 %,
+    I-FGS2M 0.91 %.  The staircase sign steps by the RANK of |g| inside its plane, so unlike sign() it reacts to fp32
+    rounding of the surrogate's gradient everywhere, not only near zero: on the CPU, noise of 1e-6 max|g| on the
+    reference's own gradients moves 2.2 % of its uint8 output (1e-7: 0.03 %; MI-FGSM: 0 % at 1e-5) -- hence its own bound."""
     g, base = golden("loops_tail2"), golden("loops_toy")
     x, label = t(base["x_u8"]).float() / 255, t(base["label"])
     first = 1 if name == "anda" else len(x)
@@ -521,14 +522,14 @@ def test_more_attacks_gpu_vs_reference(golden, name, kw):
     assert not delta.requires_grad and float(delta.abs().max()) <= EPS + 1e-6
     rate = mismatch(x, delta, g["delta_" + name])
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * rate))
-    assert rate <= 2 * BOUND
+    assert rate <= {"ifgssm": 0.03, "adamsi_fgm": 0.002}.get(name, 0.001) * (BOUND / 0.005)
 
 
 @pytest.mark.parametrize("name,kw", [("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))])
 def test_ssm_tricks_gpu_vs_reference(golden, name, kw):
     """SSM_H / SSM_P on the GPU (one ta_dct_pair view per spectrum edit, forward and backward) against the reference's
-    golden loops.  NOT YET RUN ON MI355X; bound as test_ssm_attack's (the MFMA form differs from the FFT form by fp32
-    rounding, so a few momentum signs near zero may differ)."""
+    golden loops; measured on MI355X: 0.0007 % / 0.067 % (profiles/r02/pytest_gpu_new_attacks_r2i.log).  The MFMA form
+    differs from the FFT form by fp32 rounding, so a few momentum signs near zero may differ."""
     from conftest import u8_images
     g, base = golden("loops_tail2"), golden("loops_toy")
     x224 = u8_images(1, 224, 23).float() / 255
@@ -543,4 +544,4 @@ def test_ssm_tricks_gpu_vs_reference(golden, name, kw):
     assert float(delta.abs().max()) <= EPS + 1e-6
     rate = mismatch(x224, delta, g["delta_" + name])
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * rate))
-    assert rate <= 2 * BOUND
+    assert rate <= BOUND
