@@ -1,0 +1,71 @@
+"""CPU, build container only: the REAL reference, imported live from /root/reference through oracle/ref_shim.py, against
+(a) the committed golden vectors -- so the fixtures under tests/golden/ are shown to be what the reference computes today,
+not only what it computed when they were written -- and (b) the oracle restatement and the product's host-logic tier on
+FRESH inputs (seeds no fixture uses), so the pin does not rest on the stored vectors alone.
+
+Skipped where /root/reference is absent (the GPU box): nothing under `-m gpu`, smoke() or bench.py reads the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import fake_hip
+import fgsm_oracle as O
+import transferattack_amd as ta
+from conftest import u8_images
+from transferattack_amd import backbones
+from transferattack_amd.utils import wrap_model
+
+REFERENCE = "/root/reference/transferattack"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree is only present in the build container")
+
+
+@pytest.fixture(scope="module")
+def ref_shim():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_shim as shim
+    shim.neutralise_cuda_calls()
+    return shim
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def toy():
+    return backbones.create("toy_cnn", seed=3, verbose=False)
+
+
+@pytest.mark.parametrize("name", ["mifgsm", "nifgsm", "vmifgsm", "dim", "tim", "sim", "admix"])
+def test_goldens_are_what_the_reference_computes(golden, ref_shim, name):
+    """re-run the reference's own class with the generator's seeds: the stored loop is reproduced bit for bit"""
+    g = golden("loops_toy")
+    x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    atk = ref_shim.make_reference_attack(name, toy())
+    torch.manual_seed(1234)
+    assert np.array_equal(atk(x, label).numpy(), g["delta_" + name])
+
+
+@pytest.mark.parametrize("name,kw", [("mifgsm", {}), ("dim", {}), ("tim", {}), ("admix", {}), ("vmifgsm", dict(num_neighbor=3)),
+                                     ("ifgssm", {}), ("rap", dict(epoch=5, transpoint=2, adv_steps=2)),
+                                     ("usmm", dict(num_scale=2, num_mix=2))])
+def test_fresh_inputs_reference_vs_oracle_and_product(ref_shim, monkeypatch, name, kw):
+    """inputs no fixture holds: reference (live) == oracle restatement (where it has a recipe) == product on the
+    host-logic tier, bit for bit"""
+    n, size = 3, 32
+    x = u8_images(n, size, 555).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(556))
+    torch.manual_seed(4242)
+    want = ref_shim.make_reference_attack(name, toy(), **kw)(x, label).detach().numpy()
+    if name in O.RECIPES:
+        torch.manual_seed(4242)
+        assert np.array_equal(O.run_attack(name, toy(), x, label, **kw).numpy(), want)
+    fake_hip.install(monkeypatch)
+    base = ta.load_attack_class(name)
+    cls = type("Cpu" + base.__name__, (base,), {"load_model": lambda self, mn: wrap_model(toy().eval())})
+    atk = cls(model_name="injected", **kw)
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    torch.manual_seed(4242)
+    assert np.array_equal(atk(x, label).numpy(), want)
