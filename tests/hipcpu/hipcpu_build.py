@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "transferattack_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 
 # name and element type of each file's dynamic-LDS array (a block-scope `extern` needs a namespace-scope definition)
-_DYNAMIC_LDS = {"dim.hip": [("char", "smem_raw")], "tim.hip": [("float", "smem")]}
+_DYNAMIC_LDS = {"dim.hip": [("char", "smem_raw")], "tim.hip": [("float", "smem")], "bsr.hip": [("int", "plans")]}
 
 
 def _host_text(text):
@@ -50,10 +50,17 @@ def build():
         generated = []
         for src in sources:
             name = os.path.basename(src)
-            text = _host_text(open(src).read())
+            text = open(src).read()
+            # the dynamic-LDS array becomes a namespace-scope array defined BEFORE the kernels, and the kernels' block-scope
+            # `extern __shared__` declarations of it are dropped: g++ reaches a block-scope `extern thread_local` through
+            # its TLS init function -- a weak symbol that does not exist for a plain array -- and inside loops it omits
+            # the null check (a call through address 0)
             for ctype, var in _DYNAMIC_LDS.get(name, []):
-                text += "\nnamespace ta { %s __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (
-                    "" if SANITIZE else "thread_local", ctype, var, ctype)
+                text, found = re.subn(r"^[ \t]*extern __shared__[^;\n]*\b%s\[\];[^\n]*$" % var, "", text, flags=re.M)
+                assert found, (name, var)
+                text = "namespace ta { %s __attribute__((aligned(16))) %s %s[163840 / sizeof(%s)]; }\n" % (
+                    "" if SANITIZE else "thread_local", ctype, var, ctype) + text
+            text = _host_text(text)
             generated.append(os.path.join(OUT, os.path.splitext(name)[0] + "_host.cpp"))
             with open(generated[-1], "w") as fh:
                 fh.write(text)

@@ -148,6 +148,11 @@ def test_sia_kernels_random(widened_on_host, shape, nb, copies):
     W.test_sia_kernels_random(shape, nb, copies)
 
 
+@pytest.mark.parametrize("shape", [(4096, 3, 4, 8), (2050, 3, 4, 8), (1538, 3, 4, 8), (769, 3, 4, 8), (1025, 2, 4, 8)])
+def test_bsr_plane_groups(widened_on_host, shape):
+    W.test_bsr_plane_groups(shape)
+
+
 def test_bsr_kernels_golden(golden, widened_on_host, monkeypatch):
     W.test_bsr_kernels_golden(golden, monkeypatch)
 

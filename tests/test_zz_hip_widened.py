@@ -242,6 +242,43 @@ def test_bsr_kernels_random(shape, nb, copies, monkeypatch):
     assert diff > 0 or any(exact), "forward bit-exact on this host, yet the backward matches neither ATen visiting order"
 
 
+@pytest.mark.parametrize("shape", [(4096, 3, 4, 8), (2050, 3, 4, 8), (1538, 3, 4, 8), (769, 3, 4, 8), (1025, 2, 4, 8)])
+def test_bsr_plane_groups(shape):
+    """both kernels share a copy's geometry between the planes one thread owns (12 / 6 / 3 / 2 planes per thread when the
+    plane count divides and the launch stays wide enough -- these shapes select each of those, forward and backward; small
+    batches run one plane per thread): same bits as the one-plane form, obtained here by sending the batch 16 images at
+    a time"""
+    import random
+    from transferattack_amd import _hip
+    from transferattack_amd.transforms import bsr_draw
+    nb, copies = 2, 2
+    n = shape[0]
+    gen = torch.Generator().manual_seed(shape[0] + shape[1])
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    plan = _dev(bsr_draw(shape, nb, copies))
+    x = torch.rand(shape, generator=gen).to(DEV)
+    gy = torch.randn((copies * n,) + shape[1:], generator=gen).to(DEV)
+    y = torch.empty((copies * n,) + shape[1:], device=DEV)
+    _hip.bsr_fwd(x, plan, y, copies, nb)
+    gx = torch.empty(shape, device=DEV)
+    _hip.bsr_bwd(gy, plan, gx, copies, nb)
+    sums = _hip._partials[2][:n * _hip._partials[3]].view(n, -1).double().sum(1).cpu()
+    np.testing.assert_allclose(sums.numpy(), gx.double().abs().flatten(1).sum(1).cpu().numpy(), rtol=2e-6)
+    gx_chunks, y_chunks = torch.empty(shape, device=DEV), torch.empty_like(y)
+    for lo in range(0, n, 16):
+        hi = min(lo + 16, n)
+        part = torch.cat([gy[k * n + lo:k * n + hi] for k in range(copies)]).contiguous()
+        out = torch.empty((hi - lo,) + shape[1:], device=DEV)
+        _hip.bsr_bwd(part, plan, out, copies, nb)
+        gx_chunks[lo:hi] = out
+        stack = torch.empty((copies * (hi - lo),) + shape[1:], device=DEV)
+        _hip.bsr_fwd(x[lo:hi].contiguous(), plan, stack, copies, nb)
+        for k in range(copies):
+            y_chunks[k * n + lo:k * n + hi] = stack[k * (hi - lo):(k + 1) * (hi - lo)]
+    assert torch.equal(y, y_chunks)
+    assert torch.equal(gx, gx_chunks)
+
+
 def test_bsr_attack(golden):
     """the whole BSR loop on the device against the reference's golden loop (5 copies, toy surrogate)"""
     import random

@@ -29,8 +29,11 @@
 namespace ta {
 
 constexpr int kBsrMaxBlocks = 8;
-constexpr int kBsrRows = 8;                    // rows of a plane per workgroup (2 per wave)
-constexpr int kBsrMaxPlanInts = 8192;          // all copies' plans staged in LDS by the backward
+constexpr int kBsrRows = 8;                    // rows of a plane per forward workgroup (2 per wave)
+constexpr int kBsrBwdRows = 2;                 // rows of a plane per backward workgroup (= rows per |gx| tile sum): the
+                                               // backward is long per pixel, small tiles keep >= 3 workgroups per CU
+                                               // at the planes-per-thread counts that pay (measured: r2k)
+constexpr int kBsrMaxPlanInts = 8192;          // all copies' plans staged in LDS by the backward (32 KB at most)
 
 __host__ __device__ inline int bsr_plan_stride(int nb) { return 1 + 7 * nb + 3 * nb * nb; }
 
@@ -58,21 +61,26 @@ __device__ __forceinline__ BsrSample bsr_sample(const int* __restrict__ strip, i
 }
 
 // ---------------------------------------------------------------------------------------------- forward
+// Where an output pixel of a copy samples from (strip, block, rotated sampling point, weights) is the same for every
+// image and channel: a thread owns one output pixel of P planes, finds the four taps once and reads / blends / writes
+// the P planes through them.
+template <int P>
 __global__ __launch_bounds__(kBlock) void bsr_fwd_kernel(const float* __restrict__ x, const int* __restrict__ plan,
                                                          float* __restrict__ y, int planes, int H, int W, int nb,
                                                          int row_tiles) {
     __shared__ int cp[1 + 7 * kBsrMaxBlocks + 3 * kBsrMaxBlocks * kBsrMaxBlocks];
     const int stride = bsr_plan_stride(nb);
+    const int groups = planes / P;
     const int tile = blockIdx.x % row_tiles;
-    const int plane = (blockIdx.x / row_tiles) % planes;
-    const int copy = blockIdx.x / (row_tiles * planes);
+    const int plane0 = ((blockIdx.x / row_tiles) % groups) * P;
+    const int copy = blockIdx.x / (row_tiles * groups);
     for (int i = threadIdx.x; i < stride; i += kBlock) cp[i] = plan[copy * stride + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d0 = cp[0];
     const int64_t plane_elems = static_cast<int64_t>(H) * W;
-    const float* xp = x + static_cast<int64_t>(plane) * plane_elems;
-    float* yp = y + (static_cast<int64_t>(copy) * planes + plane) * plane_elems;
+    const float* xp = x + static_cast<int64_t>(plane0) * plane_elems;
+    float* yp = y + (static_cast<int64_t>(copy) * planes + plane0) * plane_elems;
     for (int Y = tile * kBsrRows + wave; Y < min((tile + 1) * kBsrRows, H); Y += kBlock / 64) {
         for (int X = lane; X < W; X += 64) {
             const int u = d0 == 0 ? Y : X, v = d0 == 0 ? X : Y;
@@ -88,32 +96,68 @@ __global__ __launch_bounds__(kBlock) void bsr_fwd_kernel(const float* __restrict
             const int py = d0 == 0 ? pu : pv, px = d0 == 0 ? pv : pu;
             const BsrSample s = bsr_sample(strip, py, px, h, w);
             const int oy = d0 == 0 ? s0 : 0, ox = d0 == 0 ? 0 : s0;         // strip origin inside the plane
-            auto tap = [&](int cy, int cx) {
-                return (cy >= 0 && cy < h && cx >= 0 && cx < w) ? xp[static_cast<int64_t>(oy + cy) * W + ox + cx] : 0.0f;
-            };
-            const float v_nw = tap(s.y0, s.x0), v_ne = tap(s.y0, s.x0 + 1), v_sw = tap(s.y0 + 1, s.x0), v_se = tap(s.y0 + 1, s.x0 + 1);
-            yp[static_cast<int64_t>(Y) * W + X] = fmaf(v_se, s.se, fmaf(v_sw, s.sw, fmaf(v_ne, s.ne, v_nw * s.nw)));
+            // the four taps: inside the strip? byte offset in the plane (0 when outside: read, then replaced by 0)
+            bool in[4];
+            unsigned boff[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cy = s.y0 + (c >> 1), cx = s.x0 + (c & 1);
+                in[c] = cy >= 0 && cy < h && cx >= 0 && cx < w;
+                boff[c] = in[c] ? static_cast<unsigned>((oy + cy) * W + ox + cx) * 4u : 0u;
+            }
+            const unsigned out = static_cast<unsigned>(Y * W + X);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const char* base = reinterpret_cast<const char*>(xp + p * plane_elems);
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float val = *reinterpret_cast<const float*>(base + boff[c]);
+                    t[c] = in[c] ? val : 0.0f;
+                }
+                yp[p * plane_elems + out] = fmaf(t[3], s.se, fmaf(t[2], s.sw, fmaf(t[1], s.ne, t[0] * s.nw)));
+            }
         }
     }
 }
 
 // --------------------------------------------------------------------------------------------- backward
+// The geometry of a copy -- which rotated pixels reach a source pixel, with which weight, and where they went in the
+// output -- is the same for every image and channel.  A thread owns one source pixel of P planes: per copy it finds the
+// (at most 9) contributions ONCE and then runs the P planes over them (one load + one product + one add each), so the
+// search, which is all the arithmetic of this kernel, is paid once per P planes.  Per plane the products are added in
+// the same order as before (raster order of the rotated pixels / ATen's visiting order, copies descending).
+struct BsrHit {
+    int off;          // Y * W + X of the rotated pixel in its output plane
+    int key;          // ATen's visiting order (reference-order mode)
+    float wgt;
+    bool valid;
+};
+
+template <int P, bool ORDERED>
 __global__ __launch_bounds__(kBlock) void bsr_bwd_kernel(const float* __restrict__ gy, const int* __restrict__ plan,
                                                          float* __restrict__ gx, float* __restrict__ ws, int planes, int H,
                                                          int W, int copies, int nb, int row_tiles, int lanes) {
-    __shared__ int plans[kBsrMaxPlanInts];
+    extern __shared__ __attribute__((aligned(16))) int plans[];      // copies * stride ints
     __shared__ float red[kBlock / kWave];
     const int stride = bsr_plan_stride(nb);
     for (int i = threadIdx.x; i < copies * stride; i += kBlock) plans[i] = plan[i];
     __syncthreads();
     const int tile = blockIdx.x % row_tiles;
-    const int plane = blockIdx.x / row_tiles;
+    const int plane0 = (blockIdx.x / row_tiles) * P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t plane_elems = static_cast<int64_t>(H) * W;
-    float asum = 0.0f;
-    for (int sy = tile * kBsrRows + wave; sy < min((tile + 1) * kBsrRows, H); sy += kBlock / 64) {
-        for (int sx = lane; sx < W; sx += 64) {
-            float acc = 0.0f;
+    float asum[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) asum[p] = 0.0f;
+    const int chunks_x = (W + 63) / 64;                  // the tile in 64-pixel row segments, dealt to the waves in turn
+    for (int chunk = wave; chunk < kBsrBwdRows * chunks_x; chunk += kBlock / 64) {
+        {
+            const int sy = tile * kBsrBwdRows + chunk / chunks_x, sx = (chunk % chunks_x) * 64 + lane;
+            if (sy >= H || sx >= W) continue;
+            float acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
             for (int copy = copies - 1; copy >= 0; --copy) {
                 const int* cp = plans + copy * stride;
                 const int d0 = cp[0];
@@ -131,52 +175,88 @@ __global__ __launch_bounds__(kBlock) void bsr_bwd_kernel(const float* __restrict
                 const float cxb = static_cast<float>(cx) - 0.5f * w + 0.5f, cyb = static_cast<float>(cy) - 0.5f * h + 0.5f;
                 const int pxc = static_cast<int>(rintf(m0 * cxb + m3 * cyb + 0.5f * w - 0.5f));
                 const int pyc = static_cast<int>(rintf(m1 * cxb + m4 * cyb + 0.5f * h - 0.5f));
-                const float* gyp = gy + (static_cast<int64_t>(copy) * planes + plane) * plane_elems;
-                float ck = 0.0f;
-                float term[9];                                   // reference-order mode: the products, then sorted adds
-                int key[9], hits = 0;
-                for (int py = pyc - 1; py <= pyc + 1; ++py) {
-                    for (int px = pxc - 1; px <= pxc + 1; ++px) {
-                        if (py < 0 || py >= h || px < 0 || px >= w) continue;
-                        const BsrSample s = bsr_sample(strip, py, px, h, w);
-                        const int dy = cy - s.y0, dx = cx - s.x0;
-                        if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
-                        const float wgt = dy == 0 ? (dx == 0 ? s.nw : s.ne) : (dx == 0 ? s.sw : s.se);
-                        // where rotated pixel (py, px) of this strip went in the output
-                        const int pu = d0 == 0 ? py : px, pv = d0 == 0 ? px : py;
-                        int j = 0;
-                        for (int k = 1; k < nb; ++k) j = (pv >= blocks[3 * k] && pv < blocks[3 * k] + blocks[3 * k + 1]) ? k : j;
-                        const int ou = strip[2] + pu, ov = blocks[3 * j + 2] + (pv - blocks[3 * j]);
-                        const int Y = d0 == 0 ? ou : ov, X = d0 == 0 ? ov : ou;
-                        const float prod = wgt * gyp[static_cast<int64_t>(Y) * W + X];
-                        if (lanes == 0) {
-                            ck += prod;                          // raster order of the rotated pixels
-                        } else {
-                            const int flat = py * w + px, corner = 2 * dy + dx;
-                            term[hits] = prod;
-                            key[hits++] = ((flat / lanes) * 4 + corner) * lanes + flat % lanes;
+                BsrHit hit[9];
+#pragma unroll
+                for (int slot = 0; slot < 9; ++slot) {           // raster order of the candidates
+                    const int py = pyc + slot / 3 - 1, px = pxc + slot % 3 - 1;
+                    hit[slot].valid = false;
+                    hit[slot].off = 0;
+                    hit[slot].key = 0;
+                    hit[slot].wgt = 0.0f;
+                    if (py < 0 || py >= h || px < 0 || px >= w) continue;
+                    const BsrSample smp = bsr_sample(strip, py, px, h, w);
+                    const int dy = cy - smp.y0, dx = cx - smp.x0;
+                    if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
+                    // where rotated pixel (py, px) of this strip went in the output
+                    const int pu = d0 == 0 ? py : px, pv = d0 == 0 ? px : py;
+                    int j = 0;
+                    for (int k = 1; k < nb; ++k) j = (pv >= blocks[3 * k] && pv < blocks[3 * k] + blocks[3 * k + 1]) ? k : j;
+                    const int ou = strip[2] + pu, ov = blocks[3 * j + 2] + (pv - blocks[3 * j]);
+                    const int flat = py * w + px, corner = 2 * dy + dx;
+                    hit[slot].valid = true;
+                    hit[slot].off = (d0 == 0 ? ou : ov) * W + (d0 == 0 ? ov : ou);
+                    hit[slot].wgt = dy == 0 ? (dx == 0 ? smp.nw : smp.ne) : (dx == 0 ? smp.sw : smp.se);
+                    hit[slot].key = ORDERED ? ((flat / lanes) * 4 + corner) * lanes + flat % lanes : 0;
+                }
+                const float* gyc = gy + (static_cast<int64_t>(copy) * planes + plane0) * plane_elems;
+                if constexpr (ORDERED) {
+                    // verification mode: compact, then insertion sort of <= 9 entries by ATen's visiting order
+                    int off[9], key[9], hits = 0;
+                    float wgt[9];
+                    for (int slot = 0; slot < 9; ++slot)
+                        if (hit[slot].valid) {
+                            off[hits] = hit[slot].off;
+                            key[hits] = hit[slot].key;
+                            wgt[hits++] = hit[slot].wgt;
+                        }
+                    for (int a = 1; a < hits; ++a) {
+                        const int ka = key[a], oa = off[a];
+                        const float wa = wgt[a];
+                        int b = a - 1;
+                        while (b >= 0 && key[b] > ka) { key[b + 1] = key[b]; off[b + 1] = off[b]; wgt[b + 1] = wgt[b]; --b; }
+                        key[b + 1] = ka;
+                        off[b + 1] = oa;
+                        wgt[b + 1] = wa;
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        float ck = 0.0f;
+                        for (int a = 0; a < hits; ++a) ck += wgt[a] * gyc[p * plane_elems + off[a]];
+                        acc[p] = copy == copies - 1 ? ck : acc[p] + ck;
+                    }
+                } else {
+                    // slot by slot over the planes: uniform plane base + one 32-bit byte offset per slot (scalar-base
+                    // addressing), a candidate that does not reach this pixel adds an exact zero (ck is never -0, so
+                    // the sum is unchanged; the select keeps a non-finite gy of a foreign pixel out)
+                    float ck[P];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) ck[p] = 0.0f;
+#pragma unroll
+                    for (int slot = 0; slot < 9; ++slot) {
+                        const unsigned boff = static_cast<unsigned>(hit[slot].off) * 4u;
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const char* base = reinterpret_cast<const char*>(gyc + p * plane_elems);
+                            const float g = *reinterpret_cast<const float*>(base + boff);
+                            ck[p] += hit[slot].wgt * (hit[slot].valid ? g : 0.0f);
                         }
                     }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = copy == copies - 1 ? ck[p] : acc[p] + ck[p];
                 }
-                if (lanes != 0) {
-                    for (int a = 1; a < hits; ++a) {             // insertion sort of <= 9 entries by ATen's visiting order
-                        const int ka = key[a];
-                        const float ta_ = term[a];
-                        int b = a - 1;
-                        while (b >= 0 && key[b] > ka) { key[b + 1] = key[b]; term[b + 1] = term[b]; --b; }
-                        key[b + 1] = ka;
-                        term[b + 1] = ta_;
-                    }
-                    for (int a = 0; a < hits; ++a) ck += term[a];
-                }
-                acc = copy == copies - 1 ? ck : acc + ck;
             }
-            gx[static_cast<int64_t>(plane) * plane_elems + static_cast<int64_t>(sy) * W + sx] = acc;
-            asum += fabsf(acc);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                gx[static_cast<int64_t>(plane0 + p) * plane_elems + static_cast<int64_t>(sy) * W + sx] = acc[p];
+                asum[p] += fabsf(acc[p]);
+            }
         }
     }
-    const float total = block_sum(asum, red);
-    if (ws != nullptr && threadIdx.x == 0) ws[blockIdx.x] = total;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float total = block_sum(asum[p], red);
+        if (ws != nullptr && threadIdx.x == 0) ws[static_cast<int64_t>(plane0 + p) * row_tiles + tile] = total;
+    }
 }
 
 }  // namespace ta
@@ -187,32 +267,60 @@ static int check_bsr(const void* a, const void* b, const void* plan, int64_t pla
     TA_REQUIRE(a && b && plan && a != b, "null or aliased pointers");
     TA_REQUIRE(planes > 0 && h > 0 && w > 0 && copies > 0, "bad shape");
     TA_REQUIRE(nb >= 1 && nb <= kBsrMaxBlocks, "num_block %d outside 1..%d", nb, kBsrMaxBlocks);
-    TA_REQUIRE(planes * ceil_div(h, kBsrRows) * copies < (1ll << 31), "too many tiles");
+    TA_REQUIRE(planes * ceil_div(h, kBsrBwdRows) * copies < (1ll << 31), "too many tiles");
     return 0;
 }
 
-extern "C" int64_t ta_bsr_tiles(int h) { return h > 0 ? ceil_div(h, kBsrRows) : 0; }
+extern "C" int64_t ta_bsr_tiles(int h) { return h > 0 ? ceil_div(h, kBsrBwdRows) : 0; }
+
+// planes per thread: as many as divide the plane count while the launch still has >= `floor` workgroups
+static int bsr_planes_per_thread(int64_t planes, int64_t tiles, int64_t floor, int most) {
+    for (int p : {12, 6, 3, 2})
+        if (p <= most && planes % p == 0 && planes / p * tiles >= floor) return p;
+    return 1;
+}
 
 extern "C" int ta_bsr_fwd(const float* x, const int32_t* plan, float* y, int64_t planes, int h, int w, int copies, int nb,
                           void* stream) {
     if (int rc = check_bsr(x, y, plan, planes, h, w, copies, nb)) return rc;
+    TA_REQUIRE(static_cast<int64_t>(h) * w < (1ll << 29), "plane too large");
     const int row_tiles = static_cast<int>(ceil_div(h, kBsrRows));
-    hipLaunchKernelGGL(bsr_fwd_kernel, dim3(static_cast<unsigned>(copies * planes * row_tiles)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), x, plan, y, static_cast<int>(planes), h, w, nb, row_tiles);
+    const int pp = bsr_planes_per_thread(planes, static_cast<int64_t>(row_tiles) * copies, 2048, 12);
+    const dim3 grid(static_cast<unsigned>(copies * (planes / pp) * row_tiles));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define TA_BSR_FWD(P) \
+    hipLaunchKernelGGL((bsr_fwd_kernel<P>), grid, dim3(kBlock), 0, st, x, plan, y, static_cast<int>(planes), h, w, nb, row_tiles)
+    if (pp == 12) TA_BSR_FWD(12);
+    else if (pp == 6) TA_BSR_FWD(6);
+    else if (pp == 3) TA_BSR_FWD(3);
+    else if (pp == 2) TA_BSR_FWD(2);
+    else TA_BSR_FWD(1);
+#undef TA_BSR_FWD
     return check_launch("bsr_fwd");
 }
 
 extern "C" int ta_bsr_bwd(const float* gy, const int32_t* plan, float* gx, float* ws, int64_t planes, int h, int w, int copies,
                           int nb, void* stream) {
     if (int rc = check_bsr(gy, gx, plan, planes, h, w, copies, nb)) return rc;
-    TA_REQUIRE(copies * bsr_plan_stride(nb) <= kBsrMaxPlanInts, "copies * plan stride exceeds the %d ints staged in LDS",
-               kBsrMaxPlanInts);
-    const int row_tiles = static_cast<int>(ceil_div(h, kBsrRows));
+    const int plan_ints = copies * bsr_plan_stride(nb);
+    TA_REQUIRE(plan_ints <= kBsrMaxPlanInts, "copies * plan stride exceeds the %d ints staged in LDS", kBsrMaxPlanInts);
+    TA_REQUIRE(static_cast<int64_t>(h) * w < (1ll << 29), "plane too large");
+    const int row_tiles = static_cast<int>(ceil_div(h, kBsrBwdRows));
     const char* env = getenv("TA_ATEN_SUM_LANES");               // verification mode, read at every call like update.hip's
     const int value = env == nullptr ? 0 : atoi(env);
     const int lanes = (value == 8 || value == 16) ? value : 0;
-    hipLaunchKernelGGL(bsr_bwd_kernel, dim3(static_cast<unsigned>(planes * row_tiles)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), gy, plan, gx, ws, static_cast<int>(planes), h, w, copies, nb,
-                       row_tiles, lanes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = static_cast<size_t>(plan_ints) * sizeof(int);
+    const int pp = lanes ? 1 : bsr_planes_per_thread(planes, row_tiles, 768, 6);     // 12 planes: no faster than 6 (r2k)
+    const dim3 grid(static_cast<unsigned>(planes / pp * row_tiles));
+#define TA_BSR_BWD(P, ORD)                                                                                            \
+    hipLaunchKernelGGL((bsr_bwd_kernel<P, ORD>), grid, dim3(kBlock), lds, st, gy, plan, gx, ws, static_cast<int>(planes), h, w, \
+                       copies, nb, row_tiles, lanes)
+    if (lanes) TA_BSR_BWD(1, true);
+    else if (pp == 6) TA_BSR_BWD(6, false);
+    else if (pp == 3) TA_BSR_BWD(3, false);
+    else if (pp == 2) TA_BSR_BWD(2, false);
+    else TA_BSR_BWD(1, false);
+#undef TA_BSR_BWD
     return check_launch("bsr_bwd");
 }
