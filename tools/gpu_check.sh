@@ -44,6 +44,11 @@ gpus1)
 spec)
   timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -10 | tee $OUT/spectrum_microbench.txt
   timeout 300 python -m pytest tests/test_zz_hip_widened.py tests/test_hip_kernels.py -q -m gpu -k "spectrum or dim or ssm or fgsra" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/spec_pytest.txt ;;
+bsr)
+  timeout 120 python tools/bsr_microbench.py 2> $OUT/bsr_microbench.err | tee $OUT/bsr_microbench.json
+  timeout 200 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -k "bsr" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/bsr_pytest.txt ;;
+dispatch)
+  timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
 rocprof)
