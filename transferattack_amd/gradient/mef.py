@@ -28,36 +28,35 @@ class MEF(Attack):
         raise Exception("Unsupported loss {}".format(loss))
 
     def get_conditional_sampled_points(self, delta, grad_pgia):
+        """the ``num_neighbor`` sampling points: uniform in the gamma-ball around delta, then pushed by kesai along the
+        carried direction (mef.py:69-76); one draw covers all neighbours"""
         noise = self._uniform_like(grad_pgia, self.gamma)
         if noise is None:
             noise = torch.zeros_like(grad_pgia).uniform_(-self.gamma, self.gamma)
-        sample_delta = self.transform(delta + noise)
-        return self.transform(sample_delta + self.kesai * grad_pgia)
+        return self.transform(self.transform(delta + noise) + self.kesai * grad_pgia)
 
     def get_points_gradient(self, data, delta, label, **kwargs):
-        b, c, h, w = data.shape
-        grad_list = torch.zeros([self.num_neighbor, b, c, h, w]).to(self.device)
+        """gradient of the per-image mean loss taken AT each sampling point, scaled by 1 / num_neighbor (mef.py:78-89)"""
+        stack = torch.zeros((self.num_neighbor,) + tuple(data.shape)).to(self.device)
         for i in range(self.num_neighbor):
-            x_min = self.transform(data + delta[i])
-            loss = self.get_loss(self.get_logits(x_min), label)
-            grad_list[i] = self.get_grad(loss.mean(), x_min)
-        return (1 / self.num_neighbor) * grad_list
+            point = self.transform(data + delta[i])
+            stack[i] = self.get_grad(self.get_loss(self.get_logits(point), label).mean(), point)
+        return (1 / self.num_neighbor) * stack
 
     def forward(self, data, label, **kwargs):
         data, label = self._to_device(data, label)
         delta = self.init_delta(data)
         momentum = 0
-        b, c, h, w = data.shape
-        grad_pgia = torch.zeros([self.num_neighbor, b, c, h, w]).to(self.device)
+        carried = torch.zeros((self.num_neighbor,) + tuple(data.shape)).to(self.device)      # the reference's grad_pgia
         fused = self._can_fuse_update()
         for _ in range(self.epoch):
-            sample_delta = self.get_conditional_sampled_points(delta, grad_pgia)
-            gradient = self.get_points_gradient(data, sample_delta, label)
-            grad_pgia = ((gradient / torch.mean(torch.abs(gradient), (2, 3, 4), keepdim=True)).detach()
-                         - self.inner_decay * grad_pgia)
+            gradient = self.get_points_gradient(data, self.get_conditional_sampled_points(delta, carried), label)
+            per_point_mean = torch.mean(torch.abs(gradient), (2, 3, 4), keepdim=True)
+            carried = (gradient / per_point_mean).detach() - self.inner_decay * carried
+            summed = gradient.sum(0)
             if fused:
-                momentum = self._fused_update(gradient.sum(0), momentum, delta, data)
+                momentum = self._fused_update(summed, momentum, delta, data)
             else:
-                momentum = self.get_momentum(gradient.sum(0), momentum)
+                momentum = self.get_momentum(summed, momentum)
                 delta = self.update_delta(delta, data, momentum, self.alpha)
         return delta.detach()
