@@ -247,7 +247,8 @@ TAIL2 = (("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
          ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
          ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
          ("anda", dict(n_ens=4, epoch=3)),
-         ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)))
+         ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)),
+         ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False)))
 
 
 def gen_loops_tail2():

@@ -107,7 +107,8 @@ def test_bsr_loop(golden, monkeypatch):
                                      ("rgmifgsm", dict(num_directions=2, pre_epoch=2, epoch=4)), ("dual_mifgsm", dict(epoch=5)),
                                      ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)),
                                      ("usmm", dict(num_scale=3, num_mix=2)), ("anda", dict(n_ens=4, epoch=3)),
-                                     ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3))])
+                                     ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)),
+                                     ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False))])
 def test_more_attacks_through_kernels(golden, monkeypatch, name, kw):
     """the not-yet-measured GPU test of these attacks, run through the kernels' own code on the host"""
     import test_zz_hip_widened as W

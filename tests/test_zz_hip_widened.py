@@ -533,9 +533,10 @@ TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
          ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
          ("anda", dict(n_ens=4, epoch=3)),
          ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3))]
+FOOLMIX = ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False))
 
 
-@pytest.mark.parametrize("name,kw", TAIL2)
+@pytest.mark.parametrize("name,kw", TAIL2 + [FOOLMIX])
 def test_more_attacks_gpu_vs_reference(golden, name, kw):
     """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA / RAP / DeCoWA end to end on the GPU
     against the reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  Measured on MI355X

@@ -40,6 +40,7 @@ attack_zoo = {
     'ens_mifgsm': ('.gradient.mifgsm_with_tricks', 'Ens_FGSM_MIFGSM'),
     'anda': ('.gradient.anda', 'ANDA'),
     'rap': ('.gradient.rap', 'RAP'),
+    'foolmix': ('.gradient.foolmix', 'Foolmix'),
     # input transformation
     'dim': ('.input_transformation.dim', 'DIM'),
     'tim': ('.input_transformation.tim', 'TIM'),
