@@ -540,7 +540,7 @@ FOOLMIX = ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timi
 def test_more_attacks_gpu_vs_reference(golden, name, kw):
     """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA / RAP / DeCoWA end to end on the GPU
     against the reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  Measured on MI355X
-    (profiles/r02/pytest_gpu_new_attacks_r2i.log): 0.000 % for eight of them, dual MI-FGSM 0.008 %, AdaMSI-FGM 0.024 %,
+    (profiles/r02/pytest_gpu_new_attacks_r2i.log, pytest_gpu_foolmix_r2l.log): 0.000 % for nine of them (Foolmix included), dual MI-FGSM 0.008 %, AdaMSI-FGM 0.024 %,
     I-FGS2M 0.91 %.  The staircase sign steps by the RANK of |g| inside its plane, so unlike sign() it reacts to fp32
     rounding of the surrogate's gradient everywhere, not only near zero: on the CPU, noise of 1e-6 max|g| on the
     reference's own gradients moves 2.2 % of its uint8 output (1e-7: 0.03 %; MI-FGSM: 0 % at 1e-5) -- hence its own bound."""
