@@ -248,7 +248,8 @@ TAIL2 = (("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
          ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
          ("anda", dict(n_ens=4, epoch=3)),
          ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)),
-         ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False)))
+         ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False)),
+         ("ops", dict(num_sample_neighbor=2, num_sample_operator=3, epoch=2)))
 
 
 def gen_loops_tail2():
@@ -265,7 +266,8 @@ def gen_loops_tail2():
         atk = ref_shim.make_reference_attack(name, backbones.create("toy_cnn", seed=3, verbose=False), **kw)
         if name == "vaifgsm":
             atk.num_classes = 10
-        torch.manual_seed(1234)
+        import random
+        random.seed(11); np.random.seed(11); torch.manual_seed(1234)
         first = 1 if name == "anda" else n
         out["delta_" + name] = atk(x[:first], label[:first]).detach()
     # SSM with tricks (ssm_with_tricks.py:17-470): the Gaussian is hard-coded 3 x 224 x 224 -> 224-pixel input

@@ -67,6 +67,13 @@ def rotate_tensor(img, angle, mode="bilinear"):
     return fgsm_oracle.rotate_tensor(img, angle, mode)
 
 
+def functional_rotate(img, angle, interpolation=InterpolationMode.NEAREST, expand=False, center=None, fill=None):
+    """torchvision.transforms.functional.rotate with the defaults input_transformation/ops.py:219 relies on (nearest
+    neighbour, no expansion, image centre, zero fill)"""
+    assert not expand and center is None and fill is None
+    return rotate_tensor(img, angle, interpolation)
+
+
 class RandomRotation(nn.Module):
     """torchvision.transforms.RandomRotation(degrees=(lo, hi), interpolation=...): one angle per call from torch's
     default generator (``torch.empty(1).uniform_(lo, hi)``), applied to the whole batch"""
@@ -91,11 +98,16 @@ def _install_stubs():
         tv_tf.Normalize = _Normalize
         tv_tf.RandomRotation = RandomRotation
         tv_tf.InterpolationMode = InterpolationMode
+        tv_tff = types.ModuleType("torchvision.transforms.functional")
+        tv_tff.rotate = functional_rotate
+        tv_tff.InterpolationMode = InterpolationMode
+        tv_tf.functional = tv_tff
         tv.models = tv_models
         tv.transforms = tv_tf
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.models"] = tv_models
         sys.modules["torchvision.transforms"] = tv_tf
+        sys.modules["torchvision.transforms.functional"] = tv_tff
     if "timm" not in sys.modules:
         timm = types.ModuleType("timm")
         timm.list_models = lambda *a, **k: []

@@ -108,13 +108,17 @@ def test_bsr_loop(golden, monkeypatch):
                                      ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)),
                                      ("usmm", dict(num_scale=3, num_mix=2)), ("anda", dict(n_ens=4, epoch=3)),
                                      ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)),
-                                     ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False))])
+                                     ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False)),
+                                     ("ops", dict(num_sample_neighbor=2, num_sample_operator=3, epoch=2))])
 def test_more_attacks_through_kernels(golden, monkeypatch, name, kw):
     """the not-yet-measured GPU test of these attacks, run through the kernels' own code on the host"""
     import test_zz_hip_widened as W
     monkeypatch.setattr(W, "DEV", "cpu")
     monkeypatch.setattr(W, "BOUND", 0.0025)               # half the GPU bounds: only the kernels' fixed-order sum|g| differs
-    W.test_more_attacks_gpu_vs_reference(golden, name, kw)
+    if name == "ops":
+        W._run_more_attack(golden, name, kw, W.BOUND)
+    else:
+        W.test_more_attacks_gpu_vs_reference(golden, name, kw)
 
 
 @pytest.mark.parametrize("name,kw", [("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))])

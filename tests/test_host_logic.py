@@ -218,7 +218,8 @@ TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
          ("ens_mifgsm", dict(epoch=3, num_d=2)), ("maskblock", dict(patch_size=16)), ("usmm", dict(num_scale=3, num_mix=2)),
          ("anda", dict(n_ens=4, epoch=3)),
          ("rap", dict(epoch=6, transpoint=3, adv_steps=2)), ("decowa", dict(num_warping=3, epoch=3)),
-         ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False))]
+         ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False)),
+         ("ops", dict(num_sample_neighbor=2, num_sample_operator=3, epoch=2))]
 
 
 @pytest.mark.parametrize("name,kw", TAIL2)
@@ -233,7 +234,8 @@ def test_more_attacks_match_reference(golden, monkeypatch, name, kw):
     atk = make(name, **kw)
     if name == "vaifgsm":
         atk.num_classes = 10
-    torch.manual_seed(1234)
+    import random
+    random.seed(11); np.random.seed(11); torch.manual_seed(1234)
     delta = atk(x[:first], label[:first])
     assert not delta.requires_grad
     assert np.array_equal(delta.numpy(), g["delta_" + name])

@@ -153,6 +153,12 @@ def test_bsr_plane_groups(widened_on_host, shape):
     W.test_bsr_plane_groups(shape)
 
 
+@pytest.mark.parametrize("size,rate,geoms", [(224, 2.9, [(648, 0, 0), (300, 100, 249), (224, 424, 0)]),
+                                             (32, 2.9, [(91, 0, 0), (40, 20, 51)])])
+def test_dim_largest_ratio(size, rate, geoms):
+    G.test_dim_random(size, rate, geoms)
+
+
 def test_bsr_kernels_golden(golden, widened_on_host, monkeypatch):
     W.test_bsr_kernels_golden(golden, monkeypatch)
 

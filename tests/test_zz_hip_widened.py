@@ -536,14 +536,10 @@ TAIL2 = [("ifgssm", {}), ("vaifgsm", dict(epoch=4)), ("adamsi_fgm", {}),
 FOOLMIX = ("foolmix", dict(epoch=4, m=3, n=2, k=3, grad_chunk_size=5, print_timing=False))
 
 
-@pytest.mark.parametrize("name,kw", TAIL2 + [FOOLMIX])
-def test_more_attacks_gpu_vs_reference(golden, name, kw):
-    """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA / RAP / DeCoWA end to end on the GPU
-    against the reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  Measured on MI355X
-    (profiles/r02/pytest_gpu_new_attacks_r2i.log, pytest_gpu_foolmix_r2l.log): 0.000 % for nine of them (Foolmix included), dual MI-FGSM 0.008 %, AdaMSI-FGM 0.024 %,
-    I-FGS2M 0.91 %.  The staircase sign steps by the RANK of |g| inside its plane, so unlike sign() it reacts to fp32
-    rounding of the surrogate's gradient everywhere, not only near zero: on the CPU, noise of 1e-6 max|g| on the
-    reference's own gradients moves 2.2 % of its uint8 output (1e-7: 0.03 %; MI-FGSM: 0 % at 1e-5) -- hence its own bound."""
+OPS = ("ops", dict(num_sample_neighbor=2, num_sample_operator=3, epoch=2))
+
+
+def _run_more_attack(golden, name, kw, bound):
     g, base = golden("loops_tail2"), golden("loops_toy")
     x, label = t(base["x_u8"]).float() / 255, t(base["label"])
     first = 1 if name == "anda" else len(x)
@@ -555,12 +551,24 @@ def test_more_attacks_gpu_vs_reference(golden, name, kw):
     atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)      # the reference's CPU draws
     if name == "vaifgsm":
         atk.num_classes = 10
-    torch.manual_seed(1234)
+    import random
+    random.seed(11); np.random.seed(11); torch.manual_seed(1234)
     delta = atk(x, label).cpu()
     assert not delta.requires_grad and float(delta.abs().max()) <= EPS + 1e-6
     rate = mismatch(x, delta, g["delta_" + name])
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * rate))
-    assert rate <= {"ifgssm": 0.03, "adamsi_fgm": 0.002}.get(name, 0.001) * (BOUND / 0.005)
+    assert rate <= bound
+
+
+@pytest.mark.parametrize("name,kw", TAIL2 + [FOOLMIX])
+def test_more_attacks_gpu_vs_reference(golden, name, kw):
+    """I-FGS2M / VA-I-FGSM / AdaMSI-FGM / the MI-FGSM tricks / MaskBlock / US-MM / ANDA / RAP / DeCoWA end to end on the GPU
+    against the reference's golden loops (bit-exact on the host-logic tier, tests/test_host_logic.py).  Measured on MI355X
+    (profiles/r02/pytest_gpu_new_attacks_r2i.log, pytest_gpu_foolmix_r2l.log): 0.000 % for nine of them (Foolmix included), dual MI-FGSM 0.008 %, AdaMSI-FGM 0.024 %,
+    I-FGS2M 0.91 %.  The staircase sign steps by the RANK of |g| inside its plane, so unlike sign() it reacts to fp32
+    rounding of the surrogate's gradient everywhere, not only near zero: on the CPU, noise of 1e-6 max|g| on the
+    reference's own gradients moves 2.2 % of its uint8 output (1e-7: 0.03 %; MI-FGSM: 0 % at 1e-5) -- hence its own bound."""
+    _run_more_attack(golden, name, kw, {"ifgssm": 0.03, "adamsi_fgm": 0.002}.get(name, 0.001) * (BOUND / 0.005))
 
 
 @pytest.mark.parametrize("name,kw", [("ssm_h", dict(num_spectrum=2, epoch=2)), ("ssm_p", dict(num_scale=4, epoch=3))])
@@ -583,3 +591,22 @@ def test_ssm_tricks_gpu_vs_reference(golden, name, kw):
     rate = mismatch(x224, delta, g["delta_" + name])
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * rate))
     assert rate <= BOUND
+
+
+# ------------------------------------------------------------------ written after round 2's GPU minutes were spent
+def test_ops_gpu_vs_reference(golden):
+    """OPS end to end on the GPU against the reference's golden loop (bit-exact on the host-logic tier; through the
+    kernels' code on the host: 0.000 %).  NOT YET RUN ON MI355X -- the bound is the tier's (0.5 %); on the device the
+    nearest-neighbour rotations can pick the other neighbour where a sampling point falls within rounding of a pixel
+    boundary, which moves single pixels of single views out of the 7 a gradient is averaged over here."""
+    _run_more_attack(golden, OPS[0], OPS[1], BOUND)
+
+
+@pytest.mark.parametrize("size,rate,geoms", [(224, 2.9, [(648, 0, 0), (300, 100, 249), (224, 424, 0)]),
+                                             (32, 2.9, [(91, 0, 0), (40, 20, 51)])])
+def test_dim_largest_ratio(size, rate, geoms):
+    """OPS's largest resize-pad rate: the table-driven DIM kernels at their limit (a 102-pixel window of the padded image
+    per 32-pixel tile, 62.5 KB of LDS in the backward) -- bit-exact against the C oracle, as at every other ratio.
+    NOT YET RUN ON MI355X (green on the host stand-in)."""
+    import test_hip_kernels as K
+    K.test_dim_random(size, rate, geoms)

@@ -53,6 +53,7 @@ attack_zoo = {
     'ssm_h': ('.input_transformation.ssm_with_tricks', 'SSM_H'),
     'ssm_p': ('.input_transformation.ssm_with_tricks', 'SSM_P'),
     'decowa': ('.input_transformation.decowa', 'DeCowA'),
+    'ops': ('.input_transformation.ops', 'OPS'),
     'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
     'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)

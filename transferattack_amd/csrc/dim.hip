@@ -12,7 +12,7 @@
 //             updates that hit it, in that same order -> bit-identical accumulation.
 // Two kernel families: the lane-per-column kernels (dim_fwd_lanes_kernel / dim_bwd_lanes_kernel) cover every geometry
 // the reference can draw (resize <= 1.5 * size); the table-driven gathers (dim_fwd_kernel / dim_bwd_kernel) take the
-// rest (resize ratios up to ~2.4).  Same arithmetic, same bits.  The backward kernels also emit the per-tile sums of
+// rest (resize ratios up to ~2.9).  Same arithmetic, same bits.  The backward kernels also emit the per-tile sums of
 // |gx| (ws, nullable): when DIM's backward is the last kernel that writes the input gradient, the fused update reads
 // them instead of running its own pass over g (update.hip, K1).
 #include <limits.h>
@@ -42,7 +42,7 @@ constexpr int kDimMaxSide = 1024;       // LDS tables are sized for sides up to 
 
 // ---------------------------------------------------------------------------------------- forward
 constexpr int kDimFwdTile = 32;         // 32 x 32 outputs per workgroup, 4 per lane
-constexpr int kDimFwdMaxMid = 80;       // side of the LDS-resident window of the padded image; resize/size <= ~2.4
+constexpr int kDimFwdMaxMid = 100;      // side of the LDS-resident window of the padded image; resize/size <= ~2.9 (OPS)
 
 // Two stages through LDS: (1) the window of the zero-padded, rescaled image that this output tile touches is
 // computed once per pixel (4 taps of x each) into LDS; (2) every output pixel blends 4 LDS values.  Each padded pixel
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
 
 // --------------------------------------------------------------------------------------- backward
 constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
-constexpr int kDimBwdMaxMid = 80;       // side of the LDS-resident window of d(rescaled); rate <= ~2.4
+constexpr int kDimBwdMaxMid = 104;      // side of the LDS-resident window of d(rescaled); rate <= ~2.9 (OPS; 62.5 KB of LDS at 224 -> 649)
 
 struct Range {
     int lo, hi;
@@ -658,7 +658,7 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             return check_launch("dim_fwd_lanes");
         }
     }
-    // table-driven gather: resize ratios up to ~2.4
+    // table-driven gather: resize ratios up to ~2.9
     const int tps = static_cast<int>(ceil_div(size, kDimFwdTile));
     const int64_t blocks = planes * tps * tps;
     TA_REQUIRE(blocks < (1ll << 31), "too many tiles");
