@@ -159,6 +159,10 @@ def test_dim_largest_ratio(size, rate, geoms):
     G.test_dim_random(size, rate, geoms)
 
 
+def test_partials_registry_rules(widened_on_host, monkeypatch):
+    W.test_partials_registry_rules(monkeypatch)
+
+
 def test_bsr_kernels_golden(golden, widened_on_host, monkeypatch):
     W.test_bsr_kernels_golden(golden, monkeypatch)
 

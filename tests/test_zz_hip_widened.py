@@ -610,3 +610,32 @@ def test_dim_largest_ratio(size, rate, geoms):
     NOT YET RUN ON MI355X (green on the host stand-in)."""
     import test_hip_kernels as K
     K.test_dim_random(size, rate, geoms)
+
+
+def test_partials_registry_rules(monkeypatch):
+    """NOT YET RUN ON MI355X (green through the host stand-in).  The hand-over of |g| tile sums is refused when anything
+    could have changed the gradient or its ordering: a kernel of the binding writing a VIEW of the gradient (not only its
+    base address), a torch in-place op, a consumer on another stream than the producer; it is taken when none of that
+    happened"""
+    from transferattack_amd import _hip
+    gen = torch.Generator().manual_seed(3)
+    shape = (4, 3, 37, 41)
+    grad = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+    x, d = torch.rand(shape, generator=gen).to(DEV), torch.zeros(shape, device=DEV)
+
+    def reused():
+        before = _hip.stats["partials_reused"]
+        _hip.mi_update(grad, None, torch.empty_like(grad), d, x, 1.0, 1.6 / 255, EPS)
+        return _hip.stats["partials_reused"] - before == 1
+
+    _hip.abs_sum_partials(grad)
+    assert reused()
+    _hip.abs_sum_partials(grad)
+    _hip.axpy(x[1:2].contiguous(), x[2:3].contiguous(), 0.0, grad[1:2])        # writes one image of the gradient in place
+    assert not reused()
+    _hip.abs_sum_partials(grad)
+    grad.mul_(1.0)                                                             # torch in-place op: version bump
+    assert not reused()
+    _hip.abs_sum_partials(grad)
+    monkeypatch.setattr(_hip, "_stream", lambda like=None: 12345)
+    assert not reused()                                                        # consumer "on another stream"

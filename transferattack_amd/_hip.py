@@ -171,14 +171,15 @@ workspace = Workspace()
 #   * pointer, shape and autograd version must match (torch in-place ops bump the version);
 #   * every wrapper of this module that WRITES a tensor drops the entry if it writes that memory, and code that
 #     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials()``;
+#   * producer and consumer must be on the same stream (the sums are ordered after the producer only there);
 #   * one slot only: the next producer overwrites it.
-_partials = None            # (grad tensor, grad._version, ws tensor, sums per image)
+_partials = None            # (grad tensor, grad._version, ws tensor, sums per image, stream of the producer)
 stats = {"partials_reused": 0, "k1_passes": 0}
 
 
 def _register_partials(grad, ws, slots):
     global _partials
-    _partials = (grad, grad._version, ws, int(slots))
+    _partials = (grad, grad._version, ws, int(slots), _stream(grad))
 
 
 def invalidate_partials():
@@ -190,10 +191,11 @@ def _wrote(*tensors):
     """A kernel of this module wrote ``tensors``: sums registered for that memory are stale."""
     global _partials
     if _partials is not None:
-        ptr = _partials[0].data_ptr()
+        held = _partials[0]
+        lo, hi = held.data_ptr(), held.data_ptr() + held.numel() * held.element_size()
         for t in tensors:
-            if t is not None and t.data_ptr() == ptr:
-                _partials = None
+            if t is not None and t.device == held.device and t.data_ptr() < hi and lo < t.data_ptr() + t.numel() * t.element_size():
+                _partials = None                     # any overlap, not only the same base address (a view of the gradient)
                 return
 
 
@@ -202,9 +204,9 @@ def _take_partials(grad):
     entry, _partials = _partials, None
     if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
         return None                                   # the reference-order sum is never taken from a producer
-    tensor, version, ws, slots = entry
+    tensor, version, ws, slots, stream = entry
     if (tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
-            and tensor._version == version and tensor.device == grad.device):
+            and tensor._version == version and tensor.device == grad.device and stream == _stream(grad)):
         return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
         print("partials not reused: ptr %x vs %x, shape %s vs %s, version %d/%d vs %d" % (
