@@ -24,8 +24,10 @@ One JSON line on rank 0, with
   roofline      the fused momentum-sign-project update (ta_mi_update): algorithmic bytes of every launch -- 4 B/element
                 per operand it actually moves: read g, m, delta, x, write m, delta = 24; first iteration (no momentum
                 yet) 20; +4 when it also writes x + delta for the next iteration -- summed over the launches / summed
-                launch durations, measured with HIP events on the launch stream inside the timed region; peak
-                8 TB/s (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).
+                launch durations, measured with HIP events on the launch stream inside the timed region -- events bound
+                to the kernels' own dispatch packets (ta_timing_begin / ta_timing_end; ``roofline.clock``), with the
+                hipEventRecord-marker clock of the same launches beside it (``roofline.marker_clock``); peak 8 TB/s
+                (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).
   cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores,
                 same surrogate / workload, bounded sample.
 """
