@@ -86,6 +86,16 @@ def main():
                 images._ta_staging = staged                                       # keep the pinned buffer until consumed
         return images, labels, [it[2] for it in items], ready
 
+    def consume(loaded):
+        """order the consumer's stream after the upload of ``loaded`` (a result of ``batch``) and tell the caching
+        allocator that this stream uses the tensor too (it was allocated on the copy stream)"""
+        images, labels, filenames, ready = loaded
+        if ready is not None:
+            current = torch.cuda.current_stream(device)
+            current.wait_event(ready)
+            images.record_stream(current)
+        return images, labels, filenames
+
     if not args.eval:
         if args.ensemble or len(args.model.split(',')) > 1:
             args.model = args.model.split(',')
@@ -113,9 +123,7 @@ def main():
         io = ThreadPoolExecutor(max_workers=2)
         pending_write, next_batch = None, io.submit(batch, mine[0]) if mine else None
         for pos, batch_idx in enumerate(tqdm.tqdm(mine, disable=rank != 0)):
-            images, labels, filenames, ready = next_batch.result()
-            if ready is not None:
-                torch.cuda.current_stream(device).wait_event(ready)
+            images, labels, filenames = consume(next_batch.result())
             if pos + 1 < len(mine):
                 next_batch = io.submit(batch, mine[pos + 1])
             tadist.seed_batch(args.seed, batch_idx)
@@ -136,7 +144,7 @@ def main():
             model = wrap_model(model.eval().to(default_device()))
             for p in model.parameters():
                 p.requires_grad = False
-            asr = evaluate(model, (batch(i)[:3] for i in range(num_batches)), args.targeted)
+            asr = evaluate(model, (consume(batch(i)) for i in range(num_batches)), args.targeted)
             print(f'{model_name}: {asr:.1f}')
             res += f' {asr:.1f} |'
         print(res)
