@@ -249,7 +249,8 @@ def test_producer_side_partials_all_kernels():
 def test_sum_members():
     """the ensemble's fan-out backward: the members' gradients added last member first, like autograd's input buffer"""
     gen = torch.Generator().manual_seed(6)
-    for shape, m in (((3, 3, 224, 224), 4), ((2, 3, 7, 9), 3), ((1, 1, 1, 5), 2), ((2, 3, 31, 33), 8)):
+    for shape, m in (((3, 3, 224, 224), 4), ((2, 3, 7, 9), 3), ((1, 1, 1, 5), 2), ((2, 3, 31, 33), 8), ((2, 3, 31, 33), 9),
+                     ((1, 3, 16, 20), 20)):           # more than eight members: folded eight at a time, same order
         gs = [torch.randn(shape, generator=gen) for _ in range(m)]
         ref = gs[-1].clone()
         for g in reversed(gs[:-1]):

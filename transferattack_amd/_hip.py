@@ -414,6 +414,12 @@ def admix_bwd(gy, gx, num_admix, num_scale):
 def sum_members(grads, gx):
     """gx = ((g[m-1] + g[m-2]) + ...) + g[0] -- the members' input gradients of an EnsembleModel, in autograd's
     accumulation order; registers the |gx| tile sums."""
+    grads = list(grads)
+    while len(grads) > 8:                 # the entry takes eight operands: fold the LAST eight (they are added first) into one
+        head, tail = grads[:-8], grads[-8:]
+        partial = torch.empty_like(gx)
+        sum_members(tail, partial)
+        grads = head + [partial]
     m = len(grads)
     n, e = _batch(gx)
     ws, slots = _image_sums(gx, n, e)
