@@ -284,6 +284,11 @@ def gen_loops_tail2():
         np.random.seed(7)
         torch.manual_seed(4321)
         out["delta_" + name] = atk(x224, label[:1]).detach()
+    # L2T (l2t.py:415-529): its crops and spectrum views are hard-coded to 224 pixels
+    import random
+    atk = ref_shim.make_reference_attack("l2t", backbones.create("toy_cnn", seed=3, verbose=False), num_scale=2, epoch=3)
+    random.seed(13); np.random.seed(13); torch.manual_seed(1313)
+    out["delta_l2t"] = atk(x224, label[:1]).detach()
     save("loops_tail2", **out)
 
 

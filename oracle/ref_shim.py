@@ -74,6 +74,49 @@ def functional_rotate(img, angle, interpolation=InterpolationMode.NEAREST, expan
     return rotate_tensor(img, angle, interpolation)
 
 
+def _inverse_affine_matrix(center, angle, translate, scale, shear):
+    """torchvision 0.13 ``functional._get_inverse_affine_matrix`` (inverted=True), python doubles"""
+    import math
+    rot, sx, sy = math.radians(angle), math.radians(shear[0]), math.radians(shear[1])
+    cx, cy = center
+    tx, ty = translate
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    matrix = [d, -b, 0.0, -c, a, 0.0]
+    matrix = [x / scale for x in matrix]
+    matrix[2] += matrix[0] * (-cx - tx) + matrix[1] * (-cy - ty)
+    matrix[5] += matrix[3] * (-cx - tx) + matrix[4] * (-cy - ty)
+    matrix[2] += cx
+    matrix[5] += cy
+    return matrix
+
+
+def functional_affine(img, angle, translate, scale, shear, interpolation=InterpolationMode.NEAREST, fill=None, center=None):
+    """torchvision.transforms.functional.affine, tensor path of torchvision 0.13 (l2t.py:368): inverse matrix about the
+    image centre, ``_gen_affine_grid`` (the construction of rotate_tensor) and grid_sample with zero padding"""
+    assert fill is None and center is None
+    shear = [float(shear), 0.0] if not isinstance(shear, (list, tuple)) else [float(s) for s in shear] + [0.0] * (2 - len(shear))
+    matrix = _inverse_affine_matrix([0.0, 0.0], float(angle), [1.0 * t for t in translate], float(scale), shear)
+    h, w = img.shape[-2], img.shape[-1]
+    theta = torch.tensor(matrix, dtype=img.dtype).reshape(1, 2, 3)
+    base = torch.empty(1, h, w, 3, dtype=img.dtype)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, steps=w))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, steps=h).unsqueeze_(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=img.dtype)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
+    return F.grid_sample(img, grid.expand(img.shape[0], h, w, 2), mode=interpolation, padding_mode="zeros", align_corners=False)
+
+
+def functional_resized_crop(img, top, left, height, width, size, interpolation=InterpolationMode.BILINEAR):
+    """torchvision.transforms.functional.resized_crop on a float tensor (0.13): slice, then
+    ``interpolate(mode='bilinear', align_corners=False)`` without antialiasing"""
+    assert top >= 0 and left >= 0 and top + height <= img.shape[-2] and left + width <= img.shape[-1]
+    return F.interpolate(img[..., top:top + height, left:left + width], size=list(size), mode=interpolation, align_corners=False)
+
+
 class RandomRotation(nn.Module):
     """torchvision.transforms.RandomRotation(degrees=(lo, hi), interpolation=...): one angle per call from torch's
     default generator (``torch.empty(1).uniform_(lo, hi)``), applied to the whole batch"""
@@ -100,6 +143,8 @@ def _install_stubs():
         tv_tf.InterpolationMode = InterpolationMode
         tv_tff = types.ModuleType("torchvision.transforms.functional")
         tv_tff.rotate = functional_rotate
+        tv_tff.affine = functional_affine
+        tv_tff.resized_crop = functional_resized_crop
         tv_tff.InterpolationMode = InterpolationMode
         tv_tf.functional = tv_tff
         tv.models = tv_models

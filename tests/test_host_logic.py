@@ -414,6 +414,21 @@ def test_ssm_tricks_match_reference(golden, monkeypatch, name, kw):
     assert "mi_update" in fake_hip.calls
 
 
+def test_l2t_matches_reference(golden, monkeypatch):
+    """L2T (l2t.py:415-529): policy draws (torch.multinomial), the drawn pairs of operations, the REINFORCE-like policy
+    step and the MI-FGSM step -- the reference's loop on a 224-pixel input, bit for bit (every single operation is pinned
+    against the reference's own in tests/test_reference_live.py)"""
+    import random
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    x224 = u8_images(1, 224, 23).float() / 255
+    atk = make("l2t", num_scale=2, epoch=3)
+    random.seed(13); np.random.seed(13); torch.manual_seed(1313)
+    assert np.array_equal(atk(x224, t(base["label"])[:1]).numpy(), g["delta_l2t"])
+    assert "mi_update" in fake_hip.calls
+
+
 def test_dct_matrices_are_the_reference_transform():
     """the matrices ta_dct_pair multiplies with: C is the reference's unnormalised DCT-II (fgsra.py:49-123 as a matrix),
     D its inverse -- checked against the FFT factorisation the reference carries, in fp64-built fp32"""

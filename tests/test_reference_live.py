@@ -69,3 +69,33 @@ def test_fresh_inputs_reference_vs_oracle_and_product(ref_shim, monkeypatch, nam
     atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
     torch.manual_seed(4242)
     assert np.array_equal(atk(x, label).numpy(), want)
+
+
+def test_l2t_operations_against_the_reference(ref_shim, monkeypatch):
+    """every one of L2T's 98 candidate operations (l2t.py:375-387), forward and backward, against the reference's own
+    operation object on the same input with the same seeds of all three generators: the operations that run as HIP kernels
+    (sim, dim, admix, ssm -- here through the oracle-backed fake binding) and the device-op ones (rotations, block
+    shuffle, drop-out, masks, crops, translations) give the reference's bytes"""
+    import importlib
+    import random
+    ref_shim.import_reference()
+    ref_ops = importlib.import_module("transferattack.input_transformation.l2t").op_list
+    fake_hip.install(monkeypatch)
+    from transferattack_amd.input_transformation import l2t as mine
+    assert len(mine.op_list) == len(ref_ops) == 98
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 224, 224, generator=gen)
+    for k, (theirs, ours) in enumerate(zip(ref_ops, mine.op_list)):
+        outs = []
+        for op, host_draws in ((theirs, None), (ours, None), (ours, 'cpu')):
+            monkeypatch.setattr(mine, "_draw_device", host_draws)          # None: product mode; 'cpu': seeded parity mode
+            random.seed(k); np.random.seed(k); torch.manual_seed(k)
+            xin = x.clone().requires_grad_(True)
+            y = op(xin)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1000 + k))
+            gx = torch.autograd.grad(y, xin, gy)[0] if y.requires_grad else torch.zeros_like(x)
+            outs.append((y.detach(), gx))
+        assert outs[0][0].shape == outs[1][0].shape, k
+        for got in outs[1:]:
+            assert torch.equal(outs[0][0], got[0]), "operation %d (%s): forward differs" % (k, type(ours).__name__)
+            assert torch.equal(outs[0][1], got[1]), "operation %d (%s): backward differs" % (k, type(ours).__name__)

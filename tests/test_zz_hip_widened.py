@@ -639,3 +639,24 @@ def test_partials_registry_rules(monkeypatch):
     _hip.abs_sum_partials(grad)
     monkeypatch.setattr(_hip, "_stream", lambda like=None: 12345)
     assert not reused()                                                        # consumer "on another stream"
+
+
+def test_l2t_gpu_vs_reference(golden):
+    """L2T end to end on the GPU against the reference's golden loop (policy draws, drawn operation pairs on the HIP
+    kernels / device gathers, policy step, MI-FGSM step).  NOT YET RUN ON MI355X (bit-exact on the host-logic tier;
+    every operation pinned against the reference's own in tests/test_reference_live.py)."""
+    import random
+    from conftest import u8_images
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    x224 = u8_images(1, 224, 23).float() / 255
+    base_cls = ta.load_attack_class("l2t")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    cls = type("Gpu" + base_cls.__name__, (base_cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})
+    atk = cls(model_name="injected", num_scale=2, epoch=3)
+    atk.noise_source = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)
+    random.seed(13); np.random.seed(13); torch.manual_seed(1313)
+    delta = atk(x224, t(base["label"])[:1]).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-6
+    rate = mismatch(x224, delta, g["delta_l2t"])
+    print("l2t: uint8 mismatch rate GPU-vs-reference %.4f%%" % (100 * rate))
+    assert rate <= BOUND

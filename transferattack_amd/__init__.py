@@ -54,6 +54,7 @@ attack_zoo = {
     'ssm_p': ('.input_transformation.ssm_with_tricks', 'SSM_P'),
     'decowa': ('.input_transformation.decowa', 'DeCowA'),
     'ops': ('.input_transformation.ops', 'OPS'),
+    'l2t': ('.input_transformation.l2t', 'L2T'),
     'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
     'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
