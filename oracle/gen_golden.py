@@ -289,6 +289,18 @@ def gen_loops_tail2():
     atk = ref_shim.make_reference_attack("l2t", backbones.create("toy_cnn", seed=3, verbose=False), num_scale=2, epoch=3)
     random.seed(13); np.random.seed(13); torch.manual_seed(1313)
     out["delta_l2t"] = atk(x224, label[:1]).detach()
+    # SU (su.py:39-182): 224-pixel inputs (its crop and DI sizes are the module constants), targeted by default; the
+    # feature layer is resolved by surrogate NAME there -- for the toy surrogate it is the output of its third convolution
+    su_cls = ref_shim.import_reference().load_attack_class("su")
+    toy = backbones.create("toy_cnn", seed=3, verbose=False)
+    from transferattack.utils import wrap_model as ref_wrap
+    atk = type("Ref_SU", (su_cls,), {"load_model": lambda self, mn: ref_wrap(toy.eval()),
+                                     "_target_layer": lambda self, mn, depth: self.model[1].body[4]})(model_name="injected", epoch=3)
+    x2 = u8_images(2, 224, 29).float() / 255
+    tgt = (label[:2] + 3) % 10
+    random.seed(17); np.random.seed(17); torch.manual_seed(1717)
+    out["delta_su"] = atk(x2, [label[:2], tgt]).detach()
+    out["su_target"] = tgt
     save("loops_tail2", **out)
 
 

@@ -117,6 +117,47 @@ def functional_resized_crop(img, top, left, height, width, size, interpolation=I
     return F.interpolate(img[..., top:top + height, left:left + width], size=list(size), mode=interpolation, align_corners=False)
 
 
+class RandomResizedCrop(nn.Module):
+    """torchvision.transforms.RandomResizedCrop (0.13) for float NCHW tensors, as input_transformation/su.py:49 uses it:
+    ``get_params`` -- up to ten (area, log-uniform aspect ratio) draws from torch's default generator, else a central
+    crop -- then ``resized_crop`` (slice + bilinear interpolate, no antialiasing); one crop for the whole batch"""
+
+    def __init__(self, size, scale=(0.08, 1.0), ratio=(3. / 4., 4. / 3.), interpolation=InterpolationMode.BILINEAR):
+        super().__init__()
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+        self.scale, self.ratio, self.interpolation = scale, ratio, interpolation
+
+    @staticmethod
+    def get_params(img, scale, ratio):
+        import math
+        height, width = img.shape[-2], img.shape[-1]
+        area = height * width
+        log_ratio = torch.log(torch.tensor(ratio))
+        for _ in range(10):
+            target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+            aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+            w = int(round(math.sqrt(target_area * aspect_ratio)))
+            h = int(round(math.sqrt(target_area / aspect_ratio)))
+            if 0 < w <= width and 0 < h <= height:
+                i = torch.randint(0, height - h + 1, size=(1,)).item()
+                j = torch.randint(0, width - w + 1, size=(1,)).item()
+                return i, j, h, w
+        in_ratio = float(width) / float(height)
+        if in_ratio < min(ratio):
+            w = width
+            h = int(round(w / min(ratio)))
+        elif in_ratio > max(ratio):
+            h = height
+            w = int(round(h * max(ratio)))
+        else:
+            w, h = width, height
+        return (height - h) // 2, (width - w) // 2, h, w
+
+    def forward(self, img):
+        i, j, h, w = self.get_params(img, self.scale, self.ratio)
+        return functional_resized_crop(img, i, j, h, w, self.size, self.interpolation)
+
+
 class RandomRotation(nn.Module):
     """torchvision.transforms.RandomRotation(degrees=(lo, hi), interpolation=...): one angle per call from torch's
     default generator (``torch.empty(1).uniform_(lo, hi)``), applied to the whole batch"""
@@ -140,6 +181,7 @@ def _install_stubs():
         tv_tf.Resize = _Resize
         tv_tf.Normalize = _Normalize
         tv_tf.RandomRotation = RandomRotation
+        tv_tf.RandomResizedCrop = RandomResizedCrop
         tv_tf.InterpolationMode = InterpolationMode
         tv_tff = types.ModuleType("torchvision.transforms.functional")
         tv_tff.rotate = functional_rotate

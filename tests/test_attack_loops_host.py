@@ -130,6 +130,13 @@ def test_ssm_tricks_through_kernels(golden, monkeypatch, name, kw):
     W.test_ssm_tricks_gpu_vs_reference(golden, name, kw)
 
 
+def test_su_through_kernels(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.002)
+    W.test_su_gpu_vs_reference(golden)
+
+
 def test_l2t_through_kernels(golden, monkeypatch):
     import test_zz_hip_widened as W
     monkeypatch.setattr(W, "DEV", "cpu")

@@ -429,6 +429,24 @@ def test_l2t_matches_reference(golden, monkeypatch):
     assert "mi_update" in fake_hip.calls
 
 
+def test_su_matches_reference(golden, monkeypatch):
+    """SU (su.py:39-182), targeted: local crop (RandomResizedCrop draws), DI draws (numpy), logit loss + feature
+    similarity at the hooked layer, TI smoothing, MI-FGSM step -- the reference's loop on two 224-pixel images, bit for bit"""
+    import random
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    cls = ta.load_attack_class("su")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("CpuSU", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval()),
+                                 "_target_layer": lambda self, mn, depth: self.model[1].body[4]})(model_name="injected", epoch=3)
+    x2 = u8_images(2, 224, 29).float() / 255
+    random.seed(17); np.random.seed(17); torch.manual_seed(1717)
+    delta = atk(x2, [t(base["label"])[:2], t(g["su_target"])])
+    assert np.array_equal(delta.numpy(), g["delta_su"])
+    assert "depthwise_conv2d_same" in fake_hip.calls and "mi_update" in fake_hip.calls
+
+
 def test_dct_matrices_are_the_reference_transform():
     """the matrices ta_dct_pair multiplies with: C is the reference's unnormalised DCT-II (fgsra.py:49-123 as a matrix),
     D its inverse -- checked against the FFT factorisation the reference carries, in fp64-built fp32"""

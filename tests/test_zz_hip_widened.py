@@ -660,3 +660,23 @@ def test_l2t_gpu_vs_reference(golden):
     rate = mismatch(x224, delta, g["delta_l2t"])
     print("l2t: uint8 mismatch rate GPU-vs-reference %.4f%%" % (100 * rate))
     assert rate <= BOUND
+
+
+def test_su_gpu_vs_reference(golden):
+    """SU (targeted) end to end on the GPU against the reference's golden loop: local crop + DI on the device, feature
+    hook, TI smoothing through ta_depthwise_conv2d_same (5 x 5), fused update.  NOT YET RUN ON MI355X (bit-exact on the
+    host-logic tier)."""
+    import random
+    from conftest import u8_images
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    cls = ta.load_attack_class("su")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("GpuSU", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV)),
+                                 "_target_layer": lambda self, mn, depth: self.model[1].body[4]})(model_name="injected", epoch=3)
+    x2 = u8_images(2, 224, 29).float() / 255
+    random.seed(17); np.random.seed(17); torch.manual_seed(1717)
+    delta = atk(x2, [t(base["label"])[:2], t(g["su_target"])]).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-6
+    rate = mismatch(x2, delta, g["delta_su"])
+    print("su: uint8 mismatch rate GPU-vs-reference %.4f%%" % (100 * rate))
+    assert rate <= BOUND

@@ -55,6 +55,7 @@ attack_zoo = {
     'decowa': ('.input_transformation.decowa', 'DeCowA'),
     'ops': ('.input_transformation.ops', 'OPS'),
     'l2t': ('.input_transformation.l2t', 'L2T'),
+    'su': ('.input_transformation.su', 'SU'),
     'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
     'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
