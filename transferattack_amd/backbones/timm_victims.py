@@ -12,7 +12,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .vit import Block as VitBlock, Mlp
 
