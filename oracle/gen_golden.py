@@ -301,6 +301,12 @@ def gen_loops_tail2():
     random.seed(17); np.random.seed(17); torch.manual_seed(1717)
     out["delta_su"] = atk(x2, [label[:2], tgt]).detach()
     out["su_target"] = tgt
+    # Everywhere Attack (everywhere.py:14-412): always targeted, labels = [truth, target]
+    ev_cls = ref_shim.import_reference().load_attack_class("everywhere")
+    toy = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("Ref_Everywhere", (ev_cls,), {"load_model": lambda self, mn: ref_wrap(toy.eval())})(model_name="injected", targeted=True, epoch=8)
+    random.seed(19); np.random.seed(19); torch.manual_seed(1919)
+    out["delta_everywhere"] = atk(x2, [label[:2], tgt]).detach()
     save("loops_tail2", **out)
 
 

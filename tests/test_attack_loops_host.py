@@ -137,6 +137,13 @@ def test_su_through_kernels(golden, monkeypatch):
     W.test_su_gpu_vs_reference(golden)
 
 
+def test_everywhere_through_kernels(golden, monkeypatch):
+    import test_zz_hip_widened as W
+    monkeypatch.setattr(W, "DEV", "cpu")
+    monkeypatch.setattr(W, "BOUND", 0.002)
+    W.test_everywhere_gpu_vs_reference(golden)
+
+
 def test_l2t_through_kernels(golden, monkeypatch):
     import test_zz_hip_widened as W
     monkeypatch.setattr(W, "DEV", "cpu")

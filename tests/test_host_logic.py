@@ -447,6 +447,24 @@ def test_su_matches_reference(golden, monkeypatch):
     assert "depthwise_conv2d_same" in fake_hip.calls and "mi_update" in fake_hip.calls
 
 
+def test_everywhere_matches_reference(golden, monkeypatch):
+    """Everywhere Attack (everywhere.py:14-412, 'CDTM'): clean-feature recording, per-layer mixup draws, cell selection,
+    resolution-keeping DI, TI smoothing, its own momentum and box arithmetic -- the reference's loop on two 224-pixel
+    images, bit for bit"""
+    import random
+    from conftest import u8_images
+    fake_hip.install(monkeypatch)
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    cls = ta.load_attack_class("everywhere")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("CpuEverywhere", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval())})(model_name="injected", targeted=True, epoch=8)
+    x2 = u8_images(2, 224, 29).float() / 255
+    random.seed(19); np.random.seed(19); torch.manual_seed(1919)
+    delta = atk(x2, [t(base["label"])[:2], t(g["su_target"])])
+    assert np.array_equal(delta.numpy(), g["delta_everywhere"])
+    assert "depthwise_conv2d_same" in fake_hip.calls
+
+
 def test_dct_matrices_are_the_reference_transform():
     """the matrices ta_dct_pair multiplies with: C is the reference's unnormalised DCT-II (fgsra.py:49-123 as a matrix),
     D its inverse -- checked against the FFT factorisation the reference carries, in fp64-built fp32"""

@@ -680,3 +680,23 @@ def test_su_gpu_vs_reference(golden):
     rate = mismatch(x2, delta, g["delta_su"])
     print("su: uint8 mismatch rate GPU-vs-reference %.4f%%" % (100 * rate))
     assert rate <= BOUND
+
+
+def test_everywhere_gpu_vs_reference(golden):
+    """Everywhere Attack end to end on the GPU against the reference's golden loop (feature-mixup hooks, cell masks, DI,
+    TI through ta_depthwise_conv2d_same, its own momentum / box arithmetic).  NOT YET RUN ON MI355X (bit-exact on the
+    host-logic tier)."""
+    import random
+    from conftest import u8_images
+    g, base = golden("loops_tail2"), golden("loops_toy")
+    cls = ta.load_attack_class("everywhere")
+    model = backbones.create("toy_cnn", seed=3, verbose=False)
+    atk = type("GpuEverywhere", (cls,), {"load_model": lambda self, mn: wrap_model(model.eval().to(DEV))})(
+        model_name="injected", targeted=True, epoch=8)
+    x2 = u8_images(2, 224, 29).float() / 255
+    random.seed(19); np.random.seed(19); torch.manual_seed(1919)
+    delta = atk(x2, [t(base["label"])[:2], t(g["su_target"])]).cpu()
+    assert float(delta.abs().max()) <= EPS + 1e-6
+    rate = mismatch(x2, delta, g["delta_everywhere"])
+    print("everywhere: uint8 mismatch rate GPU-vs-reference %.4f%%" % (100 * rate))
+    assert rate <= BOUND

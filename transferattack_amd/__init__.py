@@ -56,6 +56,7 @@ attack_zoo = {
     'ops': ('.input_transformation.ops', 'OPS'),
     'l2t': ('.input_transformation.l2t', 'L2T'),
     'su': ('.input_transformation.su', 'SU'),
+    'everywhere': ('.input_transformation.everywhere', 'EverywhereAttack'),
     'maskblock': ('.input_transformation.maskblock', 'MaskBlock'),
     'usmm': ('.input_transformation.usmm', 'USMM'),
     'dts': ('.input_transformation.dts', 'DTS'),            # DIM+TIM+SIM composition (not in the reference zoo)
