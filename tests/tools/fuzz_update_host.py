@@ -27,7 +27,7 @@ rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     shape = (int(rng.randint(1, 6)), int(rng.randint(1, 4)), int(rng.randint(1, 70)), int(rng.randint(1, 90)))
     try:
-        G.test_fused_update_random(shape, False)
+        G.test_fused_update_random(shape)
         if shape[1] <= 3:
             G.test_normalize_and_producer_side_partials(shape)
     except AssertionError:
