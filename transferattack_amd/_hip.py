@@ -190,12 +190,14 @@ def invalidate_partials():
 def _wrote(*tensors):
     """A kernel of this module wrote ``tensors``: sums registered for that memory are stale."""
     global _partials
-    if _partials is not None:
-        held = _partials[0]
+    entry = _partials                                # one read: another host thread (main.py's writer) may clear it meanwhile
+    if entry is not None:
+        held = entry[0]
         lo, hi = held.data_ptr(), held.data_ptr() + held.numel() * held.element_size()
         for t in tensors:
             if t is not None and t.device == held.device and t.data_ptr() < hi and lo < t.data_ptr() + t.numel() * t.element_size():
-                _partials = None                     # any overlap, not only the same base address (a view of the gradient)
+                if _partials is entry:
+                    _partials = None                 # any overlap, not only the same base address (a view of the gradient)
                 return
 
 
