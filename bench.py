@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (6290 GB/s measured float4 co
 BYTES_PER_ELEM = 24            # fused update: r g,m,d,x  w m,d
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=8)
@@ -63,13 +63,22 @@ def parse():
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
     p.add_argument("--kernel-times", type=int, default=0,
                    help="time every HIP kernel call of the loop with events (config.kernels); for the transform attacks")
-    return p.parse_args()
+    p.add_argument("--graph", type=int, default=0,
+                   help="capture one whole attack iteration (transform, surrogate forward/backward, fused update) in a "
+                        "hipGraph and replay it K times per batch (TA_GRAPH=1; attacks without host-side draws only)")
+    # the four flags below exist for tests/test_bench_ranks.py: the multi-rank reporting path (barrier, MAX all-reduce of
+    # the time, all-gather of the rates, the sharded-ensemble layout) on gloo / CPU tensors with the kernels' host build
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU tests)")
+    p.add_argument("--device", default="cuda", help="cuda (= HIP); cpu only under the tests' host stand-in of the kernels")
+    p.add_argument("--image-size", type=int, default=224)
+    p.add_argument("--classes", type=int, default=1000)
+    return p.parse_args(argv)
 
 
-def synthetic_batch(n, seed):
+def synthetic_batch(n, seed, size=224, classes=1000):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255
-    y = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(seed + 1))
+    x = torch.randint(0, 256, (n, 3, size, size), generator=g, dtype=torch.uint8).float() / 255
+    y = torch.randint(0, classes, (n,), generator=torch.Generator().manual_seed(seed + 1))
     return x, y
 
 
@@ -245,96 +254,215 @@ def launch_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def main():
-    args = parse()
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        launch_ranks(args)
+def open_world(args):
+    """(rank, world, local rank) of this process; joins the process group the launcher described (one rank per GPU)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting what actually runs" % (args.gpus, world),
               file=sys.stderr)
-    torch.cuda.set_device(local)
+    if args.device == "cuda":
+        torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if not dist.is_initialized():
+            if args.device == "cuda":
+                dist.init_process_group(args.backend, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(args.backend)
+    return rank, world, local
 
-    os.environ["TA_FOLD_BN"] = "1" if args.fold_bn else "0"
-    os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
-    import transferattack_amd as ta
-    from transferattack_amd import _hip
-    from transferattack_amd import dist as tadist
-    _hip.load()
-    torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
-    model_name = args.model.split(",") if "," in args.model else args.model      # list -> EnsembleModel, as main.py:39-40
+
+def build_attacker(args, world):
+    """-> (attacker, index of this rank's image shard, number of image shards, description of the layout).  A list of
+    surrogates on a world that is a multiple of its length: one member per rank (transferattack_amd.dist.sharded_attack)."""
     import contextlib
+    import transferattack_amd as ta
+    from transferattack_amd import dist as tadist
+    rank = int(os.environ.get("RANK", "0"))
+    model_name = args.model.split(",") if "," in args.model else args.model      # list -> EnsembleModel, as main.py:39-40
     shard_rank, shard_world, layout = rank, world, "image-shard x%d, no collective" % world
     with contextlib.redirect_stdout(sys.stderr):              # stdout carries exactly one line: the JSON result
         cls = ta.load_attack_class(args.attack)
         if isinstance(model_name, list) and world > 1 and world % len(model_name) == 0:
             attacker, member, shard_rank, shard_world = tadist.sharded_attack(cls, args.attack, model_name, world)
-            layout = "%d image shard(s) x %d model ranks (one surrogate per rank; RCCL all-reduce of logits and input " \
-                     "gradients)" % (shard_world, len(model_name))
+            layout = "%d image shard(s) x %d model ranks (one surrogate per rank; %s all-reduce of logits and input " \
+                     "gradients)" % (shard_world, len(model_name), "RCCL" if args.backend == "nccl" else args.backend)
         else:
             attacker = cls(model_name=model_name)
+    return attacker, shard_rank, shard_world, layout
+
+
+def device_sync(args):
+    if args.device == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_region(step, args, world, before=None):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + device synchronisation on both sides.
+    -> (seconds between the two brackets on this rank, seconds until this rank's own last step finished)."""
+    import torch.distributed as dist
+    for i in range(args.warmup):
+        step(i)
+    device_sync(args)
+    if world > 1:
+        dist.barrier()
+    device_sync(args)
+    if before is not None:
+        before()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    device_sync(args)
+    mine = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    device_sync(args)
+    return time.perf_counter() - t0, mine
+
+
+def over_ranks(dt, rate, world, dev):
+    """MAX of the bracketed time over the ranks and every rank's own images/s (all-gather), as the contract asks.
+    -> (max seconds, [rate of rank 0, ...], world size the collective saw, backend name)"""
+    if world == 1:
+        return dt, [rate], 1, "none (single process)"
+    import torch.distributed as dist
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rates = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(rates, torch.tensor([rate], device=dev, dtype=torch.float64))
+    return float(tmax.item()), [round(float(r.item()), 2) for r in rates], dist.get_world_size(), dist.get_backend()
+
+
+def roofline(args, sink, dispatch_ms, timing_note, _hip):
+    """The fused update's launches of the timed region -> the ``roofline`` object (module docstring)."""
+    # two clocks over the same launches: hipEventRecord markers before / after each call (they include the ~3 us the
+    # command processor spends between a marker and a dependent kernel) and events bound to the kernels' own dispatch
+    # packets (begin of the call's first kernel -> end of the update kernel: what rocprofv3 --kernel-trace reports).
+    # The roofline figure uses the dispatch clock when it is sane, and always reports the marker clock beside it.
+    marker_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
+    durs_us, clock = marker_us, "hipEventRecord markers around each call"
+    if len(dispatch_ms) == len(sink) and all(0.0 < 1e3 * d <= m + 1.0 for d, m in zip(dispatch_ms, marker_us)):
+        durs_us, clock = [1e3 * d for d in dispatch_ms], "HIP events bound to the kernels' dispatch packets"
+    launch_bytes = [n_ * e_ * b_ for _, _, n_, e_, b_ in sink]
+    mean_us = sum(durs_us) / len(durs_us)
+    mean_bytes = sum(launch_bytes) / len(launch_bytes)
+    achieved = sum(launch_bytes) / sum(durs_us) / 1e3            # GB/s over the launches of the timed region
+    full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
+    pmc = committed_pmc_traffic(sink, _hip)
+    return {"bound": "hbm", "kernel": ("ta_mi_update (mi_update_kernel; |g| tile sums left by the kernel "
+                                       "that produced g)" if _hip.stats["k1_passes"] == 0 else
+                                       "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # NOT measured by this run (rocprofv3 cannot count from inside bench.py): the committed PMC passes over this
+            # kernel (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction), priced per launch; the source is named
+            "traffic": pmc["bytes_per_launch"] if pmc else None,
+            "traffic_source": pmc["source"] if pmc else None,
+            "clock": clock if timing_note is None else clock + " (dispatch clock unavailable: %s)" % timing_note,
+            "marker_clock": {"mean_us": round(sum(marker_us) / len(marker_us), 2),
+                             "frac": round(sum(launch_bytes) / sum(marker_us) / 1e3 / HBM_PEAK_GBS, 4)},
+            "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
+            "algorithmic_bytes_per_launch": int(mean_bytes),
+            "steady_state_launch": {"bytes": int(max(launch_bytes)),
+                                    "mean_us": round(sum(d for d, _ in full) / len(full), 2),
+                                    "GBps": round(sum(b for _, b in full) / sum(d for d, _ in full) / 1e3, 1)},
+            "k1_pass_skipped_launches": _hip.stats["partials_reused"],
+            "k1_passes": _hip.stats["k1_passes"],
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
+
+
+def committed_pmc_traffic(sink, _hip):
+    """HBM bytes per launch priced with the COMMITTED rocprofv3 PMC passes over the shipped kernel
+    (profiles/pmc_update_kernel.json, tools/gpu_check.sh pmc, N = 125): each launch of the timed region with the counters
+    of its own kernel instantiation (steady state / first iteration / decay 0 move different operands).  A constant read
+    from a file, labelled as such -- not a measurement of this run."""
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")
+    if not os.path.isfile(pmc_path):
+        return None
+    kernels = json.load(open(pmc_path))["kernels"]
+    per_shape = {}
+    for name, c in kernels.items():
+        if "mi_update_kernel<" not in name:
+            continue
+        flags = [f.strip() for f in name[name.index("<") + 1:name.rindex(">")].split(",")]
+        # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV>
+        key = tuple(f == "true" for f in flags[4:8])
+        per_shape[key] = c["fetch_B_per_elem_corrected"] + c["write_B_per_elem"]
+    k1 = next((c["fetch_B_per_elem_corrected"] for name, c in kernels.items() if "abs_sum_partials" in name), 4.0)
+    total, priced = 0.0, 0
+    for _, _, n_l, e_l, b_l in sink:
+        # bytes/element -> which operands moved: 12 (g, d, x read; d written... ) + 4 each for m_in, m_out, x_adv
+        shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k)) == b_l and not k[0]]
+        if shapes:
+            total += per_shape[shapes[0]] * n_l * e_l
+            priced += 1
+    if priced != len(sink):
+        return None
+    n_, e_ = sink[0][2], sink[0][3]
+    return {"bytes_per_launch": int(total / len(sink) + (k1 * e_ * n_ if _hip.stats["k1_passes"] > 0 else 0)),
+            "source": "NOT measured in this run: profiles/pmc_update_kernel.json, the committed rocprofv3 --pmc FETCH_SIZE / "
+                      "WRITE_SIZE passes over the shipped kernel at N=125, priced per launch"}
+
+
+def main(argv=None):
+    args = parse(argv)
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
+    rank, world, local = open_world(args)
+
+    os.environ["TA_FOLD_BN"] = "1" if args.fold_bn else "0"
+    os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
+    if args.graph:
+        os.environ["TA_GRAPH"] = "1"
+    from transferattack_amd import _hip
+    _hip.load()
+    torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
+    attacker, shard_rank, shard_world, layout = build_attacker(args, world)
     dev = attacker.device
 
     total = args.steps + args.warmup
-    batches = [tuple(t.to(dev) for t in synthetic_batch(args.batch, 1000 * shard_rank + 2 * i)) for i in range(min(total, 4))]
+    batches = [tuple(t.to(dev) for t in synthetic_batch(args.batch, 1000 * shard_rank + 2 * i, args.image_size, args.classes))
+               for i in range(min(total, 4))]
 
     def step(i):
         x, y = batches[i % len(batches)]
         return attacker(x, y)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _hip.profile_sink = []
-    timing_note = None
-    try:
-        _hip.timing_begin(args.steps * 64 + 64)     # events on the update kernels' own dispatch packets
-    except _hip.HipExtensionError as exc:
-        timing_note = str(exc)[:200]
-    _hip.stats["partials_reused"] = _hip.stats["k1_passes"] = 0
-    kernel_records, restore_kernels = (instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
-                                       if args.kernel_times else ({}, lambda: None))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    mine = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    state = {"timing_note": None, "records": {}, "restore": lambda: None}
+
+    def before_timed_steps():
+        if not on_gpu:
+            return
+        _hip.profile_sink = []
+        try:
+            _hip.timing_begin(args.steps * 64 + 64)     # events on the update kernels' own dispatch packets
+        except _hip.HipExtensionError as exc:
+            state["timing_note"] = str(exc)[:200]
+        _hip.stats["partials_reused"] = _hip.stats["k1_passes"] = 0
+        if args.kernel_times:
+            state["records"], state["restore"] = instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
+
+    dt, mine = timed_region(step, args, world, before_timed_steps)
     sink, _hip.profile_sink = _hip.profile_sink, None
+    timing_note, kernel_records = state["timing_note"], state["records"]
     dispatch_ms = []
-    if timing_note is None:
+    if on_gpu and timing_note is None:
         try:
             dispatch_ms = _hip.timing_end()
         except _hip.HipExtensionError as exc:
             timing_note = str(exc)[:200]
-    restore_kernels()
-    per_rank = [round(args.steps * args.batch / mine, 2)]
-    observed_world, backend = 1, "none (single process)"
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        rates = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(rates, torch.tensor([per_rank[0]], device=dev, dtype=torch.float64))
-        per_rank = [round(float(r.item()), 2) for r in rates]
-        observed_world, backend = dist.get_world_size(), dist.get_backend()
+    state["restore"]()
+    dt, per_rank, observed_world, backend = over_ranks(dt, round(args.steps * args.batch / mine, 2), world, dev)
 
     if rank == 0:
         images = args.steps * args.batch * shard_world
-        if not sink:        # attacks that call the two hooks separately (VMI): time the fused pair stand-alone
+        if on_gpu and not sink:   # attacks that call the two hooks separately: time the fused pair stand-alone
             x0 = batches[0][0]
             g0, m0, d0 = torch.randn_like(x0) * 1e-4, torch.randn_like(x0), torch.zeros_like(x0)
             _hip.profile_sink = sink = []
@@ -345,46 +473,6 @@ def main():
             torch.cuda.synchronize()
             _hip.profile_sink = None
             dispatch_ms = _hip.timing_end() if timing_note is None else []
-        # two clocks over the same launches: hipEventRecord markers before / after each call (they include the ~3 us the
-        # command processor spends between a marker and a dependent kernel) and events bound to the kernels' own dispatch
-        # packets (begin of the call's first kernel -> end of the update kernel: what rocprofv3 --kernel-trace reports).
-        # The roofline figure uses the dispatch clock when it is sane, and always reports the marker clock beside it.
-        marker_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
-        durs_us, clock = marker_us, "hipEventRecord markers around each call"
-        if len(dispatch_ms) == len(sink) and all(0.0 < 1e3 * d <= m + 1.0 for d, m in zip(dispatch_ms, marker_us)):
-            durs_us, clock = [1e3 * d for d in dispatch_ms], "HIP events bound to the kernels' dispatch packets"
-        launch_bytes = [n_ * e_ * b_ for _, _, n_, e_, b_ in sink]
-        n_, e_ = sink[0][2], sink[0][3]
-        mean_us = sum(durs_us) / len(durs_us)
-        mean_bytes = sum(launch_bytes) / len(launch_bytes)
-        achieved = sum(launch_bytes) / sum(durs_us) / 1e3            # GB/s over the launches of the timed region
-        full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_update_kernel.json")
-        if os.path.isfile(pmc_path):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes over the SHIPPED kernel (tools/gpu_check.sh pmc,
-            # N = 125): each launch of the timed region is priced with the counters of its own kernel instantiation
-            # (steady state / first iteration / decay 0 differ in the operands they move)
-            kernels = json.load(open(pmc_path))["kernels"]
-
-            per_shape = {}
-            for name, c in kernels.items():
-                if "mi_update_kernel<" not in name:
-                    continue
-                flags = [f.strip() for f in name[name.index("<") + 1:name.rindex(">")].split(",")]
-                # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV>
-                key = tuple(f == "true" for f in flags[4:8])
-                per_shape[key] = c["fetch_B_per_elem_corrected"] + c["write_B_per_elem"]
-            k1 = next((c["fetch_B_per_elem_corrected"] for name, c in kernels.items() if "abs_sum_partials" in name), 4.0)
-            total, priced = 0.0, 0
-            for _, _, n_l, e_l, b_l in sink:
-                # bytes/element -> which operands moved: 12 (g, d, x read; d written... ) + 4 each for m_in, m_out, x_adv
-                shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k)) == b_l and not k[0]]
-                if shapes:
-                    total += per_shape[shapes[0]] * n_l * e_l
-                    priced += 1
-            if priced == len(sink):
-                traffic = int(total / len(sink) + (k1 * e_ * n_ if _hip.stats["k1_passes"] > 0 else 0))
         result = {
             "metric": "adversarial images/sec (1000-img set, K=10)",
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -393,33 +481,19 @@ def main():
             "config": {"fold_bn": os.environ.get("TA_FOLD_BN", "0") == "1",
                        "images_per_step": args.batch,
                        "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
+                       "hip_graph": bool(args.graph) and bool(getattr(attacker, "graph_replays", 0)),
                        "workload": "%s on %s (seeded random init), eps=16/255, alpha=1.6/255, K=10, synthetic "
-                                   "3x224x224, batches of %d, %s"
+                                   "3x%dx%d, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
-                                      args.batch, layout),
+                                      args.image_size, args.image_size, args.batch, layout),
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "parallelism": layout, "gpus_requested": args.gpus, "ranks_observed": observed_world,
                        "collective_backend": backend, "images_per_s_per_rank": per_rank},
-            "roofline": {"bound": "hbm", "kernel": ("ta_mi_update (mi_update_kernel; |g| tile sums left by the kernel "
-                                                    "that produced g)" if _hip.stats["k1_passes"] == 0 else
-                                                    "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "clock": clock if timing_note is None else clock + " (dispatch clock unavailable: %s)" % timing_note,
-                         "marker_clock": {"mean_us": round(sum(marker_us) / len(marker_us), 2),
-                                          "frac": round(sum(launch_bytes) / sum(marker_us) / 1e3 / HBM_PEAK_GBS, 4)},
-                         "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
-                         "algorithmic_bytes_per_launch": int(mean_bytes),
-                         "steady_state_launch": {"bytes": int(max(launch_bytes)),
-                                                 "mean_us": round(sum(d for d, _ in full) / len(full), 2),
-                                                 "GBps": round(sum(b for _, b in full) / sum(d for d, _ in full) / 1e3, 1)},
-                         "k1_pass_skipped_launches": _hip.stats["partials_reused"],
-                         "k1_passes": _hip.stats["k1_passes"],
-                         "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
+            "roofline": roofline(args, sink, dispatch_ms, timing_note, _hip) if sink else None,
         }
         if kernel_records:
             result["config"]["kernels"] = summarise_kernels(kernel_records)
-        if args.kernel_sweep and world == 1:
+        if on_gpu and args.kernel_sweep and world == 1:
             try:
                 result["config"]["update_kernel_sweep"] = kernel_sweep()
             except Exception as exc:  # noqa: BLE001
@@ -432,8 +506,10 @@ def main():
                                           "sample": "failed: " + repr(exc)[:200]}
         print(json.dumps(result), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

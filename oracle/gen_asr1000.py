@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE -- the end-to-end parity statement of BASELINE.json: attack success rate on the 1000-image set.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_asr1000.py mifgsm          # configs[1]: MI-FGSM on ResNet-50, ~30 min on 8 cores
+    python oracle/gen_asr1000.py dts             # configs[2]: DIM + TIM + SIM on ResNet-50, 5 copies, ~2.5 h
+
+What it does, following /root/reference/main.py line by line with synthetic data in place of the ImageNet subset:
+
+* 1000 seeded synthetic images (``u8_images(1000, 224, seed 0)`` -- what a decoded PNG holds, utils.py:136), in the
+  reference's file-ordered batches of 32 (main.py:15,36: 31 x 32 + 8);
+* label = the surrogate's clean prediction (stands in for labels.csv: the synthetic images have no ground truth);
+* the REAL reference attack class (imported through oracle/ref_shim.py) on the CPU, batch by batch (main.py:43-52),
+  host generators re-seeded per batch with ``SEED_BASE + batch index`` (the reference seeds nothing; a parity run needs
+  the DIM draws of the two paths to be the same);
+* ``save_images``' quantisation (utils.py:64) -> uint8 adversarial images, kept per batch under oracle/_build/asr1000/
+  (scratch, resumable: an interrupted run continues with the next batch);
+* main.py:80-94 for every victim: prediction on the adversarial image vs the label.  Because a seeded random-init victim
+  has no reason to agree with the surrogate's label even on the clean image (the literal rate is 100 % for every victim),
+  the informative statistic is ``victim(adv) != victim(clean)`` -- the reference's ASR restricted to the images the
+  victim classifies "correctly", with the victim's clean prediction as its ground truth.  Both are stored.
+
+Committed fixture (tests/golden/asr1000_<config>.npz, a few KB + the sign bits): labels, every victim's clean and
+adversarial prediction per image, the packed signs of the FIRST-iteration gradient of the first SIGN_IMAGES images.  The
+-m gpu test (tests/test_hip_asr1000.py) runs the product on the same images and compares the rates.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+import fgsm_oracle as O  # noqa: E402
+from transferattack_amd import backbones  # noqa: E402  (surrogate / victim definitions only)
+
+N_IMAGES, BATCH, SEED_BASE, SIGN_IMAGES = 1000, 32, 5000, 16
+SURROGATE = ("resnet50", 0)
+# (name, weight seed): the white-box row, the same architecture with other weights, and six held-out victims
+VICTIMS = (("resnet50", 0), ("resnet50", 1), ("resnet18", 0), ("resnet101", 0), ("vgg16", 0), ("mobilenet_v2", 0),
+           ("inception_v3", 0), ("vit_base_patch16_224", 0))
+SCRATCH = os.path.join(HERE, "_build", "asr1000")
+
+
+def images_u8(n=N_IMAGES):
+    g = torch.Generator().manual_seed(0)
+    return torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8)
+
+
+def predictions(net, x, chunk=50):
+    out = []
+    with torch.no_grad():
+        for i in range(0, len(x), chunk):
+            out.append(O.logits_of(net, x[i:i + chunk]).argmax(1))
+    return torch.cat(out)
+
+
+def make_attack(config, surrogate):
+    if config == "mifgsm":
+        return ref_shim.make_reference_attack("mifgsm", surrogate)
+    if config == "dts":
+        import gen_golden
+        DTS = gen_golden._dts_class()
+        from transferattack.utils import wrap_model
+        DTS.load_model = lambda self, name: wrap_model(surrogate.eval())
+        return DTS(model_name="injected")
+    raise SystemExit("unknown config " + config)
+
+
+def main():
+    config = sys.argv[1] if len(sys.argv) > 1 else "mifgsm"
+    n_images = int(os.environ.get("TA_ASR_IMAGES", N_IMAGES))
+    torch.set_num_threads(int(os.environ.get("TA_ASR_THREADS", "8")))
+    scratch = os.path.join(SCRATCH, config)
+    os.makedirs(scratch, exist_ok=True)
+    xu8 = images_u8()[:n_images]
+    x = xu8.float() / 255
+    surrogate = backbones.create(SURROGATE[0], seed=SURROGATE[1], verbose=False)
+    label_path = os.path.join(SCRATCH, "labels_%d.npy" % n_images)
+    if os.path.isfile(label_path):
+        label = torch.from_numpy(np.load(label_path))
+    else:
+        label = predictions(surrogate, x)
+        np.save(label_path, label.numpy())
+    atk = make_attack(config, surrogate)
+    first_grad = []
+    inner = atk.get_grad
+
+    def get_grad(loss, delta, **kw):
+        g = inner(loss, delta, **kw)
+        if not first_grad:
+            first_grad.append(g.detach().clone())
+        return g
+    atk.get_grad = get_grad
+
+    t0 = time.time()
+    num_batches = (n_images + BATCH - 1) // BATCH
+    for b in range(num_batches):
+        path = os.path.join(scratch, "adv_%03d.npy" % b)
+        if os.path.isfile(path) and (b > 0 or os.path.isfile(os.path.join(scratch, "sign_bits.npy"))):
+            continue
+        lo, hi = b * BATCH, min((b + 1) * BATCH, n_images)
+        torch.manual_seed(SEED_BASE + b)
+        del first_grad[:]
+        delta = atk(x[lo:hi], label[lo:hi])
+        adv = ((x[lo:hi] + delta).permute(0, 2, 3, 1).numpy() * 255).astype(np.uint8)          # utils.py:64
+        if b == 0:
+            g = first_grad[0][:SIGN_IMAGES].numpy()
+            np.save(os.path.join(scratch, "sign_bits.npy"), np.packbits(g > 0))
+            np.save(os.path.join(scratch, "sign_zeros.npy"), np.array([(g == 0).sum()]))
+        np.save(path, adv)
+        print("%s batch %d/%d  %.0f s" % (config, b + 1, num_batches, time.time() - t0), flush=True)
+
+    adv = np.concatenate([np.load(os.path.join(scratch, "adv_%03d.npy" % b)) for b in range(num_batches)])
+    x_adv = torch.from_numpy(adv).permute(0, 3, 1, 2).float() / 255          # what AdvDataset reads back (utils.py:127-137)
+    out = dict(label=label.numpy().astype(np.int16), n_images=n_images, batch=BATCH, seed_images=0, seed_base=SEED_BASE,
+               surrogate="%s:%d" % SURROGATE, victims=np.array(["%s:%d" % v for v in VICTIMS]),
+               sign_images=SIGN_IMAGES, sign_bits=np.load(os.path.join(scratch, "sign_bits.npy")),
+               sign_zeros=np.load(os.path.join(scratch, "sign_zeros.npy")),
+               adv_crc32=np.array([__import__("zlib").crc32(adv.tobytes())], dtype=np.uint32))
+    clean_path = os.path.join(SCRATCH, "clean_pred_%d.npy" % n_images)
+    clean = np.load(clean_path) if os.path.isfile(clean_path) else None
+    if clean is None:
+        clean = np.stack([predictions(backbones.create(m, seed=s, verbose=False), x).numpy() for m, s in VICTIMS])
+        np.save(clean_path, clean)
+    advp = np.stack([predictions(backbones.create(m, seed=s, verbose=False), x_adv).numpy() for m, s in VICTIMS])
+    out["clean_pred"], out["adv_pred"] = clean.astype(np.int16), advp.astype(np.int16)
+    for (m, s), c, a in zip(VICTIMS, clean, advp):
+        print("%-24s seed %d   ASR vs label %.1f %%   ASR vs the victim's clean prediction %.1f %%" % (
+            m, s, 100 * (a != label.numpy()).mean(), 100 * (a != c).mean()))
+    path = os.path.join(ROOT, "tests", "golden", "asr1000_%s.npz" % config if n_images == N_IMAGES
+                        else "asr%d_%s.npz" % (n_images, config))
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

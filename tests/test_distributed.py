@@ -113,6 +113,30 @@ def _rank_ensemble(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _rank_ensemble_bsr(rank, world, port, out):
+    """a transform attack that draws from Python's ``random`` (BSR: axis order, strips, permutations) on a model list:
+    every rank of the group must apply the SAME transform or the all-reduced gradient mixes pixel arrangements"""
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import wrap_model
+    from conftest import u8_images
+    x = u8_images(2, 32, 5).float() / 255
+    y = torch.randint(0, 10, (2,), generator=torch.Generator().manual_seed(6))
+    grp, idx, _, _ = tadist.model_groups(world, 2)
+    import random
+    random.seed(1000 + rank)                                   # whatever state the ranks arrive with, it differs
+    member = wrap_model(backbones.create("toy_cnn", seed=3 + rank, verbose=False).eval())
+    atk = _make("bsr", tadist.ShardedEnsemble(member, grp, 2), model_name=["a", "b"], epoch=2, num_scale=3)
+    tadist.seed_batch(5, 0)
+    delta = atk(x, y)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, delta.numpy())
+    if rank == 0:
+        np.savez(out, r0=gathered[0], r1=gathered[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _rank_members(rank, world, port, out):
     tadist = _setup(rank, world, port)
     from transferattack_amd import backbones
@@ -257,6 +281,35 @@ def test_sharded_ensemble_matches_single_process(tmp_path, monkeypatch):
     ref = _make("ens", models, epoch=4)(x, y).numpy()
     assert float((got["r0"] != ref).mean()) <= 0.002
     assert np.abs(got["r0"] - ref).max() <= 2 * 1.6 / 255 + 1e-7
+
+
+def test_sharded_ensemble_bsr_same_draws_on_every_rank(tmp_path, monkeypatch):
+    """BSR on a two-member list, one member per rank: ``seed_batch`` seeds Python's ``random`` too, so both ranks shuffle
+    the same blocks -> r0 == r1, and equal to the single-process EnsembleModel run up to the rounding of the member sum."""
+    got = _run(_rank_ensemble_bsr, tmp_path)
+    assert np.array_equal(got["r0"], got["r1"])
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones, dist as tadist
+    from conftest import u8_images
+    x = u8_images(2, 32, 5).float() / 255
+    y = torch.randint(0, 10, (2,), generator=torch.Generator().manual_seed(6))
+    models = [backbones.create("toy_cnn", seed=3, verbose=False), backbones.create("toy_cnn", seed=4, verbose=False)]
+    atk = _make("bsr", models, model_name=["a", "b"], epoch=2, num_scale=3)
+    tadist.seed_batch(5, 0)
+    ref = atk(x, y).numpy()
+    assert float((got["r0"] != ref).mean()) <= 0.005
+    # and without the seeding of ``random`` the ranks would have diverged: the draw really comes from that generator
+    import random
+    from transferattack_amd.transforms import bsr_draw
+    tadist.seed_batch(5, 0)
+    a = bsr_draw((2, 3, 32, 32), 3, 3)
+    tadist.seed_batch(5, 0)
+    same = bsr_draw((2, 3, 32, 32), 3, 3)
+    tadist.seed_batch(5, 0)
+    random.seed(78)                                            # torch and numpy as before, ``random`` elsewhere
+    b = bsr_draw((2, 3, 32, 32), 3, 3)
+    assert np.array_equal(a, same) and not np.array_equal(a, b)
 
 
 def test_sharded_members_match_single_process(tmp_path, monkeypatch):

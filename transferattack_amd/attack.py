@@ -21,6 +21,7 @@ tensors must be on a HIP device.
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 
 from . import _hip, backbones
@@ -36,6 +37,7 @@ class _AdvInput(torch.autograd.Function):
         return x_adv.detach()
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         return g, None
 

@@ -20,9 +20,11 @@ The reference is single-process, single-GPU (main.py:31, 43); nothing here has a
   all-reduce, per round) so that M GPUs do the M evaluations side by side.
 """
 import os
+import random
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 import torch.distributed as dist
 import torch.nn as nn
 
@@ -66,10 +68,13 @@ def shard_batches(num_batches, rank, world):
 
 
 def seed_batch(base_seed, batch_idx):
-    """Seed the host generator for one batch; (base_seed, batch_idx) -> the DIM / Admix draws of that batch are the
-    same whichever rank processes it."""
+    """Seed the three host generators the attacks draw from for one batch -- torch (DIM / Admix / SIA), numpy (SVRE /
+    SMER member order) and Python's ``random`` (BSR's shuffles, L2T, OPS: bsr.py:44-60, l2t.py:500, ops.py:137) -- so
+    (base_seed, batch_idx) -> the draws of that batch are the same whichever rank processes it, and all ranks of a model
+    group apply the identical transform."""
     seed = (int(base_seed) * 1000003 + int(batch_idx) * 7919 + 12345) % (2 ** 63 - 1)
     torch.manual_seed(seed)
+    random.seed(seed)
     np.random.seed(seed % (2 ** 32))          # SVRE / SMER draw their member order from numpy (svre.py:75, smer.py:75)
     return seed
 
@@ -99,6 +104,7 @@ class _AllReduceMean(torch.autograd.Function):
         return out / members
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad):
         return grad / ctx.members, None, None
 
@@ -114,6 +120,7 @@ class _SumInputGrad(torch.autograd.Function):
         return x.view_as(x)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad):
         total = grad.contiguous().clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
@@ -167,6 +174,7 @@ class _OwnerCall(torch.autograd.Function):
         return logits
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_logits):
         handle = ctx.handle
         if ctx.own is not None:
@@ -218,6 +226,7 @@ class _GatherLogits(torch.autograd.Function):
         return torch.stack(parts, dim=0)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad):
         leaf, out = ctx.own
         owner = ctx.owner

@@ -11,6 +11,7 @@ FGSRA: gradient/fgsra.py:49-140; both carry the DCT pair of the SSA repository a
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _hip
 
@@ -48,6 +49,7 @@ class _SpectrumPair(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         (mask,) = ctx.saved_tensors
         c, d, ct, dt = dct_matrices(gy.shape[-1], gy.device)

@@ -16,6 +16,7 @@ import struct
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _hip
 
@@ -44,6 +45,7 @@ class DimResizePad(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
@@ -62,6 +64,7 @@ class ScaleCopies(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         gy = gy.contiguous()
         gx = torch.empty(ctx.in_shape, dtype=gy.dtype, device=gy.device)
@@ -80,6 +83,7 @@ class AdmixCopies(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         gy = gy.contiguous()
         gx = torch.empty(ctx.in_shape, dtype=gy.dtype, device=gy.device)
@@ -98,6 +102,7 @@ class LookAhead(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         return g, None, None
 
@@ -113,6 +118,7 @@ class Neighbor(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         return g, None, None, None, None, None
 
@@ -173,6 +179,7 @@ class SiaBlocks(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, plan, noise = ctx.saved_tensors
         copies, num_block, seed, offset = ctx.cfg
@@ -256,6 +263,7 @@ class BsrBlocks(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         (plan,) = ctx.saved_tensors
         copies, num_block, shape = ctx.cfg

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import _hip, backbones
 
@@ -70,6 +71,7 @@ class _NormalizeFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         (std,) = ctx.saved_tensors
         gy = gy.contiguous()
@@ -165,6 +167,7 @@ class _FanOut(torch.autograd.Function):
         return tuple(x.view_as(x) for _ in range(members))
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, *grads):
         if len(grads) == 1:
             return grads[0], None
