@@ -55,6 +55,23 @@ dispatch)
   timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
+philox)
+  mkdir -p tools/bin; [ -x tools/bin/philox_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/philox_rate.hip -o tools/bin/philox_rate
+  timeout 120 tools/bin/philox_rate 2>&1 | tee $OUT/philox_rate.txt ;;
+steady)
+  # what the metric is made of: steady-state kernels of the default bench line.  MIOpen's find-db is warmed by a prior
+  # process (its trial kernels stay out of the trace), then the trace is reduced ON THE BOX (tools/steady_trace.py)
+  B=${TA_STEADY_BATCH:-125}; X=${TA_STEADY_EXTRA:-}
+  timeout 600 python bench.py --steps 1 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 > /dev/null 2>> $OUT/bench.err
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/steady_b$B -o trace -- python $R/bench.py --steps 4 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 > $R/$OUT/steady_b$B.log 2>&1 )
+  tail -1 $OUT/steady_b$B.log
+  python tools/steady_trace.py $OUT/steady_b$B $OUT/steady_state_b$B.json 30 | tee $OUT/steady_state_b$B.txt
+  f=$(find $OUT/steady_b$B -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/steady_state_b${B}_kernel_stats.csv
+  find $OUT/steady_b$B -name "*kernel_trace.csv" -delete; find $OUT/steady_b$B -name "*.db" -delete ;;
+sweep)
+  for b in 32 64 250 500; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+asr)
+  timeout 1500 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr1000_pytest.txt | tail -60 ;;
 rocprof)
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 8 --warmup 2 --cpu-images 0 --kernel-sweep 0 > $R/$OUT/rocprof.log 2>&1 )
   tail -1 $OUT/rocprof.log

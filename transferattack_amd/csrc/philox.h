@@ -5,12 +5,27 @@
 namespace ta {
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter = (lo32(i), hi32(i), lo32(offset), hi32(offset)) ---
+// 32 x 32 -> 64-bit product in ONE instruction (v_mad_u64_u32 with a zero addend) instead of v_mul_lo_u32 + v_mul_hi_u32:
+// integer multiplies are quarter-rate on CDNA, and Philox is forty of them per four outputs
+__device__ __forceinline__ void mul_wide(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TA_PHILOX_MAD64)
+    uint64_t p;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(a), "v"(b) : "vcc");
+    hi = static_cast<uint32_t>(p >> 32);
+    lo = static_cast<uint32_t>(p);
+#else
+    hi = __umulhi(a, b);
+    lo = a * b;
+#endif
+}
+
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        uint32_t hi0, lo0, hi1, lo1;
+        mul_wide(M0, c.x, hi0, lo0);
+        mul_wide(M1, c.z, hi1, lo1);
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += W0;
         k.y += W1;
