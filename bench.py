@@ -63,9 +63,6 @@ def parse(argv=None):
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
     p.add_argument("--kernel-times", type=int, default=0,
                    help="time every HIP kernel call of the loop with events (config.kernels); for the transform attacks")
-    p.add_argument("--graph", type=int, default=0,
-                   help="capture one whole attack iteration (transform, surrogate forward/backward, fused update) in a "
-                        "hipGraph and replay it K times per batch (TA_GRAPH=1; attacks without host-side draws only)")
     # the four flags below exist for tests/test_bench_ranks.py: the multi-rank reporting path (barrier, MAX all-reduce of
     # the time, all-gather of the rates, the sharded-ensemble layout) on gloo / CPU tensors with the kernels' host build
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU tests)")
@@ -418,8 +415,6 @@ def main(argv=None):
 
     os.environ["TA_FOLD_BN"] = "1" if args.fold_bn else "0"
     os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
-    if args.graph:
-        os.environ["TA_GRAPH"] = "1"
     from transferattack_amd import _hip
     _hip.load()
     torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
@@ -481,7 +476,6 @@ def main(argv=None):
             "config": {"fold_bn": os.environ.get("TA_FOLD_BN", "0") == "1",
                        "images_per_step": args.batch,
                        "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
-                       "hip_graph": bool(args.graph) and bool(getattr(attacker, "graph_replays", 0)),
                        "workload": "%s on %s (seeded random init), eps=16/255, alpha=1.6/255, K=10, synthetic "
                                    "3x%dx%d, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,

@@ -6,7 +6,11 @@
 
 Same behaviour as the reference: the hyper-parameter flags --epoch/--eps/--alpha/--momentum/--random_start are
 parsed but, as in the reference (main.py:41), not forwarded -- every attack runs with its class defaults.
-Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches).
+Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches),
+--coalesce K (attacks that treat the images of a batch independently -- transferattack_amd.BATCH_INDEPENDENT -- run K
+reference batches per device batch: the per-image L1 normalisation and the sign step make the result independent of how the
+loss is averaged over the batch, and a 128-image launch uses the GPU better than four 32-image ones; DIM / Admix / ... keep
+the reference's batches), --profile (seconds per pipeline stage at the end).
 Input pipeline: threaded PNG decode -> page-locked staging buffer -> asynchronous upload on a side stream while the previous
 batch runs; output: GPU quantiser -> uint8 download -> threaded PNG encode, also overlapped.  With several processes the
 dataset is sharded by whole batches (transferattack_amd.dist.shard_batches); for ``--attack ens`` every group of
@@ -45,6 +49,9 @@ def get_parser():
     parser.add_argument('--GPU_ID', default='0', type=str)
     parser.add_argument('--seed', default=0, type=int, help='base seed of the per-batch host RNG (DIM / Admix draws)')
     parser.add_argument('--io_threads', default=4, type=int, help='host threads decoding / encoding PNGs')
+    parser.add_argument('--coalesce', default=0, type=int,
+                        help='reference batches per device batch for batch-independent attacks (0 = 4 for those, 1 otherwise)')
+    parser.add_argument('--profile', action='store_true', help='print the busy seconds of every pipeline stage at the end')
     parser.add_argument('--resume', action='store_true',
                         help='skip the batches whose output files all exist already (an interrupted run picks up where it '
                              'stopped; the per-batch seeding makes the remaining batches come out the same)')
@@ -66,12 +73,26 @@ def main():
     device = default_device()
     copy_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
 
+    import threading
+    import time
+    stage_seconds, stage_lock = {}, threading.Lock()
+
+    def spent(stage, t0):
+        with stage_lock:
+            stage_seconds[stage] = stage_seconds.get(stage, 0.0) + time.perf_counter() - t0
+
     def batch(idx):
-        """decode one reference batch on the host threads and start its upload: page-locked staging buffer, asynchronous
-        copy on a side stream (runs under the previous batch's kernels); returns the event the consumer waits for"""
-        lo, hi = idx * args.batchsize, min((idx + 1) * args.batchsize, len(dataset))
-        items = list(decoders.map(dataset.__getitem__, range(lo, hi)))
+        """decode one device batch (``idx``: a reference-batch index or a list of them) on the host threads and start its
+        upload: page-locked staging buffer, asynchronous copy on a side stream (runs under the previous batch's kernels);
+        returns the event the consumer waits for"""
+        t0 = time.perf_counter()
+        wanted = []
+        for i in ([idx] if isinstance(idx, int) else idx):
+            wanted.extend(range(i * args.batchsize, min((i + 1) * args.batchsize, len(dataset))))
+        items = list(decoders.map(dataset.__getitem__, wanted))
         images = torch.stack([it[0] for it in items])
+        spent("decode (PNG -> fp32 NCHW, %d host threads)" % args.io_threads, t0)
+        t0 = time.perf_counter()
         if args.targeted:
             labels = [torch.tensor([it[1][0] for it in items]), torch.tensor([it[1][1] for it in items])]
         else:
@@ -84,6 +105,7 @@ def main():
                 ready = torch.cuda.Event()
                 ready.record(copy_stream)
                 images._ta_staging = staged                                       # keep the pinned buffer until consumed
+        spent("stage + enqueue upload (pinned copy, async H2D)", t0)
         return images, labels, [it[2] for it in items], ready
 
     def consume(loaded):
@@ -120,20 +142,53 @@ def main():
             mine = [idx for idx in mine if not done(idx)]
             if world > 1:                      # every rank decides from the same directory listing before anyone writes
                 torch.distributed.barrier()
+        # device batches: K reference batches at a time where the attack does not couple the images of a batch
+        k = args.coalesce if args.coalesce > 0 else (4 if args.attack in transferattack.BATCH_INDEPENDENT
+                                                     and not isinstance(args.model, list) else 1)
+        if args.attack not in transferattack.BATCH_INDEPENDENT:
+            k = 1
+        groups = [mine[i:i + k] for i in range(0, len(mine), k)]
+
+        def write(images, filenames, perturbations):
+            t0 = time.perf_counter()
+            save_images(args.output_dir, images, filenames, perturbations)
+            spent("quantise on the GPU + download + PNG encode", t0)
+
         io = ThreadPoolExecutor(max_workers=2)
-        pending_write, next_batch = None, io.submit(batch, mine[0]) if mine else None
-        for pos, batch_idx in enumerate(tqdm.tqdm(mine, disable=rank != 0)):
+        attack_events = []
+        wall0 = time.perf_counter()
+        pending_write, next_batch = None, io.submit(batch, groups[0]) if groups else None
+        for pos, group in enumerate(tqdm.tqdm(groups, disable=rank != 0)):
+            t0 = time.perf_counter()
             images, labels, filenames = consume(next_batch.result())
-            if pos + 1 < len(mine):
-                next_batch = io.submit(batch, mine[pos + 1])
-            tadist.seed_batch(args.seed, batch_idx)
+            spent("main thread waits for decode / upload", t0)
+            if pos + 1 < len(groups):
+                next_batch = io.submit(batch, groups[pos + 1])
+            tadist.seed_batch(args.seed, group[0])
+            if args.profile and device.type == "cuda":
+                attack_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                attack_events[-1][0].record()
             perturbations = attacker(images, labels)
+            if args.profile and device.type == "cuda":
+                attack_events[-1][1].record()
+            t0 = time.perf_counter()
             if pending_write is not None:
                 pending_write.result()
+            spent("main thread waits for the previous batch's write", t0)
             if writer:
-                pending_write = io.submit(save_images, args.output_dir, images, filenames, perturbations)
+                pending_write = io.submit(write, images, filenames, perturbations)
         if pending_write is not None:
             pending_write.result()
+        if args.profile and rank == 0:
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+                stage_seconds["attack on the GPU (K iterations; HIP events)"] = sum(a.elapsed_time(b) for a, b in attack_events) / 1e3
+            wall = time.perf_counter() - wall0
+            images_done = sum(min((i + 1) * args.batchsize, len(dataset)) - i * args.batchsize for g in groups for i in g)
+            import json
+            print(json.dumps({"end_to_end_images_per_s": round(images_done / max(wall, 1e-9), 2), "images": images_done,
+                              "wall_s": round(wall, 3), "reference_batches_per_device_batch": k,
+                              "stage_busy_seconds": {k_: round(v, 3) for k_, v in sorted(stage_seconds.items())}}))
     elif rank == 0:
         if not os.environ.get("TA_WEIGHTS_DIR") and os.environ.get("TA_ALLOW_RANDOM_INIT", "0") != "1":
             raise SystemExit("--eval needs the victims' pretrained weights (TA_WEIGHTS_DIR=<dir with <name>.pth>): the attack "

@@ -10,7 +10,6 @@
 // side; `__shared__` arrays are thread_local statics (one workgroup per OS thread at a time).  Only what the csrc
 // kernels use is provided.
 #pragma once
-#define TA_HOST_STANDIN 1
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -36,8 +35,14 @@ typedef void* hipStream_t;
 typedef void* hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
+enum { hipErrorNotSupported = 801 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline const char* hipGetErrorString(hipError_t) { return "host stand-in"; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipErrorNotSupported ? "not supported by the host stand-in" : "host stand-in"; }
+/* there is no device clock here: the launch-timing entry points (ta_timing_begin / ta_timing_end) report an error */
+static inline hipError_t hipEventCreate(hipEvent_t*) { return hipErrorNotSupported; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipErrorNotSupported; }
+static inline hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t) { return hipErrorNotSupported; }
 
 namespace hipcpu {
 struct Idx { unsigned x, y, z; };

@@ -197,10 +197,10 @@ def _write_dataset(root, count):
             w.writerow(["%d.png" % i, i % 10, (i + 1) % 10])
 
 
-def _cli(inp, out, attack, model):
+def _cli(inp, out, attack, model, *extra):
     import main as cli
     sys.argv = ["main.py", "--input_dir", inp, "--output_dir", out, "--attack", attack, "--model", model,
-                "--batchsize", "2", "--seed", "5"]
+                "--batchsize", "2", "--seed", "5"] + list(extra)
     cli.main()
 
 
@@ -433,3 +433,28 @@ def test_sharded_ensemble_distinct_members_at_224(tmp_path, monkeypatch):
         ref = _make(name, models, **kw)(x, y).numpy()
         assert np.array_equal(got[name + "_r0"], got[name + "_r1"]), name
         assert np.array_equal(got[name + "_r0"], ref), name
+
+
+def test_main_cli_coalesced_batches_equal_reference_batches(tmp_path, monkeypatch, capsys):
+    """main.py --coalesce: a batch-independent attack (MI-FGSM) run three reference batches per device batch writes the
+    same PNG bytes as one reference batch at a time -- the per-image normalisation removes the 1/N of the batch-mean loss
+    (a power of two here, so even the rounding is the same); a batch-coupled attack (DIM) is never coalesced."""
+    from PIL import Image
+    import json
+    _write_dataset(str(tmp_path / "data"), 6)
+    import host_kernels
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    lines = {}
+    for tag, extra in (("k1", ["--coalesce", "1", "--profile"]), ("k2", ["--coalesce", "2", "--profile"]), ("auto", ["--profile"])):
+        _cli(str(tmp_path / "data"), str(tmp_path / ("mi_" + tag)), "mifgsm", "toy_cnn", *extra)
+        lines[tag] = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert [lines[t]["reference_batches_per_device_batch"] for t in ("k1", "k2", "auto")] == [1, 2, 4]
+    assert all(lines[t]["images"] == 6 and lines[t]["end_to_end_images_per_s"] > 0 for t in lines)
+    for i in range(6):
+        one = np.array(Image.open(tmp_path / "mi_k1" / ("%d.png" % i)))
+        assert np.array_equal(one, np.array(Image.open(tmp_path / "mi_k2" / ("%d.png" % i)))), i
+    _cli(str(tmp_path / "data"), str(tmp_path / "dim_k4"), "dim", "toy_cnn", "--coalesce", "4", "--profile")
+    line = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert line["reference_batches_per_device_batch"] == 1

@@ -55,6 +55,9 @@ dispatch)
   timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
+e2e)
+  # main.py end to end on 1000 synthetic PNGs: decode -> upload -> attack -> quantise -> download -> encode
+  timeout 900 python tools/e2e_main.py 2> $OUT/e2e_main.err | tee $OUT/e2e_main.jsonl ;;
 philox)
   mkdir -p tools/bin; [ -x tools/bin/philox_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/philox_rate.hip -o tools/bin/philox_rate
   timeout 120 tools/bin/philox_rate 2>&1 | tee $OUT/philox_rate.txt ;;

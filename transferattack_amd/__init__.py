@@ -69,6 +69,12 @@ attack_zoo = {
 }
 
 
+# Attacks whose result for one image does not depend on the other images of its batch (no shared geometry draw, no mixing
+# partner, no batch statistic): the loop normalises the gradient per image (attack.py:124-128) and steps by its sign, so
+# even the 1/N of the batch-mean loss drops out.  main.py may run several reference batches of these per device batch.
+BATCH_INDEPENDENT = frozenset(['fgsm', 'ifgsm', 'mifgsm', 'nifgsm', 'vmifgsm', 'vnifgsm', 'tim', 'sim'])
+
+
 def load_attack_class(attack_name):
     if attack_name not in attack_zoo:
         raise Exception('Unspported attack algorithm {}'.format(attack_name))

@@ -37,7 +37,6 @@ LaunchEvents claim_launch_events() {
     return g_timing_pool[g_timing_claimed++];
 }
 
-#if !defined(TA_HOST_STANDIN)
 static void release_timing_pool() {
     for (LaunchEvents& ev : g_timing_pool) {
         if (ev.start) (void)hipEventDestroy(ev.start);
@@ -47,16 +46,10 @@ static void release_timing_pool() {
     g_timing_claimed = 0;
     g_timing_armed = false;
 }
-#endif
 
 }  // namespace ta
 
 extern "C" int ta_timing_begin(int capacity) {
-#if defined(TA_HOST_STANDIN)
-    (void)capacity;
-    ta::set_error("launch timing needs the device");
-    return TA_EINVAL;
-#else
     TA_REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity %d", capacity);
     std::lock_guard<std::mutex> lock(ta::g_timing_mutex);
     TA_REQUIRE(!ta::g_timing_armed, "launch timing is already armed");
@@ -73,15 +66,9 @@ extern "C" int ta_timing_begin(int capacity) {
     ta::g_timing_claimed = 0;
     ta::g_timing_armed = true;
     return 0;
-#endif
 }
 
 extern "C" int ta_timing_end(float* ms, int capacity, int* count) {
-#if defined(TA_HOST_STANDIN)
-    (void)ms; (void)capacity; (void)count;
-    ta::set_error("launch timing needs the device");
-    return TA_EINVAL;
-#else
     TA_REQUIRE(ms && count && capacity >= 0, "null pointer");
     std::lock_guard<std::mutex> lock(ta::g_timing_mutex);
     TA_REQUIRE(ta::g_timing_armed, "launch timing is not armed");
@@ -98,7 +85,6 @@ extern "C" int ta_timing_end(float* ms, int capacity, int* count) {
         return static_cast<int>(err);
     }
     return 0;
-#endif
 }
 
 extern "C" int ta_abi_version(void) { return TA_ABI_VERSION; }

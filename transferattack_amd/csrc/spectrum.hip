@@ -36,8 +36,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#elif defined(TA_HOST_STANDIN)
-    return hipcpu_mfma_f32_16x16x4(a, b, c);          // tests/hipcpu: the instruction's arithmetic on the host
 #else
     return c;                                         // hipcc's host pass only parses this function
 #endif

@@ -1,9 +1,7 @@
 // Shared helpers for the gfx950 kernels of libta_hip.so (wave64, 256-thread workgroups).
 #pragma once
 #include <hip/hip_runtime.h>
-#if !defined(TA_HOST_STANDIN)
 #include <hip/hip_ext.h>
-#endif
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/ta_hip.h"
@@ -58,10 +56,6 @@ __device__ __forceinline__ float sign_of(float m) {   // torch.sign: NaN -> 0, +
 }  // namespace ta
 
 // a launch that carries timing events when it is the first (start) / last (stop) kernel of a timed call
-#if defined(TA_HOST_STANDIN)
-#define TA_LAUNCH_TIMED(kernel, grid, block, st, ev_start, ev_stop, ...) \
-    hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__)
-#else
 #define TA_LAUNCH_TIMED(kernel, grid, block, st, ev_start, ev_stop, ...)                                 \
     do {                                                                                                 \
         if ((ev_start) != nullptr || (ev_stop) != nullptr)                                               \
@@ -69,7 +63,6 @@ __device__ __forceinline__ float sign_of(float m) {   // torch.sign: NaN -> 0, +
         else                                                                                             \
             hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                 \
     } while (0)
-#endif
 
 #define TA_REQUIRE(cond, ...)                 \
     do {                                      \
