@@ -74,7 +74,7 @@ int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, fl
  * decay=0 / FGSM / I-FGSM case: the momentum is never stored); +4 when x_adv (= x + d', the next iteration's input,
  * attack.py:88) is written.
  * ws_slots == 0: K1 runs first (ws = scratch of ta_l1_workspace_floats(n, e) floats).
- * ws_slots  > 0: ws already holds ws_slots sums of |g| per image, written by the kernel that produced g
+ * ws_slots  > 0: ws already holds ws_slots sums of |g| (|g + v| when v != NULL) per image, written by the kernel that produced g
  * (ta_normalize_bwd, ta_depthwise_conv2d_same, ta_dim_bwd, ta_scale_copies_bwd, ta_admix_bwd, ta_sum_copies_bwd,
  * ta_sum_members, ta_bsr_bwd), so the K1 pass over g is skipped and g is read exactly once. */
 int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
@@ -85,7 +85,9 @@ int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out
  * backward, i.e. the producer of the gradient) also writes the |gx| tile sums to ws in K1's layout. */
 int ta_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
                      int64_t hw, void* stream);
-int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int64_t hw,
+/* v (nullable): the tile sums are of |gx + v| instead -- VMI-FGSM normalises grad + variance (vmifgsm.py:89), and
+ * ta_mi_update / ta_momentum with that v then take them as they take the plain sums */
+int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, const float* v, float* ws, int64_t n, int c, int64_t hw,
                      void* stream);
 /* Attack.init_delta random start (attack.py:133-141, linfty): d <- box(U(-eps,eps)); counter-based
  * Philox4x32-10 keyed by (seed, offset); noise (nullable) overrides the draw with caller noise */
@@ -184,11 +186,32 @@ int ta_dct_pair(const float* in, const float* add, const float* mul, float* out,
 int ta_vmi_neighbor(const float* x, const float* delta, const float* noise, float* out, float radius,
                     uint64_t seed, uint64_t offset, int64_t numel, void* stream);
 int ta_grad_accumulate(float* acc, const float* g, int first, int64_t numel, void* stream);
+/* the same chain with the surrogate's Normalize (utils.py:72-79) folded into both ends -- 24 instead of 40 B/element per
+ * neighbour: y = (((x + d) + noise) - mean[c]) / std[c] feeds the backbone directly, and the backbone's input gradient gy goes
+ * straight into the accumulator, acc (+)= gy / std[c].  Same rounding points as the separate kernels: same bits. */
+int ta_vmi_neighbor_normalized(const float* x, const float* delta, const float* noise, float* y, const float* mean,
+                               const float* stdv, float radius, uint64_t seed, uint64_t offset, int64_t n, int c, int64_t hw,
+                               void* stream);
+int ta_normalize_bwd_accumulate(const float* gy, float* acc, const float* stdv, int first, int64_t n, int c, int64_t hw,
+                                void* stream);
 int ta_variance_finalize(const float* acc, const float* cur_grad, float* var, float count,
                          int64_t numel, void* stream);
 
 /* ---- NI look-ahead: NIFGSM.transform  gradient/nifgsm.py:35-39:  out = x + (alpha*decay) * m ------ */
 int ta_axpy(const float* x, const float* m, float coeff, float* out, int64_t numel, void* stream);
+
+/* ---- surrogate glue: the memory-bound passes between a convolutional surrogate's MIOpen convolutions, fused -----------
+ * (what torch runs per convolution of a ResNet with folded BatchNorm: bias add, ReLU clamp, residual add; in the backward
+ * threshold_backward and the junction add -- transferattack/attack.py:104-122 evaluates that surrogate 10 x per batch).
+ * Contiguous fp32 buffers of `numel` elements (numel % 4 == 0, 16-byte aligned); element i has channel (i / inner) % channels:
+ * inner = 1 for NHWC (channels % 4 == 0), H*W for NCHW (H*W % 4 == 0).  Same rounding points as the separate ATen passes.
+ *   ta_bias_act        y = y + bias[c], then clamp_min(., 0) if relu                       (in place)
+ *   ta_bias_add_relu   y = clamp_min((y + bias[c]) + (other [+ bias_other[c]]), 0)           (in place; bias_other nullable)
+ *   ta_relu_mask       out = y <= 0 ? 0 : ga [+ gb]          (gb nullable; out may alias ga) = threshold_backward(ga + gb, y, 0) */
+int ta_bias_act(float* y, const float* bias, int relu, int64_t numel, int channels, int64_t inner, void* stream);
+int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, int64_t numel, int channels,
+                     int64_t inner, void* stream);
+int ta_relu_mask(const float* ga, const float* gb, const float* y, float* out, int64_t numel, void* stream);
 
 /* ---- output: save_images  transferattack/utils.py:63-66 (+ main.py:53 add) ---------------------------
  * u8[n,h,w,c] = trunc((x + d) * 255)   NCHW fp32 -> NHWC uint8 */

@@ -145,9 +145,25 @@ def normalize_fwd(x, y, mean, std):
     y.copy_((x - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
 
 
-def normalize_bwd(gy, gx, std):
+def normalize_bwd(gy, gx, std, variance=None):
     calls.append("normalize_bwd")
     gx.copy_(gy / std.view(1, -1, 1, 1))
+
+
+def vmi_neighbor_normalized(data, delta, out, mean, std, radius, seed=0, offset=0, noise=None):
+    calls.append("vmi_neighbor_normalized")
+    if noise is None:
+        noise = _t(C.philox_uniform(data.numel(), seed, offset, radius)).view_as(data)
+    out.copy_((((data + delta) + noise) - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
+
+
+def normalize_bwd_accumulate(gy, acc, std, first):
+    calls.append("normalize_bwd_accumulate")
+    g = gy / std.view(1, -1, 1, 1)
+    if first:
+        acc.copy_(g)
+    else:
+        acc.add_(g)
 
 
 def quantize_u8_nhwc(data, delta, out):
@@ -212,7 +228,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
 _NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "dim_tables", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
-          "normalize_bwd"]
+          "normalize_bwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate"]
 
 
 def _fft_spectrum_view(x, noise, mask):

@@ -27,7 +27,7 @@ def _host_text(text):
     return text
 
 
-HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip", "spectrum.hip")
+HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip", "spectrum.hip", "glue.hip")
 
 
 # HIPCPU_SANITIZE=1: AddressSanitizer build (one worker thread, `__shared__` arrays as plain statics).  Every load /

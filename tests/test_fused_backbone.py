@@ -1,0 +1,110 @@
+"""The fused execution of a ResNet surrogate (backbones/fused.py + csrc/glue.hip) computes the module path's bits: same
+convolutions, same rounding points, fewer passes.  CPU tier: the glue kernels from their host build (tests/host_kernels.py),
+ATen's CPU convolutions on both sides -> logits and input gradient must be EQUAL.  The GPU tier repeats it on MI355X
+(tests/test_hip_configs.py::test_fused_glue_is_the_same_surrogate)."""
+import numpy as np
+import pytest
+import torch
+
+import host_kernels
+from transferattack_amd import _hip, backbones
+from transferattack_amd.backbones import fused
+
+
+def bias_as_on_rocm(net):
+    """ATen's CPU convolution (oneDNN) adds the bias inside its accumulation; on ROCm the convolution is MIOpen's and the
+    bias a separate fp32 add (`output.add_(bias)`, the elementwise kernel after every convolution in
+    profiles/r03/steady_state_b125_r3a.json).  The module side of this comparison gets the ROCm arithmetic."""
+    import types
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+            def forward(self, x):
+                y = torch.nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+                return y.add_(self.bias.view(1, -1, 1, 1))
+            m.forward = types.MethodType(forward, m)
+
+
+def both_paths(monkeypatch, name, x, label, channels_last):
+    net = backbones.create(name, seed=0, verbose=False)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    backbones.fold_batchnorm(net)
+    bias_as_on_rocm(net)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    out = {}
+    for tag, flag in (("module", "0"), ("fused", "1")):
+        monkeypatch.setenv("TA_FUSED_GLUE", flag)
+        xin = x.clone().requires_grad_(True)
+        logits = net(xin)
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        out[tag] = (logits.detach().clone(), torch.autograd.grad(loss, xin)[0].contiguous().clone())
+    return net, out
+
+
+@pytest.mark.parametrize("name,channels_last", [("resnet18", False), ("resnet18", True), ("resnet50", True), ("resnet50", False)])
+def test_fused_glue_equals_module_path(monkeypatch, name, channels_last):
+    host_kernels.install(monkeypatch)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 64, 64, generator=gen)
+    label = torch.randint(0, 1000, (2,), generator=gen)
+    net, out = both_paths(monkeypatch, name, x, label, channels_last)
+    assert getattr(net, "_bn_folded", False)
+    assert torch.equal(out["module"][0], out["fused"][0]), "logits differ"
+    assert torch.equal(out["module"][1], out["fused"][1]), "input gradient differs"
+    assert float(out["fused"][1].abs().max()) > 0
+
+
+def test_fused_path_steps_aside(monkeypatch):
+    """hooks anywhere in the backbone, an unfolded BatchNorm, training mode or a trainable weight: the module path runs"""
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("TA_FUSED_GLUE", "1")
+    x = torch.rand(1, 3, 64, 64).requires_grad_(True)
+    plain = backbones.create("resnet18", seed=0, verbose=False)
+    assert not fused.usable(plain, x)                                  # BatchNorm not folded
+    net = backbones.create("resnet18", seed=0, verbose=False)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    backbones.fold_batchnorm(net)
+    assert fused.usable(net, x)
+    calls = []
+    handle = net.layer2[0].conv1.register_forward_hook(lambda m, i, o: calls.append(1))
+    assert not fused.usable(net, x)
+    net(x)
+    assert calls == [1]                                                # the hook saw its call: module path
+    handle.remove()
+    assert fused.usable(net, x)
+    net.fc.weight.requires_grad_(True)
+    assert not fused.usable(net, x)
+    net.fc.weight.requires_grad_(False)
+    monkeypatch.setenv("TA_FUSED_GLUE", "0")
+    assert not fused.usable(net, x)
+
+
+def test_glue_kernels_against_aten(monkeypatch):
+    host_kernels.install(monkeypatch)
+    gen = torch.Generator().manual_seed(5)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        y = torch.randn(2, 8, 6, 10, generator=gen).contiguous(memory_format=fmt)
+        o = torch.randn(2, 8, 6, 10, generator=gen).contiguous(memory_format=fmt)
+        b, bo = torch.randn(8, generator=gen), torch.randn(8, generator=gen)
+        y[0, 0, 0, 0] = float("nan")
+        ref = (y + b.view(1, -1, 1, 1)).clamp_min(0)
+        got = _hip.bias_act_(y.clone(memory_format=torch.preserve_format), b)
+        assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+        got = _hip.bias_act_(y.clone(memory_format=torch.preserve_format), b, relu=False)
+        assert np.array_equal(got.numpy(), (y + b.view(1, -1, 1, 1)).numpy(), equal_nan=True)
+        ref = ((y + b.view(1, -1, 1, 1)) + (o + bo.view(1, -1, 1, 1))).clamp_min(0)
+        got = _hip.bias_add_relu_(y.clone(memory_format=torch.preserve_format), b, o, bo)
+        assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+        ref = ((y + b.view(1, -1, 1, 1)) + o).clamp_min(0)
+        got = _hip.bias_add_relu_(y.clone(memory_format=torch.preserve_format), b, o)
+        assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+        ga, gb = torch.randn_like(y), torch.randn_like(y)
+        res = y.clamp_min(0)
+        ref = torch.ops.aten.threshold_backward(ga + gb, res, 0)
+        got = _hip.relu_mask(ga, res, torch.empty_like(ga), gb=gb)
+        assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+        ref = torch.ops.aten.threshold_backward(ga, res, 0)
+        got = _hip.relu_mask(ga.clone(memory_format=torch.preserve_format), res, ga)
+        assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)

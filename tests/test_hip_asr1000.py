@@ -8,12 +8,18 @@ applied to its output on the device.
 
 Bit equality of the images is unattainable end to end (a random-init ReLU network's fp32 input gradient differs between
 ANY two machines by ~1e-2, and the sign step amplifies that: DESIGN.md section 4), so the statement that can hold -- and
-the one north_star asks for -- is equality of the attack success rate within the sampling error of 1000 images:
+the one north_star asks for -- is equality of the attack success rate within the sampling error of 1000 images.  Both
+paths attack the SAME images, so the right statistic is the paired one (McNemar): with b / c the images only one of the
+two paths fools,
 
-    |ASR_gpu - ASR_ref| <= 3 * sqrt(p (1 - p) / n)            per victim (p pooled; floor of 3 images when p is 0 or 1)
+    z = |b - c| / sqrt(b + c)        asserted:  z <= 3.5   (and |ASR_gpu - ASR_ref| <= 3 images when b + c < 9)
 
-plus agreement of the FIRST-iteration gradient sign with the reference's (>= 99 %: the inputs of both surrogates are
-identical there, whatever happens later).  ASR is counted two ways (gen_asr1000.py's docstring): against the label the
+3.5 rather than 3 because 8 victims x 2 definitions x 3 runs are tested at once (Bonferroni: 1 % false alarms overall).
+The review's unpaired bound 3 * sqrt(p (1 - p) / n) is printed beside it: the trajectories of the two paths decorrelate
+(78 % of the pixels differ), so which individual images fall differs in ~2 p (1 - p) n cases and that bound is only ~2.1
+standard deviations of the difference -- a correct implementation would trip it in 1 of 30 comparisons.  (r3a: every one
+of the 32 comparisons also met it.)  Plus agreement of the FIRST-iteration gradient sign with the reference's (>= 99 %:
+the inputs of both surrogates are identical there, whatever happens later).  ASR is counted two ways (gen_asr1000.py's docstring): against the label the
 attack used (main.py:90 literally) and against the victim's own clean prediction (the informative one for seeded victims).
 """
 import os
@@ -110,18 +116,22 @@ def check_rates(config, tag, g, x, label, adv):
                                              ("vs clean prediction", adv_gpu != clean_gpu, adv_ref != clean_ref)):
             p_gpu, p_ref = fooled_gpu.mean(), fooled_ref.mean()
             p = 0.5 * (p_gpu + p_ref)
-            bound = max(3 * np.sqrt(p * (1 - p) / n), 3.0 / n)
+            bound = max(3 * np.sqrt(p * (1 - p) / n), 3.0 / n)                       # the unpaired bound, reported
             only_gpu, only_ref = int((fooled_gpu & ~fooled_ref).sum()), int((~fooled_gpu & fooled_ref).sum())
-            rows.append((name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, float((clean_gpu == clean_ref).mean())))
-            worst = max(worst, abs(p_gpu - p_ref) / bound)
+            z = abs(only_gpu - only_ref) / np.sqrt(only_gpu + only_ref) if only_gpu + only_ref >= 9 else 0.0
+            rows.append((name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, float((clean_gpu == clean_ref).mean()), z))
+            worst = max(worst, z)
     print("\n%s [%s], %d images: attack success rate, reference (CPU) vs product (MI355X)" % (config, tag, n))
-    for name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, same_clean in rows:
-        print("  %-26s %-20s ref %6.2f %%   gpu %6.2f %%   |diff| %5.2f <= %5.2f   discordant images %d / %d   "
-              "clean predictions equal %.1f %%" % (name, kind, 100 * p_ref, 100 * p_gpu, 100 * abs(p_gpu - p_ref),
-                                                   100 * bound, only_gpu, only_ref, 100 * same_clean))
-    for name, kind, p_ref, p_gpu, bound, *_ in rows:
-        assert abs(p_gpu - p_ref) <= bound, "%s %s: ASR %.2f %% on the GPU vs %.2f %% by the reference" % (
-            name, kind, 100 * p_gpu, 100 * p_ref)
+    for name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, same_clean, z in rows:
+        print("  %-26s %-20s ref %6.2f %%   gpu %6.2f %%   |diff| %5.2f (unpaired 3-sigma bound %5.2f: %s)   discordant "
+              "images %d / %d   paired z %.2f   clean predictions equal %.1f %%"
+              % (name, kind, 100 * p_ref, 100 * p_gpu, 100 * abs(p_gpu - p_ref), 100 * bound,
+                 "met" if abs(p_gpu - p_ref) <= bound else "EXCEEDED", only_gpu, only_ref, z, 100 * same_clean))
+    for name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, same_clean, z in rows:
+        assert z <= 3.5, "%s %s: ASR %.2f %% on the GPU vs %.2f %% by the reference (paired z = %.2f)" % (
+            name, kind, 100 * p_gpu, 100 * p_ref, z)
+        if only_gpu + only_ref < 9:
+            assert abs(only_gpu - only_ref) <= 3, (name, kind, only_gpu, only_ref)
     return rows
 
 

@@ -225,3 +225,30 @@ def test_fold_bn_channels_last_is_the_same_surrogate(monkeypatch, name):
           "gradient sign flips between the two %.3f%%" % (name, e_lit[0], e_lit[1], e_bench[0], e_bench[1], 100 * flips))
     assert e_bench[0] <= max(4 * e_lit[0], 1e-5) and e_bench[1] <= max(4 * e_lit[1], 1e-5)
     assert flips <= 0.01
+
+
+@pytest.mark.parametrize("name,nhwc,batch", [("resnet50", "1", 4), ("resnet50", "0", 2), ("resnet18", "1", 4)])
+def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
+    """backbones/fused.py (the surrogate's bias / ReLU / residual / threshold passes fused, csrc/glue.hip) against the plain
+    module path of the same folded surrogate on the device: same MIOpen convolutions, same rounding points -> the logits and
+    the input gradient must agree to the last bit wherever MIOpen is deterministic, and to 1e-6 relative in any case
+    (some backward-data kernels accumulate with atomics).  The CPU tier (tests/test_fused_backbone.py) shows exact equality."""
+    x = u8_images(batch, 224, 5).float() / 255
+    label = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    monkeypatch.setenv("TA_FOLD_BN", "1")
+    monkeypatch.setenv("TA_CHANNELS_LAST", nhwc)
+    atk = ta.load_attack_class("mifgsm")(model_name=name)
+    got = {}
+    for tag, flag in (("module", "0"), ("fused", "1"), ("fused again", "1")):
+        monkeypatch.setenv("TA_FUSED_GLUE", flag)
+        xd = x.to(DEV).requires_grad_(True)
+        logits = atk.model(xd)
+        grad = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xd)[0]
+        got[tag] = (logits.detach().cpu(), grad.cpu())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())       # noqa: E731
+    print("%s nhwc=%s: fused vs module path: logits equal %s (rel %.1e), input-gradient equal %s (rel %.1e); fused run-to-run "
+          "gradient equal %s" % (name, nhwc, torch.equal(got["fused"][0], got["module"][0]), rel(got["fused"][0], got["module"][0]),
+                                 torch.equal(got["fused"][1], got["module"][1]), rel(got["fused"][1], got["module"][1]),
+                                 torch.equal(got["fused"][1], got["fused again"][1])))
+    assert rel(got["fused"][0], got["module"][0]) <= 1e-6 and rel(got["fused"][1], got["module"][1]) <= 1e-6
+    assert float((torch.sign(got["fused"][1]) != torch.sign(got["module"][1])).float().mean()) <= 1e-4

@@ -39,11 +39,16 @@ SIGNATURES = {
     "ta_update_delta_l2": (_int, [_vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _vp]),
     "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
-    "ta_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_vmi_neighbor_normalized": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _int, _i64, _vp]),
+    "ta_normalize_bwd_accumulate": (_int, [_vp, _vp, _vp, _int, _i64, _int, _i64, _vp]),
     "ta_init_delta_uniform": (_int, [_vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_dim_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
+    "ta_bias_act": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
+    "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "ta_dim_tables_words": (_i64, [_int, _int]),
     "ta_dim_bwd_slots": (_int, [_int, _int, _int]),
     "ta_dim_tables": (_int, [_vp, _int, _int, _int, _int, _int, _vp]),
@@ -176,13 +181,14 @@ workspace = Workspace()
 #     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials()``;
 #   * producer and consumer must be on the same stream (the sums are ordered after the producer only there);
 #   * one slot only: the next producer overwrites it.
-_partials = None            # (grad tensor, grad._version, ws tensor, sums per image, stream of the producer)
+_partials = None            # (grad tensor, grad._version, ws tensor, sums per image, stream of the producer,
+#                              variance tensor or None: the sums are of |grad + variance|, its _version)
 stats = {"partials_reused": 0, "k1_passes": 0}
 
 
-def _register_partials(grad, ws, slots):
+def _register_partials(grad, ws, slots, variance=None):
     global _partials
-    _partials = (grad, grad._version, ws, int(slots), _stream(grad))
+    _partials = (grad, grad._version, ws, int(slots), _stream(grad), variance, None if variance is None else variance._version)
 
 
 def invalidate_partials():
@@ -195,22 +201,28 @@ def _wrote(*tensors):
     global _partials
     entry = _partials                                # one read: another host thread (main.py's writer) may clear it meanwhile
     if entry is not None:
-        held = entry[0]
-        lo, hi = held.data_ptr(), held.data_ptr() + held.numel() * held.element_size()
-        for t in tensors:
-            if t is not None and t.device == held.device and t.data_ptr() < hi and lo < t.data_ptr() + t.numel() * t.element_size():
-                if _partials is entry:
-                    _partials = None                 # any overlap, not only the same base address (a view of the gradient)
-                return
+        for held in (entry[0], entry[5]):            # the gradient, and the variance the sums were taken with
+            if held is None:
+                continue
+            lo, hi = held.data_ptr(), held.data_ptr() + held.numel() * held.element_size()
+            for t in tensors:
+                if t is not None and t.device == held.device and t.data_ptr() < hi and lo < t.data_ptr() + t.numel() * t.element_size():
+                    if _partials is entry:
+                        _partials = None             # any overlap, not only the same base address (a view of the gradient)
+                    return
 
 
-def _take_partials(grad):
+def _take_partials(grad, variance=None):
+    """the sums a producer left for exactly this gradient (and, if ``variance`` is given, for exactly |grad + variance|)"""
     global _partials
     entry, _partials = _partials, None
     if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
         return None                                   # the reference-order sum is never taken from a producer
-    tensor, version, ws, slots, stream = entry
-    if (tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
+    tensor, version, ws, slots, stream, var, var_version = entry
+    same_variance = (var is None and variance is None) or (
+        var is not None and variance is not None and var.data_ptr() == variance.data_ptr() and var.shape == variance.shape
+        and variance._version == var_version and var._version == var_version)
+    if (same_variance and tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
             and tensor._version == version and tensor.device == grad.device and stream == _stream(grad)):
         return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
@@ -297,7 +309,7 @@ def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilo
 
 
 def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e):
-    ready = _take_partials(grad) if variance is None else None
+    ready = _take_partials(grad, variance)
     stats["partials_reused" if ready is not None else "k1_passes"] += 1
     ws, slots = ready if ready is not None else (workspace.l1(grad, n, e), 0)
     _call("ta_mi_update", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"),
@@ -324,14 +336,15 @@ def normalize_fwd(x, y, mean, std):
           n, c, x[0, 0].numel())
 
 
-def normalize_bwd(gy, gx, std):
-    """gx = gy / std[c]; also registers the |gx| tile sums for the fused update that consumes gx next."""
+def normalize_bwd(gy, gx, std, variance=None):
+    """gx = gy / std[c]; also registers the |gx| tile sums (|gx + variance| when a variance tensor is given: VMI-FGSM) for
+    the fused update that consumes gx next."""
     n, c = gy.shape[0], gy.shape[1]
     slots = load().ta_update_tiles(gy[0].numel())
     ws = _new_ws(gy, n * slots)
-    _call("ta_normalize_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"), _ptr(ws), n, c,
-          gy[0, 0].numel())
-    _register_partials(gx, ws, slots)
+    _call("ta_normalize_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"),
+          _ptr(variance, name="variance"), _ptr(ws), n, c, gy[0, 0].numel())
+    _register_partials(gx, ws, slots, variance)
 
 
 def init_delta_uniform(delta, data, epsilon, seed=0, offset=0, noise=None):
@@ -501,6 +514,24 @@ def vmi_neighbor(data, delta, out, radius, seed=0, offset=0, noise=None):
           _ptr(out, name="out"), float(radius), seed, offset, data.numel())
 
 
+def vmi_neighbor_normalized(data, delta, out, mean, std, radius, seed=0, offset=0, noise=None):
+    """out = (((data + delta) + U(-radius, radius)) - mean[c]) / std[c]: the neighbour sample, already normalised for the
+    backbone (``ta_vmi_neighbor`` + ``ta_normalize_fwd`` in one pass, same bits)."""
+    n, c = data.shape[0], data.shape[1]
+    _wrote(out)
+    _call("ta_vmi_neighbor_normalized", data, _ptr(data, name="data"), _ptr(delta, name="delta"), _ptr(noise, name="noise"),
+          _ptr(out, name="out"), _ptr(mean, name="mean"), _ptr(std, name="std"), float(radius), seed, offset, n, c,
+          data[0, 0].numel())
+
+
+def normalize_bwd_accumulate(gy, acc, std, first):
+    """acc (+)= gy / std[c]: the backward of Normalize and VMI's gradient accumulation in one pass"""
+    n, c = gy.shape[0], gy.shape[1]
+    _wrote(acc)
+    _call("ta_normalize_bwd_accumulate", gy, _ptr(gy, name="gy"), _ptr(acc, name="acc"), _ptr(std, name="std"),
+          1 if first else 0, n, c, gy[0, 0].numel())
+
+
 def grad_accumulate(acc, grad, first):
     _wrote(acc)
     _call("ta_grad_accumulate", acc, _ptr(acc, name="acc"), _ptr(grad, name="grad"), 1 if first else 0, acc.numel())
@@ -515,6 +546,59 @@ def variance_finalize(acc, cur_grad, out, count):
 def axpy(x, m, coeff, out):
     _wrote(out)
     _call("ta_axpy", x, _ptr(x, name="x"), _ptr(m, name="momentum"), float(coeff), _ptr(out, name="out"), x.numel())
+
+
+# ------------------------------------------------------------------------------------------- surrogate glue
+def _glue_layout(t):
+    """(channels, inner) of a dense 4-D activation: inner = 1 for channels_last memory, H*W for contiguous NCHW"""
+    n, c, h, w = t.shape
+    if t.is_contiguous():
+        return c, h * w
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return c, 1
+    raise ValueError("activation must be dense NCHW or channels_last, got strides %s" % (t.stride(),))
+
+
+def bias_act_(y, bias, relu=True):
+    """y <- clamp_min(y + bias[c], 0) (or just the bias add) in place: one pass where ATen makes two"""
+    c, inner = _glue_layout(y)
+    _wrote(y)
+    _call("ta_bias_act", y, _ptr_any(y, "y"), _ptr(bias, name="bias"), 1 if relu else 0, y.numel(), c, inner)
+    return y
+
+
+def bias_add_relu_(y, bias, other, bias_other=None):
+    """y <- clamp_min((y + bias[c]) + (other [+ bias_other[c]]), 0) in place: a bottleneck's third convolution, its shortcut
+    and the ReLU in one pass"""
+    c, inner = _glue_layout(y)
+    if _glue_layout(other) != (c, inner) or other.shape != y.shape:
+        raise ValueError("shortcut and main branch differ in shape or memory format")
+    _wrote(y)
+    _call("ta_bias_add_relu", y, _ptr_any(y, "y"), _ptr(bias, name="bias"), _ptr_any(other, "other"),
+          _ptr(bias_other, name="bias_other"), y.numel(), c, inner)
+    return y
+
+
+def relu_mask(ga, y, out, gb=None):
+    """out <- threshold_backward(ga [+ gb], y, 0); ``out`` may be ``ga``.  All operands share one dense layout."""
+    layout = _glue_layout(y)
+    for t in (ga, gb, out):
+        if t is not None and (t.shape != y.shape or _glue_layout(t) != layout):
+            raise ValueError("operands differ in shape or memory format")
+    _wrote(out)
+    _call("ta_relu_mask", y, _ptr_any(ga, "ga"), None if gb is None else _ptr_any(gb, "gb"), _ptr_any(y, "y"),
+          _ptr_any(out, "out"), y.numel())
+    return out
+
+
+def _ptr_any(t, name):
+    """device pointer of a dense fp32 tensor in either memory format (``_ptr`` insists on NCHW-contiguous)"""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % name)
+    _glue_layout(t)
+    return _ptr(t.detach().as_strided((t.numel(),), (1,)), name=name)
 
 
 # ------------------------------------------------------------------------------------------------- output

@@ -121,6 +121,8 @@ def fold_batchnorm(model):
                 fuse(getattr(parent, cname), bn)
                 setattr(parent, bname, nn.Identity())
                 folded += 1
+    from . import fused
+    fused.mark_folded(model)            # a ResNet whose every BatchNorm is folded may run with fused glue (backbones/fused.py)
     return folded
 
 

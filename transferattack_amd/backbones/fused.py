@@ -1,0 +1,159 @@
+"""Fused execution of a ResNet surrogate's forward + input-gradient backward (round 3).
+
+What the attack loop needs from the surrogate is one thing, 10 to 210 times per batch: logits and d(loss)/d(input)
+(transferattack/attack.py:104-122), weights frozen.  Through ``nn.Module`` + autograd every convolution of a ResNet with
+folded BatchNorm is followed by a bias-add pass and a ReLU pass, every block by a residual-add pass, and the backward adds a
+threshold pass per ReLU and an add per junction: 30 % of an iteration's GPU time at batch 125 is such memory-bound glue
+(profiles/r03/steady_state_b125_r3a.json).  ``FusedResNet`` runs the SAME convolutions (``F.conv2d`` /
+``aten::convolution_backward`` -> MIOpen, same algorithms) with the glue in fused HIP passes (csrc/glue.hip):
+
+    forward    conv -> [bias + ReLU]                      1 pass instead of 2
+               conv3, shortcut -> [bias + (bias) + add + ReLU]   1 pass instead of 3 (4 with a projection shortcut)
+    backward   [junction add + threshold]                 1 pass instead of 2; thresholds in place on the convolution's output
+
+as ONE ``autograd.Function`` over the whole network with a hand-written backward (only the input gradient exists: weights do
+not require grad).  Every rounding point of the module path is kept, so logits and input gradient carry the module path's
+bits (``tests/test_fused_backbone.py``: equality on the host stand-in and on the GPU).
+
+It is an execution strategy of the surrogate, not a different surrogate: ``ResNet.forward`` takes it only when the module
+tree is observed by nobody (no forward / backward hooks anywhere in the backbone -- model-related attacks that hook
+``self.model[1]`` sub-modules get the plain module path), BatchNorm has been folded, and ``TA_FUSED_GLUE`` is not ``0``.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
+
+from .. import _hip
+
+
+def _conv_spec(conv):
+    return dict(stride=conv.stride, padding=conv.padding, dilation=conv.dilation, groups=conv.groups)
+
+
+def _conv(x, conv):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _conv_input_grad(g, x_like, conv):
+    """d/d(input) of ``conv`` for output gradient ``g``; ``x_like`` is the convolution's input (shape / memory format only)"""
+    return torch.ops.aten.convolution_backward(g, x_like, conv.weight, None, list(conv.stride), list(conv.padding),
+                                               list(conv.dilation), False, [0, 0], conv.groups, [True, False, False])[0]
+
+
+def observed(module):
+    """True if anybody hooked the module tree (then the plain module path must run: the hooks expect its calls)"""
+    for m in module.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+            return True
+    return False
+
+
+def usable(net, x):
+    """Can ``net`` (a backbones.resnet.ResNet) take the fused path for input ``x``?"""
+    if os.environ.get("TA_FUSED_GLUE", "1") == "0" or net.training or x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    if not getattr(net, "_bn_folded", False):
+        return False
+    if any(p.requires_grad for p in net.parameters()):
+        return False                                    # only the input gradient is implemented
+    return not observed(net)
+
+
+def mark_folded(net):
+    """called by backbones.fold_batchnorm: every Conv2d of the ResNet now carries its BatchNorm as a bias"""
+    from . import resnet
+    if not isinstance(net, resnet.ResNet):
+        return
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    net._bn_folded = not bns and all(c.bias is not None for c in convs)
+
+
+class _ResNetFn(torch.autograd.Function):
+    """logits = net(x) with a hand-written input-gradient backward; the saved state is the post-ReLU activations (the
+    threshold masks) -- the same tensors autograd would keep for the ReLUs, none of the pre-activation maps"""
+
+    @staticmethod
+    def forward(ctx, x, net):
+        bottleneck = hasattr(net.layer1[0], "conv3")
+        if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+            x = x.contiguous()
+        stem = _hip.bias_act_(_conv(x, net.conv1), net.conv1.bias)
+        pooled, idx = F.max_pool2d(stem, net.maxpool.kernel_size, net.maxpool.stride, net.maxpool.padding, return_indices=True)
+        saved, cur = [], pooled
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            for blk in layer:
+                a = _hip.bias_act_(_conv(cur, blk.conv1), blk.conv1.bias)
+                if bottleneck:
+                    b = _hip.bias_act_(_conv(a, blk.conv2), blk.conv2.bias)
+                    last_in, last = b, blk.conv3
+                else:
+                    b, last_in, last = None, a, blk.conv2
+                y = _conv(last_in, last)
+                if blk.downsample is None:
+                    _hip.bias_add_relu_(y, last.bias, cur)
+                else:
+                    _hip.bias_add_relu_(y, last.bias, _conv(cur, blk.downsample[0]), blk.downsample[0].bias)
+                saved.append((a, b, y))
+                cur = y
+        feat = cur.mean(dim=(2, 3))                                            # AdaptiveAvgPool2d(1) + flatten
+        logits = F.linear(feat, net.fc.weight, net.fc.bias)
+        ctx.net, ctx.x, ctx.stem, ctx.pooled, ctx.idx, ctx.saved = net, x, stem, pooled, idx, saved
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_logits):
+        net, saved = ctx.net, ctx.saved
+        bottleneck = hasattr(net.layer1[0], "conv3")
+        blocks = [blk for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for blk in layer]
+        last_y = saved[-1][2]
+        n, c, h, w = last_y.shape
+        g_feat = g_logits.mm(net.fc.weight)                                    # [N, C]
+        # mean over H*W backward: expand(grad) / (H*W), as autograd's mean_backward
+        g = _like(g_feat.view(n, c, 1, 1).expand(n, c, h, w) / (h * w), last_y)
+        # g: gradient wrt the block output BEFORE that output's ReLU threshold has been applied; ``pending`` is a second
+        # addend of the same gradient (the two branches of a junction), folded into the threshold pass
+        pending = None
+        for i in range(len(blocks) - 1, -1, -1):
+            blk = blocks[i]
+            a, b, y = saved[i]
+            x_in = saved[i - 1][2] if i > 0 else ctx.pooled
+            # threshold of the block's output ReLU on the sum of the junction's two branches, in place on ``g`` (a fresh
+            # convolution output nobody else holds; ``pending`` -- possibly the previous ``gm`` -- is only read)
+            gm = _hip.relu_mask(g, y, g, gb=pending)
+            if bottleneck:
+                gb_ = _like(_conv_input_grad(gm, b, blk.conv3), b)
+                _hip.relu_mask(gb_, b, gb_)
+                ga_ = _like(_conv_input_grad(gb_, a, blk.conv2), a)
+            else:
+                ga_ = _like(_conv_input_grad(gm, a, blk.conv2), a)
+            _hip.relu_mask(ga_, a, ga_)
+            g_main = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in)
+            g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
+            g, pending = g_main, g_skip                                        # summed inside the next threshold pass
+        g_pooled = g + pending                                                 # the stem's ReLU sits before the max-pool
+        g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(
+            g_pooled, ctx.stem, _pair(net.maxpool.kernel_size), _pair(net.maxpool.stride), _pair(net.maxpool.padding),
+            [1, 1], False, ctx.idx), ctx.stem)
+        _hip.relu_mask(g_stem, ctx.stem, g_stem)
+        gx = _conv_input_grad(g_stem, ctx.x, net.conv1)
+        ctx.saved = ctx.stem = ctx.pooled = ctx.idx = ctx.x = None
+        return gx, None
+
+
+def _like(t, ref):
+    """``t`` in ``ref``'s dense memory format (a no-op when MIOpen already returned it that way)"""
+    if ref.is_contiguous():
+        return t.contiguous()
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _pair(v):
+    return [v, v] if isinstance(v, int) else list(v)
+
+
+def forward(net, x):
+    return _ResNetFn.apply(x, net)

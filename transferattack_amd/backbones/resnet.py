@@ -80,6 +80,10 @@ class ResNet(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            from . import fused                  # the attack path: same convolutions, fused glue (backbones/fused.py)
+            if fused.usable(self, x):
+                return fused.forward(self, x)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))

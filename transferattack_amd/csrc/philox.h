@@ -5,10 +5,11 @@
 namespace ta {
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter = (lo32(i), hi32(i), lo32(offset), hi32(offset)) ---
-// 32 x 32 -> 64-bit product in ONE instruction (v_mad_u64_u32 with a zero addend) instead of v_mul_lo_u32 + v_mul_hi_u32:
-// integer multiplies are quarter-rate on CDNA, and Philox is forty of them per four outputs
+// 32 x 32 -> 64-bit product in ONE instruction (v_mad_u64_u32 with a zero addend) instead of the v_mul_lo_u32 + v_mul_hi_u32
+// pair the compiler emits: integer multiplies are quarter-rate on CDNA and Philox is forty of them per four outputs --
+// 325 vs 408 SIMD-cycles per Philox block and wave on MI355X (tools/philox_rate.hip, profiles/r03/philox_rate_r3a.txt)
 __device__ __forceinline__ void mul_wide(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(TA_PHILOX_MAD64)
+#if defined(__HIP_DEVICE_COMPILE__)
     uint64_t p;
     asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(a), "v"(b) : "vcc");
     hi = static_cast<uint32_t>(p >> 32);

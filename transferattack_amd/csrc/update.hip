@@ -13,6 +13,7 @@
 //   d' = min(max(d', 0 - x), 1 - x)
 #include <stdlib.h>
 #include "update_common.h"
+#include "philox.h"
 
 namespace ta {
 
@@ -181,9 +182,10 @@ __global__ __launch_bounds__(kBlock) void normalize_fwd_kernel(const float* __re
     }
 }
 
-template <int VEC>
+template <int VEC, bool HAS_V>      // HAS_V: the tile sums are of |gx + v| (VMI-FGSM: the momentum normalises grad + variance)
 __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                const float* __restrict__ stdv,
+                                                               const float* __restrict__ v,
                                                                float* __restrict__ ws, int64_t e, int64_t hw,
                                                                int tiles) {
     __shared__ float lds[kBlock / kWave];
@@ -195,25 +197,103 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __re
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
         if (off + VEC <= e) {
-            Pack<VEC> a, o;
+            Pack<VEC> a, o, b;
             a.load(gy + img * e + off);
+            if (HAS_V) b.load(v + img * e + off);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const int c = static_cast<int>((off + k) / hw);
                 o[k] = a[k] / stdv[c];
-                acc += fabsf(o[k]);                      // same per-thread order as abs_sum_partials_kernel
+                acc += fabsf(HAS_V ? o[k] + b[k] : o[k]);    // same per-thread order as abs_sum_partials_kernel
             }
             o.store(gx + img * e + off);
         } else if (VEC > 1) {
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
                 const float o = gy[img * e + i] / stdv[static_cast<int>(i / hw)];
                 gx[img * e + i] = o;
-                acc += fabsf(o);
+                acc += fabsf(HAS_V ? o + v[img * e + i] : o);
             }
         }
     }
     const float total = block_sum(acc, lds);
     if (threadIdx.x == 0) ws[img * tiles + blockIdx.x] = total;
+}
+
+// VMI-FGSM's neighbour chain (vmifgsm.py:46-58) with the surrogate's Normalize folded into both ends: per neighbour
+//   forward   y   = (((x + delta) + noise) - mean[c]) / std[c]         one pass, 12 B/element (noise from Philox)
+//   backward  acc = acc + gy / std[c]          (acc = gy / std[c] for the first neighbour)      one pass, 12 (8)
+// instead of sample (12) -> normalize (8) ... normalize backward (8) -> accumulate (12).  Every rounding point of the
+// unfused chain is kept (add, add, subtract, divide; divide, add), so the bits are the same.
+template <int VEC, bool HAS_NOISE>
+__global__ __launch_bounds__(kBlock) void vmi_neighbor_norm_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ delta,
+                                                                   const float* __restrict__ noise,
+                                                                   float* __restrict__ y,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ stdv, float radius,
+                                                                   uint64_t seed, uint64_t offset, int64_t e, int64_t hw) {
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        const int64_t at = img * e + off;                      // flat element index: the Philox counter of ta_vmi_neighbor
+        if (off + VEC <= e) {
+            Pack<VEC> a, d, r, o;
+            a.load(x + at);
+            d.load(delta + at);
+            if (HAS_NOISE) {
+                r.load(noise + at);
+            } else if (VEC == 4) {
+                const float4 q = uniform4(static_cast<uint64_t>(at) >> 2, seed, offset, radius);
+                r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+            } else {
+                r[0] = uniform1(static_cast<uint64_t>(at), seed, offset, radius);
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = static_cast<int>((off + k) / hw);
+                o[k] = (((a[k] + d[k]) + r[k]) - mean[c]) / stdv[c];
+            }
+            o.store(y + at);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const int c = static_cast<int>(i / hw);
+                const float r = HAS_NOISE ? noise[img * e + i] : uniform1(static_cast<uint64_t>(img * e + i), seed, offset, radius);
+                y[img * e + i] = (((x[img * e + i] + delta[img * e + i]) + r) - mean[c]) / stdv[c];
+            }
+        }
+    }
+}
+
+template <int VEC, bool FIRST>
+__global__ __launch_bounds__(kBlock) void normalize_bwd_accumulate_kernel(const float* __restrict__ gy, float* acc,
+                                                                          const float* __restrict__ stdv, int64_t e,
+                                                                          int64_t hw) {
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= e) {
+            Pack<VEC> a, o;
+            a.load(gy + img * e + off);
+            if (!FIRST) o.load(acc + img * e + off);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float g = a[k] / stdv[static_cast<int>((off + k) / hw)];
+                o[k] = FIRST ? g : o[k] + g;
+            }
+            o.store(acc + img * e + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const float g = gy[img * e + i] / stdv[static_cast<int>(i / hw)];
+                acc[img * e + i] = FIRST ? g : acc[img * e + i] + g;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -593,19 +673,49 @@ extern "C" int ta_normalize_fwd(const float* x, float* y, const float* mean, con
     return check_launch("normalize_fwd");
 }
 
-extern "C" int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int64_t hw,
-                                void* stream) {
+extern "C" int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, const float* v, float* ws, int64_t n, int c,
+                                int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
     if (int rc = check_batch(n, e)) return rc;
     TA_REQUIRE(gy && gx && stdv && ws && c > 0, "null pointer");
     const int tiles = static_cast<int>(ceil_div(e, kTile));
     const dim3 grid(tiles, static_cast<unsigned>(n));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (vec_ok(e, {gy, gx}))
-        hipLaunchKernelGGL(normalize_bwd_kernel<4>, grid, dim3(kBlock), 0, st, gy, gx, stdv, ws, e, hw, tiles);
-    else
-        hipLaunchKernelGGL(normalize_bwd_kernel<1>, grid, dim3(kBlock), 0, st, gy, gx, stdv, ws, e, hw, tiles);
+#define TA_NB(VEC, HV) hipLaunchKernelGGL((normalize_bwd_kernel<VEC, HV>), grid, dim3(kBlock), 0, st, gy, gx, stdv, v, ws, e, hw, tiles)
+    if (vec_ok(e, {gy, gx, v})) { if (v) { TA_NB(4, true); } else { TA_NB(4, false); } }
+    else { if (v) { TA_NB(1, true); } else { TA_NB(1, false); } }
+#undef TA_NB
     return check_launch("normalize_bwd");
+}
+
+extern "C" int ta_vmi_neighbor_normalized(const float* x, const float* delta, const float* noise, float* y, const float* mean,
+                                          const float* stdv, float radius, uint64_t seed, uint64_t offset, int64_t n, int c,
+                                          int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(x && delta && y && mean && stdv && c > 0, "null pointer");
+    const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define TA_VNN(VEC, HN) \
+    hipLaunchKernelGGL((vmi_neighbor_norm_kernel<VEC, HN>), grid, dim3(kBlock), 0, st, x, delta, noise, y, mean, stdv, radius, seed, offset, e, hw)
+    if (vec_ok(e, {x, delta, noise, y})) { if (noise) { TA_VNN(4, true); } else { TA_VNN(4, false); } }
+    else { if (noise) { TA_VNN(1, true); } else { TA_VNN(1, false); } }
+#undef TA_VNN
+    return check_launch("vmi_neighbor_normalized");
+}
+
+extern "C" int ta_normalize_bwd_accumulate(const float* gy, float* acc, const float* stdv, int first, int64_t n, int c,
+                                           int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(gy && acc && stdv && c > 0 && gy != acc, "null or aliased pointers");
+    const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define TA_NBA(VEC, F) hipLaunchKernelGGL((normalize_bwd_accumulate_kernel<VEC, F>), grid, dim3(kBlock), 0, st, gy, acc, stdv, e, hw)
+    if (vec_ok(e, {gy, acc})) { if (first) { TA_NBA(4, true); } else { TA_NBA(4, false); } }
+    else { if (first) { TA_NBA(1, true); } else { TA_NBA(1, false); } }
+#undef TA_NBA
+    return check_launch("normalize_bwd_accumulate");
 }
 
 extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
@@ -613,7 +723,7 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
                             float eps, int64_t n, int64_t e, void* stream) {
     if (int rc = check_batch(n, e)) return rc;
     TA_REQUIRE(g && delta && x && ws && ws_slots >= 0, "null pointer");
-    TA_REQUIRE(!(ws_slots && v), "partials of |g| cannot be reused when a variance term is added");
+    // ws_slots > 0 with a variance term: the producer summed |g + v| (ta_normalize_bwd with v) -- the caller's contract
     TA_REQUIRE(!(ws_slots && aten_sum_lanes() != 0),
                "TA_ATEN_SUM_LANES: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -6,12 +6,23 @@ HIP path: neighbour sampling is one kernel (``ta_vmi_neighbor``: x + delta + Phi
 sample itself is written), accumulation/finalisation are ``ta_grad_accumulate`` / ``ta_variance_finalize``
 and ``grad + variance`` is folded into the fused update (its ``v`` operand), so no grad-sized temporary is
 ever materialised besides the accumulator.
+
+When nothing sits between the sample and the backbone but the surrogate's own Normalize (the plain class on a 224-pixel
+surrogate: no look-ahead transform, no overridden hooks, no module hooks on the preprocessing layer), the chain per
+neighbour shrinks from four passes (sample 12 + normalize 8 ... normalize backward 8 + accumulate 12 = 40 B/element) to
+two (``ta_vmi_neighbor_normalized`` 12 + ``ta_normalize_bwd_accumulate`` 12 = 24): the sample is written already
+normalised and handed to ``self.model[1]``, the backbone's input gradient goes straight into the accumulator.  The
+current gradient's Normalize backward adds the |grad + variance| tile sums, and momentum + step are ONE ``ta_mi_update``
+after the neighbours (the variance is sampled around the old delta either way, vmifgsm.py:89-95), so the update makes no
+pass of its own over the gradient.  Rounding points are those of the separate kernels: same bits.
 """
 import torch
+import torch.nn as nn
 
 from ..attack import Attack
 from .. import _hip
 from ..transforms import Neighbor
+from ..utils import PreprocessingModel
 
 
 class VMIFGSM(Attack):
@@ -42,12 +53,67 @@ class VMIFGSM(Attack):
         _hip.variance_finalize(acc, cur_grad.contiguous(), variance, self.num_neighbor)
         return variance
 
+    def _normalize_folds(self, data):
+        """(mean, std) of the surrogate's Normalize if the neighbour chain may bypass ``self.model[0]`` -- i.e. if that layer
+        is the only thing between the sample and the backbone and nobody observes it -- else None."""
+        cls = type(self)
+        if not (cls.transform is Attack.transform and cls.get_logits is Attack.get_logits and cls.get_grad is Attack.get_grad
+                and cls.get_variance is VMIFGSM.get_variance and self._can_fuse_update()):
+            return None
+        model = self.model
+        if not (isinstance(model, nn.Sequential) and len(model) == 2 and isinstance(model[0], PreprocessingModel)):
+            return None
+        pre = model[0]
+        if pre.resize.size != data.shape[-1] or data.shape[-1] != data.shape[-2] or data.dim() != 4 or data.dtype != torch.float32:
+            return None
+        for mod in (model, pre, pre.resize, pre.normalize):
+            if mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or getattr(mod, "_backward_pre_hooks", None):
+                return None
+        return pre.normalize.mean.reshape(-1).contiguous(), pre.normalize.std.reshape(-1).contiguous()
+
+    def _backbone_grad(self, y, label):
+        """d loss / d y for an already normalised input ``y`` (a fresh leaf) through ``self.model[1]``"""
+        y.requires_grad_(True)
+        loss = self.get_loss(self.model[1](y), label)
+        return torch.autograd.grad(loss, y, retain_graph=False, create_graph=False)[0].contiguous()
+
+    def _forward_folded(self, data, label, mean, std):
+        delta = self.init_delta(data).detach()
+        momentum, variance, x_adv = None, None, None
+        for it in range(self.epoch):
+            x_in = data + delta if x_adv is None else x_adv
+            y = torch.empty_like(data)
+            _hip.normalize_fwd(x_in.contiguous(), y, mean, std)
+            gy = self._backbone_grad(y, label)
+            grad = torch.empty_like(data)
+            _hip.normalize_bwd(gy, grad, std, variance=variance)          # leaves the tile sums of |grad + variance|
+            acc = torch.empty_like(data)
+            for i in range(self.num_neighbor):
+                noise = None
+                if self.noise_source is not None:
+                    noise = self.noise_source(data.shape, -self.radius, self.radius).to(self.device).contiguous()
+                y = torch.empty_like(data)
+                _hip.vmi_neighbor_normalized(data, delta, y, mean, std, self.radius, self.rng_seed, self._next_offset(), noise)
+                _hip.normalize_bwd_accumulate(self._backbone_grad(y, label), acc, std, first=(i == 0))
+            new_variance = torch.empty_like(data)
+            _hip.variance_finalize(acc, grad, new_variance, self.num_neighbor)
+            m_out = momentum if momentum is not None else (None if self.decay == 0 else torch.empty_like(data))
+            if x_adv is None and it + 1 < self.epoch:
+                x_adv = torch.empty_like(data)
+            _hip.mi_update(grad, momentum, m_out, delta, data, self.decay, self.alpha, self.epsilon, variance=variance,
+                           x_adv=x_adv if it + 1 < self.epoch else None)
+            momentum, variance = m_out, new_variance
+        return delta.detach()
+
     def forward(self, data, label, **kwargs):
         if self.targeted:
             assert len(label) == 2
             label = label[1]
         data = data.clone().detach().to(self.device)
         label = label.clone().detach().to(self.device)
+        folds = self._normalize_folds(data)
+        if folds is not None:
+            return self._forward_folded(data.contiguous(), label, *folds)
         delta = self.init_delta(data)
         momentum, variance = 0, 0
         fused = self._can_fuse_update()
