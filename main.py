@@ -147,7 +147,18 @@ def main():
                                                      and not isinstance(args.model, list) else 1)
         if args.attack not in transferattack.BATCH_INDEPENDENT:
             k = 1
-        groups = [mine[i:i + k] for i in range(0, len(mine), k)]
+        # groups of 4 / 2 / 1 FULL reference batches (a short last batch stays alone): the batch-mean loss then carries
+        # 1/(kB) instead of 1/B, an exact power-of-two factor that the per-image normalisation removes without a rounding
+        # difference -- the coalesced run computes the reference batches' arithmetic, not just its value
+        full = [idx for idx in mine if (idx + 1) * args.batchsize <= len(dataset)]
+        groups, at = [], 0
+        while at < len(full):
+            take = 1
+            while take * 2 <= k and at + take * 2 <= len(full):
+                take *= 2
+            groups.append(full[at:at + take])
+            at += take
+        groups += [[idx] for idx in mine if (idx + 1) * args.batchsize > len(dataset)]
 
         def write(images, filenames, perturbations):
             t0 = time.perf_counter()
@@ -188,6 +199,7 @@ def main():
             import json
             print(json.dumps({"end_to_end_images_per_s": round(images_done / max(wall, 1e-9), 2), "images": images_done,
                               "wall_s": round(wall, 3), "reference_batches_per_device_batch": k,
+                              "device_batches": [len(g) for g in groups],
                               "stage_busy_seconds": {k_: round(v, 3) for k_, v in sorted(stage_seconds.items())}}))
     elif rank == 0:
         if not os.environ.get("TA_WEIGHTS_DIR") and os.environ.get("TA_ALLOW_RANDOM_INIT", "0") != "1":

@@ -174,7 +174,7 @@ def _check_registered(out, exact):
     the kernels that use K1's tiling, else equal to an fp64 sum within fp32 summation error)"""
     assert _hip._partials is not None and _hip._partials[0].data_ptr() == out.data_ptr()
     entry = _hip._partials
-    _, _, ws, slots, _ = entry
+    ws, slots = entry[2], entry[3]
     n = out.shape[0]
     sums = ws[:n * slots].view(n, slots).clone()
     k1 = _k1_sums(out)
