@@ -55,6 +55,21 @@ dispatch)
   timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
+newtests)
+  # the GPU tests of what changed last (fused surrogate glue, folded VMI chain, DIM tables, ASR with the bench arrangement)
+  timeout 900 python -m pytest tests/test_hip_configs.py tests/test_hip_kernels.py tests/test_hip_attacks.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
+      -k "fused or vmi or vni or dim or partials or streaming or config4" 2>&1 | grep -v Warning | tee $OUT/newtests_pytest.txt | tail -25
+  timeout 600 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "folded or dts" 2>&1 | grep -v Warning | tee $OUT/asr1000_fused_pytest.txt | tail -30 ;;
+benchpair)
+  # the default line with the surrogate's glue fused (default) and through the plain module path
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue.json
+  TA_FUSED_GLUE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_module_path.json
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_b32.json ;;
+ktrace)
+  # rocprofv3's own durations of every kernel of the stand-alone bench (event timing adds the marker overhead)
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace -o trace -- python $R/tools/kernel_bench.py > $R/$OUT/ktrace.log 2>&1 )
+  f=$(find $OUT/ktrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_bench_kernel_stats.csv && head -40 "$f" | cut -c1-150
+  find $OUT/ktrace -name "*kernel_trace.csv" -delete; find $OUT/ktrace -name "*.db" -delete ;;
 e2e)
   # main.py end to end on 1000 synthetic PNGs: decode -> upload -> attack -> quantise -> download -> encode
   timeout 900 python tools/e2e_main.py 2> $OUT/e2e_main.err | tee $OUT/e2e_main.jsonl ;;

@@ -58,6 +58,9 @@ def main():
         rec("dim_tables", timed(lambda i: _hip.dim_tables(sets[0][0], 246, 237, 3, 5)), 0)
         rec("vmi_neighbor_philox", timed(lambda i: _hip.vmi_neighbor(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
                                                                       0.09, seed=1, offset=i)), 12)
+        rec("vmi_neighbor_normalized_philox", timed(lambda i: _hip.vmi_neighbor_normalized(
+            sets[i % 3][0], sets[i % 3][1], sets[i % 3][2], mean, std, 0.09, seed=1, offset=i)), 12)
+        rec("normalize_bwd_accumulate", timed(lambda i: _hip.normalize_bwd_accumulate(sets[i % 3][0], sets[i % 3][1], std, False)), 12)
         rec("grad_accumulate", timed(lambda i: _hip.grad_accumulate(sets[i % 3][0], sets[i % 3][1], False)), 12)
         rec("variance_finalize", timed(lambda i: _hip.variance_finalize(sets[i % 3][0], sets[i % 3][1],
                                                                         sets[i % 3][2], 20)), 12)
@@ -72,6 +75,16 @@ def main():
                                                                         0.006, 0.06, sets[i % 3][3])), 16)
         rec("mi_update_two_launch", timed(lambda i: _hip.mi_update(sets[i % 3][0], sets[i % 3][1], sets[i % 3][1],
                                                                    sets[i % 3][2], sets[i % 3][3], 1.0, 0.006, 0.06)), 24)
+        # surrogate glue on a layer1-sized NHWC activation map of this batch ([n, 256, 56, 56])
+        acts = [torch.randn(n, 256, 56, 56, device=DEV).contiguous(memory_format=torch.channels_last) for _ in range(6)]
+        bias = torch.randn(256, device=DEV)
+        ea = acts[0].numel() / (E * n)                   # elements relative to an image batch, for the GB/s column
+        rec("glue_bias_relu_nhwc", timed(lambda i: _hip.bias_act_(acts[i % 3], bias)), 8 * ea)
+        rec("glue_bias_add_relu_nhwc", timed(lambda i: _hip.bias_add_relu_(acts[i % 3], bias, acts[3 + i % 3])), 12 * ea)
+        rec("glue_relu_mask_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3])), 12 * ea)
+        rec("glue_relu_mask_add_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3],
+                                                                      gb=acts[3 + (i + 1) % 3])), 16 * ea)
+        del acts
         if n == 32:
             import random
             import numpy as np
