@@ -78,6 +78,7 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((ui
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only used on wave-uniform values */
 #define __builtin_assume(cond) ((void)0)
 namespace hipcpu { int wave_any(int pred); void mfma_f32_16x16x4(float a, float b, float (&c)[4]); }

@@ -652,34 +652,65 @@ __global__ __launch_bounds__(kBlock) void dim_tables_kernel(int* __restrict__ ta
     }
 }
 
+// gx of one pixel of a row that its last rescaled row reaches with BOTH taps (only the last row of x): the general
+// accumulation of dim_bwd_lanes_kernel with the hit tables rebuilt on the spot (one wave per bottom tile and plane).
+__device__ __forceinline__ float dim_bwd_double_row(const float* mid, int ix, int iy, int size, int rnd, float scale1,
+                                                    int rx_lo, int ry_lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(ix));       // opaque: keeps the table arithmetic below inside the branch that needs it (left to
+#endif                                 // itself the compiler hoists it, loop-invariant and side-effect free, into every workgroup)
+    const Hit hx = find_hits(ix, size, rnd, scale1);
+    const Hit hy = find_hits(iy, size, rnd, scale1);
+    float acc = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < kHitSlots; ++ky)            // static indices into the Hit arrays: a rolled loop would put them in scratch
+        if (ky < hy.n) {
+            const float* mrow = mid + (hy.first - ry_lo + ky) * 64;
+#pragma unroll
+            for (int kx = 0; kx < kHitSlots; ++kx)
+                acc = hit_accumulate<false>(acc, mrow[min(hx.first - rx_lo + kx, 63)], hy.w[ky], hy.w2[ky], (hy.both >> ky) & 1u, hx, kx);
+        }
+    return acc;
+}
+
 template <int RPW, int SB, int PP>
 __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                               float* __restrict__ ws, const int* __restrict__ tab,
-                                                              int size, int resize, int rnd, int top, int left,
-                                                              float scale1, float scale2, int tw, int tiles_x,
-                                                              int tiles_y) {
+                                                              DimTables L, int size, int rnd, int top, int left,
+                                                              float scale1, int tw) {
     constexpr int ROWS = 4 * RPW;
+    constexpr int HALF = (RPW + 1) / 2;                                   // stage A runs in two halves: 4 * HALF loads in flight
     __shared__ __attribute__((aligned(16))) float mid[(ROWS + 3) * 64];   // d(rescaled) window (+ slack: stage B reads ahead)
+    __shared__ __attribute__((aligned(16))) float4 rowA[ROWS];            // window row p : (first output row, n, wy0, wy1)
+    __shared__ __attribute__((aligned(16))) float4 rowB[kDimLaneRows][2]; // tile row r   : (window row, n, double?, -) (wy0..wy3)
     __shared__ float red[kBlock / kWave];
-    const DimTables L = dim_tables_layout(size, resize);
     const float* ftab = reinterpret_cast<const float*>(tab);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(blockIdx.x);
-    const int group = tid / tiles;
-    const int t = tid - group * tiles;
-    const int tyi = t / tiles_x;
-    const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
+    const int tiles_x = static_cast<int>(gridDim.x), tiles = tiles_x * static_cast<int>(gridDim.y);
+    const int t = static_cast<int>(blockIdx.y) * tiles_x + static_cast<int>(blockIdx.x);
+    const int group = static_cast<int>(blockIdx.z);
+    const int iy0 = static_cast<int>(blockIdx.y) * kDimLaneRows, ix0 = static_cast<int>(blockIdx.x) * tw;
     const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
 
-    // window of d(rescaled) behind this tile of x (wave-uniform: scalar loads)
+    // window of d(rescaled) behind this tile of x (wave-uniform: scalar loads, once per workgroup)
     const int ix_last = ix0 + twc - 1, iy_last = iy0 + th - 1;
     const int rx_lo = tab[L.b_first + ix0], rx_hi = tab[L.b_first + ix_last] + tab[L.b_n + ix_last] - 1;
     const int ry_lo = tab[L.b_first + iy0], ry_hi = tab[L.b_first + iy_last] + tab[L.b_n + iy_last] - 1;
-    const int mw = rx_hi - rx_lo + 1, mh = ry_hi - ry_lo + 1;           // <= 64, <= ROWS (host-checked)
+    const int mh = ry_hi - ry_lo + 1;                                    // <= ROWS; the window is <= 64 wide (host-checked)
 
+    // the tile's row entries, from the per-call table into LDS: one thread per row, read back as 16-byte broadcasts
+    if (static_cast<int>(threadIdx.x) < mh) {
+        const int py = ry_lo + static_cast<int>(threadIdx.x) + top;
+        rowA[threadIdx.x] = make_float4(__int_as_float(tab[L.a_first + py]), __int_as_float(tab[L.a_n + py]),
+                                        ftab[L.a_w0 + py], ftab[L.a_w1 + py]);
+    } else if (static_cast<int>(threadIdx.x) >= 128 && static_cast<int>(threadIdx.x) < 128 + th) {
+        const int r = static_cast<int>(threadIdx.x) - 128, iy = iy0 + r;
+        rowB[r][0] = make_float4(__int_as_float(tab[L.b_first + iy] - ry_lo), __int_as_float(tab[L.b_n + iy]),
+                                 __int_as_float(tab[L.b_tail_rel + iy]), 0.0f);
+        rowB[r][1] = make_float4(ftab[L.b_w0 + iy], ftab[L.b_w1 + iy], ftab[L.b_w2 + iy], ftab[L.b_w3 + iy]);
+    }
     // stage-A column entry of this lane: window column `lane` = padded column px
     const int px = min(rx_lo + lane, rx_hi) + left;
     const int a_fx = tab[L.a_first + px];
@@ -697,6 +728,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __res
     const bool wave_has_tail = __builtin_amdgcn_readfirstlane(__any(b_tail_rel >= 0)) != 0;   // last column tile only
     const bool on1 = b_n > 1, on2 = b_n > 2, on3 = b_n > 3;
     const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+    __syncthreads();
 
 #pragma unroll 1
     for (int q = 0; q < PP; ++q) {
@@ -704,12 +736,18 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __res
     const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
     char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
     // -- stage A: mid[p][c] = sum over the <= 2 x 2 outputs that touch padded pixel (ry_lo + p + top, px)
-    {
-        float g00[RPW], g01[RPW], g10[RPW], g11[RPW];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int p = min(wave + 4 * i, mh - 1);                               // clamped: loads stay in bounds
-            const int fy = tab[L.a_first + ry_lo + p + top];
+    for (int half = 0; half < 2; ++half) {
+        float g00[HALF], g01[HALF], g10[HALF], g11[HALF];
+        int ny_s[HALF], wy0_s[HALF], wy1_s[HALF];                                  // wave-uniform: kept in scalar registers
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const int p = min(wave + 4 * (half * HALF + i), mh - 1);               // clamped: loads stay in bounds
+            const float4 ra = rowA[p];
+            const int fy = __builtin_amdgcn_readfirstlane(__float_as_int(ra.x));
+            ny_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.y));
+            wy0_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.z));
+            wy1_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.w));
             const char* r0 = gyp + static_cast<unsigned>(fy) * row_bytes;          // wave-uniform row pointers
             const char* r1 = gyp + static_cast<unsigned>(min(fy + 1, size - 1)) * row_bytes;
             g00[i] = *reinterpret_cast<const float*>(r0 + a_c0);
@@ -719,19 +757,18 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __res
         }
         float* out = mid + wave * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int p = wave + 4 * i;
-            if (p < mh) {
-                const int py = ry_lo + p + top;
-                const float wy0 = ftab[L.a_w0 + py], wy1 = ftab[L.a_w1 + py];
-                const bool two_y = tab[L.a_n + py] > 1;
+        for (int i = 0; i < HALF; ++i) {
+            const int p = wave + 4 * (half * HALF + i);
+            if (half * HALF + i < RPW && p < mh) {
+                const float wy0 = __int_as_float(wy0_s[i]), wy1 = __int_as_float(wy1_s[i]);
+                const bool two_y = ny_s[i] > 1;
                 float acc = fmaf(wy0 * a_wx0, g00[i], 0.0f);
                 acc = fmaf(wy0 * a_wx1, a_two ? g01[i] : 0.0f, acc);
                 if (two_y) {
                     acc = fmaf(wy1 * a_wx0, g10[i], acc);
                     acc = fmaf(wy1 * a_wx1, a_two ? g11[i] : 0.0f, acc);
                 }
-                out[i * 256] = acc;
+                out[(half * HALF + i) * 256] = acc;
             }
         }
     }
@@ -745,12 +782,11 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __res
         for (int j = 0; j < kDimLaneRows / 4; ++j) {
             const int r = wave + 4 * j;
             if (r >= th) continue;
-            const int iy = iy0 + r;
-            if (tab[L.b_tail_rel + iy] >= 0) continue;                   // the last row of x: below
-            const int fy = tab[L.b_first + iy] - ry_lo;
-            const int n_y = tab[L.b_n + iy];
+            const float4 rb = rowB[r][0], wy = rowB[r][1];
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(rb.z)) >= 0) continue;   // the last row of x: below
+            const int fy = __builtin_amdgcn_readfirstlane(__float_as_int(rb.x));
+            const int n_y = __builtin_amdgcn_readfirstlane(__float_as_int(rb.y));
             const float* m = mcol + fy * 64;
-            const float wy[4] = {ftab[L.b_w0 + iy], ftab[L.b_w1 + iy], ftab[L.b_w2 + iy], SB > 3 ? ftab[L.b_w3 + iy] : 0.0f};
             // all window values of the row first (unconditional, in bounds: `mid` has rows of slack), then the selects
             float v[SB][SB], vt[SB];
 #pragma unroll
@@ -759,36 +795,26 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __res
                 for (int kx = 0; kx < SB; ++kx) v[ky][kx] = m[ky * 64 + kx];
                 vt[ky] = wave_has_tail ? m[ky * 64 + max(b_tail_rel, 0)] : 0.0f;
             }
+            const float wys[4] = {wy.x, wy.y, wy.z, wy.w};
             float acc = 0.0f;
 #pragma unroll
             for (int ky = 0; ky < SB; ++ky)
                 if (ky < n_y) {
-                    acc = fmaf(wy[ky] * b_wx0, v[ky][0], acc);
-                    acc = fmaf(wy[ky] * b_wx1, on1 ? v[ky][1] : 0.0f, acc);
-                    acc = fmaf(wy[ky] * b_wx2, on2 ? v[ky][2] : 0.0f, acc);
-                    if (SB > 3) acc = fmaf(wy[ky] * b_wx3, on3 ? v[ky][3] : 0.0f, acc);
-                    if (wave_has_tail) acc = fmaf(wy[ky] * b_tail_w, b_tail_rel >= 0 ? vt[ky] : 0.0f, acc);
+                    acc = fmaf(wys[ky] * b_wx0, v[ky][0], acc);
+                    acc = fmaf(wys[ky] * b_wx1, on1 ? v[ky][1] : 0.0f, acc);
+                    acc = fmaf(wys[ky] * b_wx2, on2 ? v[ky][2] : 0.0f, acc);
+                    if (SB > 3) acc = fmaf(wys[ky] * b_wx3, on3 ? v[ky][3] : 0.0f, acc);
+                    if (wave_has_tail) acc = fmaf(wys[ky] * b_tail_w, b_tail_rel >= 0 ? vt[ky] : 0.0f, acc);
                 }
-            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy) * row_bytes) = acc;
+            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy0 + r) * row_bytes) = acc;
             asum += fabsf(acc);
         }
         // the last row of x (if this tile holds it and it has a double hit): its last rescaled row reaches it with both taps,
         // whose contributions interleave with the columns -- the general accumulation of dim_bwd_lanes_kernel, tables
         // rebuilt here (one row per plane and tile column)
         if (iy_last == size - 1 && ((th - 1) & 3) == wave && tab[L.b_tail_rel + iy_last] >= 0) {
-            const int iy = iy_last;
-            const Hit hx = find_hits(ix, size, rnd, scale1);
-            const Hit hy = find_hits(iy, size, rnd, scale1);
-            float acc = 0.0f;
-#pragma unroll 1
-            for (int ky = 0; ky < hy.n; ++ky) {
-                const float* mrow = mid + (hy.first - ry_lo + ky) * 64;
-#pragma unroll
-                for (int kx = 0; kx < kHitSlots; ++kx)
-                    acc = hit_accumulate<false>(acc, mrow[min(hx.first - rx_lo + kx, 63)], hy.w[ky], hy.w2[ky],
-                                                (hy.both >> ky) & 1u, hx, kx);
-            }
-            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy) * row_bytes) = acc;
+            const float acc = dim_bwd_double_row(mid, ix, iy_last, size, rnd, scale1, rx_lo, ry_lo);
+            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy_last) * row_bytes) = acc;
             asum += fabsf(acc);
         }
     }
@@ -967,7 +993,11 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, const void* tab
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
             // the three planes of an RGB image share one workgroup's hit tables (a quarter of the backward's instructions)
             // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
-            const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
+            int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
+            if (const char* force = getenv("TA_DIM_PP")) {        // measurement knob (round 3): planes per workgroup
+                const int want = atoi(force);
+                if ((want == 1 || want == 3) && planes % want == 0) pp = want;
+            }
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
@@ -976,14 +1006,17 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, const void* tab
             const int fast_slots = tables != nullptr ? dim_bwd_fast_slots(size, resize, rnd) : 0;
             if (fast_slots != 0) {
                 const int* tab = static_cast<const int*>(tables);
+                const DimTables layout = dim_tables_layout(size, resize);
+                TA_REQUIRE(planes / pp <= 65535, "too many planes for one launch");
+                const dim3 grid3(static_cast<unsigned>(tiles_x), static_cast<unsigned>(tiles_y), static_cast<unsigned>(planes / pp));
 #define TA_DIM_ROWS(RPW, SB)                                                                                             \
     do {                                                                                                                 \
         if (pp == 3)                                                                                                     \
-            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 3>), grid, dim3(kBlock), 0, st, gy, gx, ws, tab, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
+            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 3>), grid3, dim3(kBlock), 0, st, gy, gx, ws, tab, layout,   \
+                               size, rnd, top, left, scale1, tw);                                                        \
         else                                                                                                             \
-            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 1>), grid, dim3(kBlock), 0, st, gy, gx, ws, tab, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
+            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 1>), grid3, dim3(kBlock), 0, st, gy, gx, ws, tab, layout,   \
+                               size, rnd, top, left, scale1, tw);                                                        \
     } while (0)
                 if (rows <= 40) { if (fast_slots == 3) TA_DIM_ROWS(10, 3); else TA_DIM_ROWS(10, 4); }
                 else { if (fast_slots == 3) TA_DIM_ROWS(17, 3); else TA_DIM_ROWS(17, 4); }
