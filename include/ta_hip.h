@@ -213,6 +213,14 @@ int ta_bias_add_relu(float* y, const float* bias, const float* other, const floa
                      int64_t inner, void* stream);
 int ta_relu_mask(const float* ga, const float* gb, const float* y, float* out, int64_t numel, void* stream);
 
+/* ---- the stem convolution's input gradient (7 x 7, stride 2, padding 3, 3 -> 64 channels: ResNet / ImageNet CNN stems) ----
+ * The last convolution of the surrogate's backward, producer of the gradient the update consumes (attack.py:118-122).
+ * dx[n,c,2i+py,2j+px] = sum_{a,b<4} sum_k dy[n,i-1+a,j-1+b,k] * w[k,c,5-2a+py,5-2b+px] on the fp32 matrix cores, deterministic.
+ *   ta_stem7s2_prepare      w [64,3,7,7] (dense NCHW) -> w2 (16384 floats, device): once per model
+ *   ta_stem7s2_input_grad   dy channels_last [n, oh, ow, 64] -> dx NCHW [n, 3, 2*oh, 2*ow] */
+int ta_stem7s2_prepare(const float* w, float* w2, void* stream);
+int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, int64_t n, int oh, int ow, void* stream);
+
 /* ---- output: save_images  transferattack/utils.py:63-66 (+ main.py:53 add) ---------------------------
  * u8[n,h,w,c] = trunc((x + d) * 255)   NCHW fp32 -> NHWC uint8 */
 int ta_quantize_u8_nhwc(const float* x, const float* delta, uint8_t* out, int64_t n, int c, int h,

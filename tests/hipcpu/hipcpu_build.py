@@ -21,13 +21,14 @@ def _host_text(text):
     text = text.replace("typedef float floatx4 __attribute__((ext_vector_type(4)));", "struct floatx4 { float x, y, z, w; };")
     text = text.replace("typedef float v2f __attribute__((ext_vector_type(2)));", "struct alignas(8) v2f { float x, y; };")
     text = text.replace("typedef float f32x4 __attribute__((ext_vector_type(4)));", "/* f32x4: tests/hipcpu/hip/hip_runtime.h */")
+    text = text.replace("typedef float stem_f32x4 __attribute__((ext_vector_type(4)));", "typedef f32x4 stem_f32x4;")
     # the MFMA instruction's arithmetic on the host (the product source only knows hipcc's device and host passes)
     text = text.replace("return c;                                         // hipcc's host pass only parses this function",
                         "return hipcpu_mfma_f32_16x16x4(a, b, c);")
     return text
 
 
-HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip", "spectrum.hip", "glue.hip")
+HOST_SOURCES = ("runtime.hip", "update.hip", "elementwise.hip", "tim.hip", "dim.hip", "sia.hip", "bsr.hip", "spectrum.hip", "glue.hip", "stem.hip")
 
 
 # HIPCPU_SANITIZE=1: AddressSanitizer build (one worker thread, `__shared__` arrays as plain statics).  Every load /

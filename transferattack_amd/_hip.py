@@ -46,6 +46,8 @@ SIGNATURES = {
     "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_dim_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
+    "ta_stem7s2_prepare": (_int, [_vp, _vp, _vp]),
+    "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "ta_bias_act": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -589,6 +591,27 @@ def relu_mask(ga, y, out, gb=None):
     _call("ta_relu_mask", y, _ptr_any(ga, "ga"), None if gb is None else _ptr_any(gb, "gb"), _ptr_any(y, "y"),
           _ptr_any(out, "out"), y.numel())
     return out
+
+
+def stem7s2_prepare(weight):
+    """the stem convolution's weights [64, 3, 7, 7] rearranged for ``stem7s2_input_grad`` (once per model)"""
+    if tuple(weight.shape) != (64, 3, 7, 7) or weight.dtype != torch.float32:
+        raise ValueError("stem weights must be fp32 [64, 3, 7, 7], got %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    w2 = torch.empty(16 * 16 * 4 * 16, dtype=torch.float32, device=w.device)
+    _call("ta_stem7s2_prepare", w, _ptr(w, name="weight"), _ptr(w2, name="w2"))
+    return w2
+
+
+def stem7s2_input_grad(dy, w2, dx):
+    """dx [n, 3, 2*oh, 2*ow] (NCHW) = d/d(input) of the 7x7 / stride 2 / padding 3 stem convolution for the output gradient
+    ``dy`` [n, 64, oh, ow] in channels_last memory"""
+    n, k, oh, ow = dy.shape
+    if k != 64 or not dy.is_contiguous(memory_format=torch.channels_last) or tuple(dx.shape) != (n, 3, 2 * oh, 2 * ow):
+        raise ValueError("stem7s2_input_grad: dy must be channels_last [n, 64, oh, ow] and dx [n, 3, 2*oh, 2*ow]")
+    _wrote(dx)
+    _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), n, oh, ow)
+    return dx
 
 
 def _ptr_any(t, name):

@@ -139,9 +139,24 @@ class _ResNetFn(torch.autograd.Function):
             g_pooled, ctx.stem, _pair(net.maxpool.kernel_size), _pair(net.maxpool.stride), _pair(net.maxpool.padding),
             [1, 1], False, ctx.idx), ctx.stem)
         _hip.relu_mask(g_stem, ctx.stem, g_stem)
-        gx = _conv_input_grad(g_stem, ctx.x, net.conv1)
+        gx = _stem_input_grad(net, g_stem, ctx.x)
         ctx.saved = ctx.stem = ctx.pooled = ctx.idx = ctx.x = None
         return gx, None
+
+
+def _stem_input_grad(net, g_stem, x):
+    """d/d(image) through the stem convolution: the 7 x 7 / stride 2 / 3 -> 64 stem of the ResNets on the fp32-MFMA kernel
+    (csrc/stem.hip; MIOpen's backward-data spends 7.5 % of a ResNet-50 iteration here), anything else through MIOpen"""
+    conv = net.conv1
+    if (os.environ.get("TA_STEM_KERNEL", "1") != "0" and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[-1] % 2 == 0
+            and x.shape[-2] % 2 == 0 and g_stem.is_contiguous(memory_format=torch.channels_last)):
+        w2 = getattr(net, "_stem_w2", None)
+        if w2 is None or w2.device != conv.weight.device or net._stem_w2_version != conv.weight._version:
+            w2 = net._stem_w2 = _hip.stem7s2_prepare(conv.weight)
+            net._stem_w2_version = conv.weight._version
+        return _hip.stem7s2_input_grad(g_stem, w2, torch.empty(x.shape, dtype=x.dtype, device=x.device))
+    return _conv_input_grad(g_stem, x, conv)
 
 
 def _like(t, ref):
