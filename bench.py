@@ -111,7 +111,9 @@ def kernel_sweep(sizes=(32, 125, 250), reps=30):
 _NB = lambda t: 4 * t.numel()                                                   # noqa: E731
 KERNEL_BYTES = {
     "normalize_fwd": lambda x, y, *a: _NB(x) + _NB(y),
-    "normalize_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
+    "normalize_bwd": lambda gy, gx, *a, **k: _NB(gy) * (3 if k.get("variance") is not None else 2),
+    "vmi_neighbor_normalized": lambda data, delta, out, *a, **k: 3 * _NB(data),
+    "normalize_bwd_accumulate": lambda gy, acc, std, first: _NB(gy) * (2 if first else 3),
     "momentum": lambda g, m_in, m_out, *a, **k: _NB(g) * (2 if m_in is None else 3),
     "update_delta_linf": lambda d, x, m, *a, **k: 4 * _NB(d),
     "depthwise_conv2d_same": lambda inp, out, w: _NB(inp) + _NB(out),

@@ -204,7 +204,7 @@ int ta_axpy(const float* x, const float* m, float coeff, float* out, int64_t num
  * (what torch runs per convolution of a ResNet with folded BatchNorm: bias add, ReLU clamp, residual add; in the backward
  * threshold_backward and the junction add -- transferattack/attack.py:104-122 evaluates that surrogate 10 x per batch).
  * Contiguous fp32 buffers of `numel` elements (numel % 4 == 0, 16-byte aligned); element i has channel (i / inner) % channels:
- * inner = 1 for NHWC (channels % 4 == 0), H*W for NCHW (H*W % 4 == 0).  Same rounding points as the separate ATen passes.
+ * inner = 1 for NHWC, H*W for NCHW (fastest when channels % 4 == 0 resp. H*W % 4 == 0).  Same rounding points as the separate ATen passes.
  *   ta_bias_act        y = y + bias[c], then clamp_min(., 0) if relu                       (in place)
  *   ta_bias_add_relu   y = clamp_min((y + bias[c]) + (other [+ bias_other[c]]), 0)           (in place; bias_other nullable)
  *   ta_relu_mask       out = y <= 0 ? 0 : ga [+ gb]          (gb nullable; out may alias ga) = threshold_backward(ga + gb, y, 0) */

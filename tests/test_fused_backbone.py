@@ -110,9 +110,10 @@ def test_fused_path_steps_aside(monkeypatch):
 def test_glue_kernels_against_aten(monkeypatch):
     host_kernels.install(monkeypatch)
     gen = torch.Generator().manual_seed(5)
-    for fmt in (torch.contiguous_format, torch.channels_last):
-        y = torch.randn(2, 8, 6, 10, generator=gen).contiguous(memory_format=fmt)
-        o = torch.randn(2, 8, 6, 10, generator=gen).contiguous(memory_format=fmt)
+    for fmt, hw in ((torch.contiguous_format, (6, 10)), (torch.channels_last, (6, 10)), (torch.contiguous_format, (7, 7)),
+                    (torch.channels_last, (7, 7))):
+        y = torch.randn(4, 8, *hw, generator=gen).contiguous(memory_format=fmt)
+        o = torch.randn(4, 8, *hw, generator=gen).contiguous(memory_format=fmt)
         b, bo = torch.randn(8, generator=gen), torch.randn(8, generator=gen)
         y[0, 0, 0, 0] = float("nan")
         ref = (y + b.view(1, -1, 1, 1)).clamp_min(0)

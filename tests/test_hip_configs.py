@@ -229,12 +229,17 @@ def test_fold_bn_channels_last_is_the_same_surrogate(monkeypatch, name):
 
 @pytest.mark.parametrize("name,nhwc,batch", [("resnet50", "1", 4), ("resnet50", "0", 2), ("resnet18", "1", 4)])
 def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
-    """backbones/fused.py (the surrogate's bias / ReLU / residual / threshold passes fused, csrc/glue.hip) against the plain
-    module path of the same folded surrogate on the device: same MIOpen convolutions, same rounding points -> the logits and
-    the input gradient must agree to the last bit wherever MIOpen is deterministic, and to 1e-6 relative in any case
-    (some backward-data kernels accumulate with atomics).  The CPU tier (tests/test_fused_backbone.py) shows exact equality."""
+    """backbones/fused.py (the surrogate's bias / ReLU / residual / threshold passes fused, csrc/glue.hip; the stem's input
+    gradient on csrc/stem.hip) against the plain module path of the same folded surrogate, both on the device, both against
+    the fp64 truth.  On the CPU tier the two are EQUAL bit for bit (tests/test_fused_backbone.py); on the device MIOpen may
+    pick other algorithms for a convolution called without its bias, and a seeded random-init ResNet amplifies any
+    rounding-level change of an activation to ~1e-2 of the input gradient (two CPUs differ as much) --
+    so the claim checked here is the one of test_fold_bn_channels_last_is_the_same_surrogate: as accurate as the module
+    path (<= 4 x its error vs fp64, or 1e-5), same gradient sign on >= 99 %, logits equal to rounding."""
     x = u8_images(batch, 224, 5).float() / 255
-    label = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    label_cpu = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(6))
+    label = label_cpu.to(DEV)
+    logits64, grad64 = _truth(name, x, label_cpu)
     monkeypatch.setenv("TA_FOLD_BN", "1")
     monkeypatch.setenv("TA_CHANNELS_LAST", nhwc)
     atk = ta.load_attack_class("mifgsm")(model_name=name)
@@ -244,11 +249,15 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
         xd = x.to(DEV).requires_grad_(True)
         logits = atk.model(xd)
         grad = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xd)[0]
-        got[tag] = (logits.detach().cpu(), grad.cpu())
-    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())       # noqa: E731
-    print("%s nhwc=%s: fused vs module path: logits equal %s (rel %.1e), input-gradient equal %s (rel %.1e); fused run-to-run "
-          "gradient equal %s" % (name, nhwc, torch.equal(got["fused"][0], got["module"][0]), rel(got["fused"][0], got["module"][0]),
-                                 torch.equal(got["fused"][1], got["module"][1]), rel(got["fused"][1], got["module"][1]),
-                                 torch.equal(got["fused"][1], got["fused again"][1])))
-    assert rel(got["fused"][0], got["module"][0]) <= 1e-6 and rel(got["fused"][1], got["module"][1]) <= 1e-6
-    assert float((torch.sign(got["fused"][1]) != torch.sign(got["module"][1])).float().mean()) <= 1e-4
+        got[tag] = (logits.detach().cpu().double(), grad.cpu().double())
+    rel = lambda a, b: float((a - b).norm() / b.norm())       # noqa: E731
+    e_mod = (rel(got["module"][0], logits64), rel(got["module"][1], grad64))
+    e_fus = (rel(got["fused"][0], logits64), rel(got["fused"][1], grad64))
+    flips = float((torch.sign(got["fused"][1]) != torch.sign(got["module"][1])).float().mean())
+    print("%s nhwc=%s: rel-L2 error vs fp64 truth (logits, input-gradient): module path %.2e %.2e; fused glue %.2e %.2e; fused vs "
+          "module: logits rel %.1e, gradient rel %.1e, sign flips %.3f%%; fused run-to-run gradient equal: %s"
+          % (name, nhwc, e_mod[0], e_mod[1], e_fus[0], e_fus[1], rel(got["fused"][0], got["module"][0]),
+             rel(got["fused"][1], got["module"][1]), 100 * flips, torch.equal(got["fused"][1], got["fused again"][1])))
+    assert rel(got["fused"][0], got["module"][0]) <= 1e-5
+    assert e_fus[0] <= max(4 * e_mod[0], 1e-5) and e_fus[1] <= max(4 * e_mod[1], 1e-5)
+    assert flips <= 0.01

@@ -25,22 +25,27 @@ struct ChannelOf {
     }
 };
 
+// the four bias values of the 16-byte group starting at element i.  mode 0: NHWC, four consecutive channels (C % 4 == 0);
+// mode 1: NCHW with H*W % 4 == 0, one channel for the whole group; mode 2: NCHW with any H*W (a 7 x 7 map), per element
+__device__ __forceinline__ float4 bias4(const float* __restrict__ bias, const ChannelOf& ch, unsigned i, int mode) {
+    if (mode == 0) return *reinterpret_cast<const float4*>(bias + ch(i));
+    if (mode == 1) {
+        const float s = bias[ch(i)];
+        return make_float4(s, s, s, s);
+    }
+    return make_float4(bias[ch(i)], bias[ch(i + 1)], bias[ch(i + 2)], bias[ch(i + 3)]);
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(kBlock) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, ChannelOf ch,
-                                                          unsigned numel, bool vec_channels) {
+                                                          unsigned numel, int mode) {
     const unsigned base = blockIdx.x * kTile;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
         const unsigned i = base + (u * kBlock + threadIdx.x) * kVec;
         if (i + kVec <= numel) {
             float4 a = *reinterpret_cast<const float4*>(y + i);
-            float4 b;
-            if (vec_channels) {                       // NHWC: four consecutive channels (C % 4 == 0)
-                b = *reinterpret_cast<const float4*>(bias + ch(i));
-            } else {                                  // NCHW: one channel for the whole group (inner % 4 == 0)
-                const float s = bias[ch(i)];
-                b = make_float4(s, s, s, s);
-            }
+            const float4 b = bias4(bias, ch, i, mode);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             if (RELU) { a.x = relu_like_aten(a.x); a.y = relu_like_aten(a.y); a.z = relu_like_aten(a.z); a.w = relu_like_aten(a.w); }
             *reinterpret_cast<float4*>(y + i) = a;
@@ -57,7 +62,7 @@ template <bool HAS_BO>
 __global__ __launch_bounds__(kBlock) void bias_add_relu_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                const float* __restrict__ other,
                                                                const float* __restrict__ bias_other, ChannelOf ch,
-                                                               unsigned numel, bool vec_channels) {
+                                                               unsigned numel, int mode) {
     const unsigned base = blockIdx.x * kTile;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -65,17 +70,11 @@ __global__ __launch_bounds__(kBlock) void bias_add_relu_kernel(float* __restrict
         if (i + kVec <= numel) {
             float4 a = *reinterpret_cast<const float4*>(y + i);
             float4 o = *reinterpret_cast<const float4*>(other + i);
-            float4 b, bo = make_float4(0.f, 0.f, 0.f, 0.f);
-            const unsigned c = ch(i);
-            if (vec_channels) {
-                b = *reinterpret_cast<const float4*>(bias + c);
-                if (HAS_BO) bo = *reinterpret_cast<const float4*>(bias_other + c);
-            } else {
-                const float s = bias[c];
-                b = make_float4(s, s, s, s);
-                if (HAS_BO) { const float t = bias_other[c]; bo = make_float4(t, t, t, t); }
+            const float4 b = bias4(bias, ch, i, mode);
+            if (HAS_BO) {                                                               // the shortcut's own bias first
+                const float4 bo = bias4(bias_other, ch, i, mode);
+                o.x += bo.x; o.y += bo.y; o.z += bo.z; o.w += bo.w;
             }
-            if (HAS_BO) { o.x += bo.x; o.y += bo.y; o.z += bo.z; o.w += bo.w; }        // the shortcut's own bias first
             a.x = relu_like_aten((a.x + b.x) + o.x);
             a.y = relu_like_aten((a.y + b.y) + o.y);
             a.z = relu_like_aten((a.z + b.z) + o.z);
@@ -123,16 +122,14 @@ __global__ __launch_bounds__(kBlock) void relu_mask_kernel(const float* ga, cons
 
 using namespace ta;
 
-static int glue_shape(int64_t numel, int channels, int64_t inner, ChannelOf* ch, bool* vec_channels) {
+static int glue_shape(int64_t numel, int channels, int64_t inner, ChannelOf* ch, int* mode) {
     TA_REQUIRE(numel > 0 && numel < (1ll << 32) - kTile && channels > 0 && inner > 0 && inner < (1ll << 31),
                "shape (numel=%lld, channels=%d, inner=%lld)", (long long)numel, channels, (long long)inner);
-    TA_REQUIRE(numel % 4 == 0 && ((inner == 1 && channels % 4 == 0) || (inner > 1 && inner % 4 == 0)),
-               "16-byte groups must not straddle channels (numel=%lld, channels=%d, inner=%lld)", (long long)numel, channels,
-               (long long)inner);
+    TA_REQUIRE(numel % 4 == 0, "numel=%lld is not a multiple of 4", (long long)numel);
     ch->inner = static_cast<unsigned>(inner);
     ch->channels = static_cast<unsigned>(channels);
     ch->mask = (channels & (channels - 1)) == 0 ? static_cast<unsigned>(channels - 1) : 0u;
-    *vec_channels = inner == 1;
+    *mode = (inner == 1 && channels % 4 == 0) ? 0 : (inner > 1 && inner % 4 == 0) ? 1 : 2;
     return 0;
 }
 
@@ -141,7 +138,7 @@ static int glue_shape(int64_t numel, int channels, int64_t inner, ChannelOf* ch,
 extern "C" int ta_bias_act(float* y, const float* bias, int relu, int64_t numel, int channels, int64_t inner, void* stream) {
     TA_REQUIRE(y && bias && aligned16(y) && aligned16(bias), "null or unaligned pointer");
     ChannelOf ch;
-    bool vc;
+    int vc;
     if (int rc = glue_shape(numel, channels, inner, &ch, &vc)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (relu)
@@ -156,7 +153,7 @@ extern "C" int ta_bias_add_relu(float* y, const float* bias, const float* other,
     TA_REQUIRE(y && bias && other && y != other && aligned16(y) && aligned16(bias) && aligned16(other) &&
                (bias_other == nullptr || aligned16(bias_other)), "null, aliased or unaligned pointer");
     ChannelOf ch;
-    bool vc;
+    int vc;
     if (int rc = glue_shape(numel, channels, inner, &ch, &vc)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bias_other)
