@@ -65,6 +65,12 @@ benchpair)
   timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue.json
   TA_FUSED_GLUE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_module_path.json
   timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_b32.json ;;
+stempair)
+  # the default line with the stem's input gradient on csrc/stem.hip (default) and on MIOpen
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_stem.json
+  TA_STEM_KERNEL=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_miopen_stem.json ;;
+fusedtest)
+  timeout 600 python -m pytest tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider -k "fused" 2>&1 | grep -v Warning | tee $OUT/fused_pytest.txt | tail -12 ;;
 ktrace)
   # rocprofv3's own durations of every kernel of the stand-alone bench (event timing adds the marker overhead)
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace -o trace -- python $R/tools/kernel_bench.py > $R/$OUT/ktrace.log 2>&1 )

@@ -30,7 +30,8 @@ def timed(fn, reps=20):
 def main():
     _hip.load()
     out = {}
-    for n in (32, 160):
+    sizes = [int(v) for v in os.environ.get("TA_BENCH_N", "32,160").split(",")]
+    for n in sizes:
         sets = [[torch.randn(n, 3, 224, 224, device=DEV) * 1e-3 for _ in range(4)] for _ in range(3)]
         big = [torch.empty(5 * n, 3, 224, 224, device=DEV) for _ in range(2)] if n == 32 else None
         big15 = [torch.empty(15 * n, 3, 224, 224, device=DEV) for _ in range(2)] if n == 32 else None
@@ -85,6 +86,18 @@ def main():
         rec("glue_relu_mask_add_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3],
                                                                       gb=acts[3 + (i + 1) % 3])), 16 * ea)
         del acts
+        # the stem convolution's input gradient (7x7 / stride 2 / 3 -> 64): csrc/stem.hip against MIOpen's backward-data
+        wst = (torch.randn(64, 3, 7, 7, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)
+        dys = [torch.randn(n, 64, 112, 112, device=DEV).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+        xs = torch.empty(n, 3, 224, 224, device=DEV)
+        w2 = _hip.stem7s2_prepare(wst)
+        flop_per_elem = 2 * 64 * 49 / 4                  # per element of dx: 49 taps / 4 phases x 64 channels, multiply + add
+        rec("stem7s2_input_grad_mfma", timed(lambda i: _hip.stem7s2_input_grad(dys[i % 2], w2, xs), reps=10), 4 + 4 * 64 / 12, flop_per_elem)
+        torch.backends.cudnn.benchmark = True
+        rec("stem7s2_input_grad_miopen", timed(lambda i: torch.ops.aten.convolution_backward(
+            dys[i % 2], xs, wst, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [True, False, False]), reps=10), 4 + 4 * 64 / 12,
+            flop_per_elem)
+        del dys, xs
         if n == 32:
             import random
             import numpy as np
