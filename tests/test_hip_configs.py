@@ -244,8 +244,10 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
     monkeypatch.setenv("TA_CHANNELS_LAST", nhwc)
     atk = ta.load_attack_class("mifgsm")(model_name=name)
     got = {}
-    for tag, flag in (("module", "0"), ("fused", "1"), ("fused again", "1")):
+    for tag, flag, stem in (("module", "0", "1"), ("module again", "0", "1"), ("fused", "1", "1"), ("fused again", "1", "1"),
+                            ("fused, MIOpen stem", "1", "0")):
         monkeypatch.setenv("TA_FUSED_GLUE", flag)
+        monkeypatch.setenv("TA_STEM_KERNEL", stem)
         xd = x.to(DEV).requires_grad_(True)
         logits = atk.model(xd)
         grad = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xd)[0]
@@ -254,10 +256,40 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
     e_mod = (rel(got["module"][0], logits64), rel(got["module"][1], grad64))
     e_fus = (rel(got["fused"][0], logits64), rel(got["fused"][1], grad64))
     flips = float((torch.sign(got["fused"][1]) != torch.sign(got["module"][1])).float().mean())
-    print("%s nhwc=%s: rel-L2 error vs fp64 truth (logits, input-gradient): module path %.2e %.2e; fused glue %.2e %.2e; fused vs "
-          "module: logits rel %.1e, gradient rel %.1e, sign flips %.3f%%; fused run-to-run gradient equal: %s"
-          % (name, nhwc, e_mod[0], e_mod[1], e_fus[0], e_fus[1], rel(got["fused"][0], got["module"][0]),
-             rel(got["fused"][1], got["module"][1]), 100 * flips, torch.equal(got["fused"][1], got["fused again"][1])))
+    e_mio = (rel(got["fused, MIOpen stem"][0], logits64), rel(got["fused, MIOpen stem"][1], grad64))
+    print("%s nhwc=%s: rel-L2 error vs fp64 truth (logits, input-gradient): module path %.2e %.2e; fused glue %.2e %.2e (with "
+          "MIOpen's stem backward %.2e %.2e); fused vs module: logits rel %.1e, gradient rel %.1e, sign flips %.3f%%; run-to-run "
+          "gradient equal: module %s, fused %s"
+          % (name, nhwc, e_mod[0], e_mod[1], e_fus[0], e_fus[1], e_mio[0], e_mio[1], rel(got["fused"][0], got["module"][0]),
+             rel(got["fused"][1], got["module"][1]), 100 * flips, torch.equal(got["module"][1], got["module again"][1]),
+             torch.equal(got["fused"][1], got["fused again"][1])))
     assert rel(got["fused"][0], got["module"][0]) <= 1e-5
     assert e_fus[0] <= max(4 * e_mod[0], 1e-5) and e_fus[1] <= max(4 * e_mod[1], 1e-5)
     assert flips <= 0.01
+
+
+@pytest.mark.parametrize("n,oh,ow", [(4, 112, 112), (1, 9, 37), (2, 150, 150)])
+def test_stem_input_grad_kernel_on_device(n, oh, ow):
+    """csrc/stem.hip on MI355X against MIOpen's backward-data and an fp64 evaluation of the same convolution backward: at
+    least as accurate as MIOpen (<= 4 x its error, or 2e-6 of max|dx|) -- the 224 / 299-pixel stems and a ragged shape"""
+    gen = torch.Generator().manual_seed(7)
+    w = torch.randn(64, 3, 7, 7, generator=gen) * 0.05
+    dy = torch.randn(n, 64, oh, ow, generator=gen)
+    spec = ([2, 2], [3, 3], [1, 1], False, [0, 0], 1, [True, False, False])
+    truth = torch.ops.aten.convolution_backward(dy.double(), torch.empty(n, 3, 2 * oh, 2 * ow).double(), w.double(), None, *spec)[0]
+    dyd = dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    xd = torch.empty(n, 3, 2 * oh, 2 * ow, device=DEV)
+    ref = torch.ops.aten.convolution_backward(dyd, xd, wd, None, *spec)[0].cpu().double()
+    got = _hip.stem7s2_input_grad(dyd, _hip.stem7s2_prepare(wd), torch.full_like(xd, float("nan"))).cpu().double()
+    again = _hip.stem7s2_input_grad(dyd, _hip.stem7s2_prepare(wd), torch.full_like(xd, float("nan"))).cpu().double()
+    scale = float(truth.abs().max())
+    e_got, e_ref = float((got - truth).abs().max()) / scale, float((ref - truth).abs().max()) / scale
+    bad = (got - truth).abs() > 1e-4 * scale
+    print("stem input gradient [%d, 64, %d, %d]: max error / max|dx| vs fp64: csrc/stem.hip %.2e, MIOpen %.2e; elements off by more "
+          "than 1e-4: %d of %d; run-to-run equal: %s" % (n, oh, ow, e_got, e_ref, int(bad.sum()), bad.numel(), torch.equal(got, again)))
+    if bad.any():
+        idx = bad.nonzero()[:8].tolist()
+        print("  first offenders (n, c, y, x):", idx)
+    assert not torch.isnan(got).any() and torch.equal(got, again)
+    assert e_got <= max(4 * e_ref, 2e-6)

@@ -69,7 +69,7 @@ def main():
         rec("quantize_u8", timed(lambda i: _hip.quantize_u8_nhwc(sets[i % 3][0], sets[i % 3][1], u8)), 9)
         rec("normalize_fwd", timed(lambda i: _hip.normalize_fwd(sets[i % 3][0], sets[i % 3][1], mean, std)), 8)
         rec("normalize_bwd_partials", timed(lambda i: _hip.load().ta_normalize_bwd(
-            sets[i % 3][0].data_ptr(), sets[i % 3][1].data_ptr(), std.data_ptr(), ws.data_ptr(), n, 3, 224 * 224,
+            sets[i % 3][0].data_ptr(), sets[i % 3][1].data_ptr(), std.data_ptr(), None, ws.data_ptr(), n, 3, 224 * 224,
             torch.cuda.current_stream().cuda_stream)), 8)
         rec("momentum_hook", timed(lambda i: _hip.momentum(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2], 1.0)), 12)
         rec("update_delta_hook", timed(lambda i: _hip.update_delta_linf(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
