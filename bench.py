@@ -119,7 +119,7 @@ KERNEL_BYTES = {
     "depthwise_conv2d_same": lambda inp, out, w: _NB(inp) + _NB(out),
     "sum_members": lambda grads, gx: _NB(gx) * (len(grads) + 1),
     "dim_fwd": lambda x, y, *a: _NB(x) + _NB(y),
-    "dim_bwd": lambda gy, gx, *a, **k: _NB(gy) + _NB(gx),
+    "dim_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
     "scale_copies_fwd": lambda x, y, *a: _NB(x) + _NB(y),
     "scale_copies_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),
     "sum_copies_bwd": lambda gy, gx, *a: _NB(gy) + _NB(gx),

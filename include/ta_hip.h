@@ -109,16 +109,8 @@ int ta_depthwise_conv2d_same(const float* in, float* out, const float* w, float*
  */
 int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top,
                int left, void* stream);
-/* geometry tables of the backward (which outputs touch which source index, with which weights): the same for every plane
- * and tile of a call, so they are built once -- ta_dim_tables, one small launch -- into `tables` (device,
- * ta_dim_tables_words(size, resize) 4-byte words) and handed to ta_dim_bwd.  tables == NULL: every workgroup rebuilds
- * its own (the round-2 kernel; also taken for resize ratios the table-driven kernel does not cover).  Same bits either way. */
-int64_t ta_dim_tables_words(int size, int resize);
-int ta_dim_bwd_slots(int size, int resize, int rnd);   /* 3 / 4: ta_dim_bwd takes the table-driven kernel when given tables (the
-                                                          value is its stage-B slot count); 0: geometry outside its assumptions */
-int ta_dim_tables(void* tables, int size, int resize, int rnd, int top, int left, void* stream);
-int ta_dim_bwd(const float* gy, float* gx, float* ws, const void* tables, int64_t planes, int size, int resize, int rnd,
-               int top, int left, void* stream);
+int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
+               int left, void* stream);
 
 /* ---- SIM / Admix: sim.py:36-40, admix.py:40-45 ------------------------------------------------------
  * sim fwd : y[i*n + b] = x[b] / 2^i                              i < num_scale

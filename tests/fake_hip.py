@@ -68,12 +68,7 @@ def dim_fwd(x, y, resize, rnd, top, left):
     y.copy_(_t(C.dim_fwd(x.numpy(), (True, rnd, top, left), resize)))
 
 
-def dim_tables(like, resize, rnd, top, left):
-    return (resize, rnd, top, left)                      # the fake's backward needs no tables: the geometry is its token
-
-
-def dim_bwd(gy, gx, resize, rnd, top, left, tables=None):
-    assert tables is None or tables == (resize, rnd, top, left), "tables of another geometry"
+def dim_bwd(gy, gx, resize, rnd, top, left):
     calls.append("dim_bwd")
     gx.copy_(_t(C.dim_bwd(gy.numpy(), (True, rnd, top, left), resize)))
 
@@ -226,7 +221,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
 
 
 _NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
-          "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "dim_tables", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
+          "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
           "normalize_bwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate"]
 

@@ -235,7 +235,10 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
     pick other algorithms for a convolution called without its bias, and a seeded random-init ResNet amplifies any
     rounding-level change of an activation to ~1e-2 of the input gradient (two CPUs differ as much) --
     so the claim checked here is the one of test_fold_bn_channels_last_is_the_same_surrogate: as accurate as the module
-    path (<= 4 x its error vs fp64, or 1e-5), same gradient sign on >= 99 %, logits equal to rounding."""
+    path, same gradient sign on >= 99 %, logits equal to rounding.  "As accurate" has a floor of 1e-2: the module path's OWN
+    error on the well-conditioned ResNet-18 moves between 9e-7 and 3e-3 from run to run with MIOpen's algorithm choice (r3c /
+    r3d: Winograd variants for the 3 x 3 convolutions once the find-db knows them), and neither path is run-to-run
+    deterministic on the device (atomic accumulation in backward-data and max-pool backward)."""
     x = u8_images(batch, 224, 5).float() / 255
     label_cpu = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(6))
     label = label_cpu.to(DEV)
@@ -264,7 +267,7 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
              rel(got["fused"][1], got["module"][1]), 100 * flips, torch.equal(got["module"][1], got["module again"][1]),
              torch.equal(got["fused"][1], got["fused again"][1])))
     assert rel(got["fused"][0], got["module"][0]) <= 1e-5
-    assert e_fus[0] <= max(4 * e_mod[0], 1e-5) and e_fus[1] <= max(4 * e_mod[1], 1e-5)
+    assert e_fus[0] <= max(4 * e_mod[0], 1e-5) and e_fus[1] <= max(4 * e_mod[1], 1e-2)
     assert flips <= 0.01
 
 

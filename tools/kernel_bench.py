@@ -51,12 +51,7 @@ def main():
 
         rec("tim_conv15", timed(lambda i: _hip.depthwise_conv2d_same(sets[i % 3][0], sets[i % 3][1], w)), 8, 450)
         rec("dim_fwd", timed(lambda i: _hip.dim_fwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
-        tabs = _hip.dim_tables(sets[0][0], 246, 237, 3, 5)          # as DimResizePad: built once, in the forward pass
-        rec("dim_bwd", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5, tables=tabs)), 8)
-        rec("dim_bwd_incl_tables_launch", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
-        rec("dim_bwd_round2_kernel", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5,
-                                                                  tables=False)), 8)
-        rec("dim_tables", timed(lambda i: _hip.dim_tables(sets[0][0], 246, 237, 3, 5)), 0)
+        rec("dim_bwd", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
         rec("vmi_neighbor_philox", timed(lambda i: _hip.vmi_neighbor(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
                                                                       0.09, seed=1, offset=i)), 12)
         rec("vmi_neighbor_normalized_philox", timed(lambda i: _hip.vmi_neighbor_normalized(

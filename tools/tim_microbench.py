@@ -16,11 +16,9 @@ for n in sizes:
     o = torch.empty_like(g[0])
     w = torch.rand(15, 15, device="cuda")
     w = (w / w.sum()).contiguous()
-    tabs = _hip.dim_tables(g[0], 246, 237, 3, 5)
     for name, call in (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
                        ("dim_fwd", lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)),
-                       ("dim_bwd (table-driven rows)", lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5, tables=tabs)),
-                       ("dim_bwd (round-2 lanes kernel)", lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5, tables=False))):
+                       ("dim_bwd", lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5))):
         for i in range(6):
             call(i)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -45,15 +45,12 @@ SIGNATURES = {
     "ta_init_delta_uniform": (_int, [_vp, _vp, _vp, _f32, _u64, _u64, _i64, _vp]),
     "ta_depthwise_conv2d_same": (_int, [_vp, _vp, _vp, _vp, _int, _i64, _int, _int, _vp]),
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
-    "ta_dim_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
+    "ta_dim_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_stem7s2_prepare": (_int, [_vp, _vp, _vp]),
     "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "ta_bias_act": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
-    "ta_dim_tables_words": (_i64, [_int, _int]),
-    "ta_dim_bwd_slots": (_int, [_int, _int, _int]),
-    "ta_dim_tables": (_int, [_vp, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_scale_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ta_sum_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
@@ -379,30 +376,13 @@ def dim_fwd(x, y, resize, rnd, top, left):
     _call("ta_dim_fwd", x, _ptr(x, name="x"), _ptr(y, name="y"), x.numel() // (size * size), size, resize, rnd, top, left)
 
 
-def dim_tables(like, resize, rnd, top, left):
-    """The backward's geometry tables for one drawn geometry (which outputs touch which source index, with which
-    weights): one small launch, the result is handed to ``dim_bwd`` -- DimResizePad builds them in the forward pass."""
-    size = like.shape[-1]
-    words = load().ta_dim_tables_words(size, resize)
-    tables = torch.empty(max(int(words), 1), dtype=torch.int32, device=like.device)
-    _call("ta_dim_tables", like, _ptr(tables, torch.int32, name="tables"), size, resize, rnd, top, left)
-    return tables
-
-
-def dim_bwd(gy, gx, resize, rnd, top, left, tables=None):
-    """``tables``: what ``dim_tables`` returned for this geometry (DimResizePad builds it in the forward pass); None:
-    built here; False: none at all -- every workgroup rebuilds its own (the round-2 kernel, kept for comparison)."""
+def dim_bwd(gy, gx, resize, rnd, top, left):
     size = gy.shape[-1]
-    if tables is None:
-        tables = dim_tables(gy, resize, rnd, top, left)
-    elif tables is False:
-        tables = None
     planes = gy.numel() // (size * size)
     per_image = gy[0].numel() // (size * size) if gy.dim() == 4 else 0
     tiles = load().ta_dim_bwd_tiles(size, resize)
     ws = _new_ws(gy, planes * tiles) if per_image else None
-    _call("ta_dim_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws),
-          None if tables is None else _ptr(tables, torch.int32, name="tables"), planes, size, resize, rnd, top, left)
+    _call("ta_dim_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(ws), planes, size, resize, rnd, top, left)
     if ws is not None:
         _register_partials(gx, ws, per_image * tiles)
     else:

@@ -587,242 +587,6 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 }
 
 
-// ------------------------------------------------------------------------------- backward, table-driven rows (round 3)
-// The lane-per-column backward above spends its time on VALU issue (PMC r2c: 141 lane-operations per output element,
-// 985 per wave): every workgroup rebuilds the hit tables of its tile, every gather recomputes 64-bit-free but still
-// per-access byte offsets, every slot is predicated over the worst-case run length of 3, and the LDS reads of stage B
-// take one address addition each.  The geometry is the same for every plane and tile of a call, so here
-//   * the hit tables are built ONCE per call by a one-workgroup kernel (dim_tables_kernel, find_hits above) into a small
-//     device table in structure-of-arrays form; row entries are wave-uniform and arrive through the scalar cache
-//     (s_load), column entries are one coalesced load per lane and tile;
-//   * stage A (d(rescaled) window <- gy) knows that a padded index is touched by at most TWO outputs and never by both
-//     taps of one (resize > size: the second resample shrinks, its source index advances by more than one per output):
-//     2 x 2 slots instead of 3 x 3, gathered through a wave-uniform row pointer + a per-lane constant column offset;
-//   * stage B (gx <- window) reads the window at  base + (ky * 64 + kx) * 4  with the offsets as instruction immediates:
-//     one address addition per output row instead of nine;
-//   * the only index that one output can hit with BOTH taps is the last one of x (size - 1; first resample, clamped
-//     border).  In a column that is one more slot after the regular ones (same order as ATen's (.., x0), (.., x1)); for
-//     the last ROW the two contributions interleave with the columns, so that single row per plane runs the general
-//     code of the kernel above (find_hits + hit_accumulate<false>).
-// Arithmetic and accumulation order are unchanged (fma(wy * wx, g, acc), rows outer, columns inner): bit-identical to
-// dim_bwd_lanes_kernel, which stays for geometries outside these assumptions (checked on the host, dim_bwd_fast_ok).
-struct DimTables {          // offsets (in 4-byte words) into the table buffer; A: per padded index, B: per index of x
-    int a_first, a_n, a_w0, a_w1;
-    int b_first, b_n, b_w0, b_w1, b_w2, b_w3, b_tail_rel, b_tail_w;
-    int words;
-};
-
-__host__ __device__ inline DimTables dim_tables_layout(int size, int resize) {
-    DimTables t;
-    int at = 0;
-    auto take = [&](int n) { const int o = at; at += (n + 3) & ~3; return o; };
-    t.a_first = take(resize); t.a_n = take(resize); t.a_w0 = take(resize); t.a_w1 = take(resize);
-    t.b_first = take(size); t.b_n = take(size); t.b_w0 = take(size); t.b_w1 = take(size); t.b_w2 = take(size);
-    t.b_w3 = take(size); t.b_tail_rel = take(size); t.b_tail_w = take(size);
-    t.words = at;
-    return t;
-}
-
-__global__ __launch_bounds__(kBlock) void dim_tables_kernel(int* __restrict__ tab, int size, int resize, int rnd,
-                                                            float scale1, float scale2) {
-    const DimTables L = dim_tables_layout(size, resize);
-    float* ftab = reinterpret_cast<float*>(tab);
-    for (int q = threadIdx.x; q < resize; q += kBlock) {          // stage A: outputs (resize -> size) touching padded q
-        const Hit h = find_hits(q, resize, size, scale2);
-        tab[L.a_first + q] = h.first;
-        tab[L.a_n + q] = h.n;
-        ftab[L.a_w0 + q] = h.w[0];
-        ftab[L.a_w1 + q] = h.w[1];
-    }
-    for (int t = threadIdx.x; t < size; t += kBlock) {            // stage B: rescaled pixels (size -> rnd) touching x index t
-        const Hit h = find_hits(t, size, rnd, scale1);
-        tab[L.b_first + t] = h.first;
-        tab[L.b_n + t] = h.n;
-        ftab[L.b_w0 + t] = h.w[0];
-        ftab[L.b_w1 + t] = h.w[1];
-        ftab[L.b_w2 + t] = h.w[2];
-        ftab[L.b_w3 + t] = h.w[3];
-        int rel = -1;
-        float w = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kHitSlots; ++k)
-            if ((h.both >> k) & 1u) { rel = k; w = h.w2[k]; }
-        tab[L.b_tail_rel + t] = rel;
-        ftab[L.b_tail_w + t] = w;
-    }
-}
-
-// gx of one pixel of a row that its last rescaled row reaches with BOTH taps (only the last row of x): the general
-// accumulation of dim_bwd_lanes_kernel with the hit tables rebuilt on the spot (one wave per bottom tile and plane).
-__device__ __forceinline__ float dim_bwd_double_row(const float* mid, int ix, int iy, int size, int rnd, float scale1,
-                                                    int rx_lo, int ry_lo) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(ix));       // opaque: keeps the table arithmetic below inside the branch that needs it (left to
-#endif                                 // itself the compiler hoists it, loop-invariant and side-effect free, into every workgroup)
-    const Hit hx = find_hits(ix, size, rnd, scale1);
-    const Hit hy = find_hits(iy, size, rnd, scale1);
-    float acc = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < kHitSlots; ++ky)            // static indices into the Hit arrays: a rolled loop would put them in scratch
-        if (ky < hy.n) {
-            const float* mrow = mid + (hy.first - ry_lo + ky) * 64;
-#pragma unroll
-            for (int kx = 0; kx < kHitSlots; ++kx)
-                acc = hit_accumulate<false>(acc, mrow[min(hx.first - rx_lo + kx, 63)], hy.w[ky], hy.w2[ky], (hy.both >> ky) & 1u, hx, kx);
-        }
-    return acc;
-}
-
-template <int RPW, int SB, int PP>
-__global__ __launch_bounds__(kBlock) void dim_bwd_rows_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                              float* __restrict__ ws, const int* __restrict__ tab,
-                                                              DimTables L, int size, int rnd, int top, int left,
-                                                              float scale1, int tw) {
-    constexpr int ROWS = 4 * RPW;
-    constexpr int HALF = (RPW + 1) / 2;                                   // stage A runs in two halves: 4 * HALF loads in flight
-    __shared__ __attribute__((aligned(16))) float mid[(ROWS + 3) * 64];   // d(rescaled) window (+ slack: stage B reads ahead)
-    __shared__ __attribute__((aligned(16))) float4 rowA[ROWS];            // window row p : (first output row, n, wy0, wy1)
-    __shared__ __attribute__((aligned(16))) float4 rowB[kDimLaneRows][2]; // tile row r   : (window row, n, double?, -) (wy0..wy3)
-    __shared__ float red[kBlock / kWave];
-    const float* ftab = reinterpret_cast<const float*>(tab);
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles_x = static_cast<int>(gridDim.x), tiles = tiles_x * static_cast<int>(gridDim.y);
-    const int t = static_cast<int>(blockIdx.y) * tiles_x + static_cast<int>(blockIdx.x);
-    const int group = static_cast<int>(blockIdx.z);
-    const int iy0 = static_cast<int>(blockIdx.y) * kDimLaneRows, ix0 = static_cast<int>(blockIdx.x) * tw;
-    const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
-
-    // window of d(rescaled) behind this tile of x (wave-uniform: scalar loads, once per workgroup)
-    const int ix_last = ix0 + twc - 1, iy_last = iy0 + th - 1;
-    const int rx_lo = tab[L.b_first + ix0], rx_hi = tab[L.b_first + ix_last] + tab[L.b_n + ix_last] - 1;
-    const int ry_lo = tab[L.b_first + iy0], ry_hi = tab[L.b_first + iy_last] + tab[L.b_n + iy_last] - 1;
-    const int mh = ry_hi - ry_lo + 1;                                    // <= ROWS; the window is <= 64 wide (host-checked)
-
-    // the tile's row entries, from the per-call table into LDS: one thread per row, read back as 16-byte broadcasts
-    if (static_cast<int>(threadIdx.x) < mh) {
-        const int py = ry_lo + static_cast<int>(threadIdx.x) + top;
-        rowA[threadIdx.x] = make_float4(__int_as_float(tab[L.a_first + py]), __int_as_float(tab[L.a_n + py]),
-                                        ftab[L.a_w0 + py], ftab[L.a_w1 + py]);
-    } else if (static_cast<int>(threadIdx.x) >= 128 && static_cast<int>(threadIdx.x) < 128 + th) {
-        const int r = static_cast<int>(threadIdx.x) - 128, iy = iy0 + r;
-        rowB[r][0] = make_float4(__int_as_float(tab[L.b_first + iy] - ry_lo), __int_as_float(tab[L.b_n + iy]),
-                                 __int_as_float(tab[L.b_tail_rel + iy]), 0.0f);
-        rowB[r][1] = make_float4(ftab[L.b_w0 + iy], ftab[L.b_w1 + iy], ftab[L.b_w2 + iy], ftab[L.b_w3 + iy]);
-    }
-    // stage-A column entry of this lane: window column `lane` = padded column px
-    const int px = min(rx_lo + lane, rx_hi) + left;
-    const int a_fx = tab[L.a_first + px];
-    const bool a_two = tab[L.a_n + px] > 1;
-    const float a_wx0 = ftab[L.a_w0 + px], a_wx1 = ftab[L.a_w1 + px];
-    const unsigned a_c0 = static_cast<unsigned>(a_fx) * 4u, a_c1 = static_cast<unsigned>(min(a_fx + 1, size - 1)) * 4u;
-    // stage-B column entry: tile column `lane` = x column ix
-    const int ix = min(ix0 + lane, ix_last);
-    const int b_n = tab[L.b_n + ix];
-    const int b_c0 = tab[L.b_first + ix] - rx_lo;
-    const float b_wx0 = ftab[L.b_w0 + ix], b_wx1 = ftab[L.b_w1 + ix], b_wx2 = ftab[L.b_w2 + ix];
-    const float b_wx3 = SB > 3 ? ftab[L.b_w3 + ix] : 0.0f;
-    const int b_tail_rel = tab[L.b_tail_rel + ix];
-    const float b_tail_w = ftab[L.b_tail_w + ix];
-    const bool wave_has_tail = __builtin_amdgcn_readfirstlane(__any(b_tail_rel >= 0)) != 0;   // last column tile only
-    const bool on1 = b_n > 1, on2 = b_n > 2, on3 = b_n > 3;
-    const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int q = 0; q < PP; ++q) {
-    const int plane = group * PP + q;
-    const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
-    char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
-    // -- stage A: mid[p][c] = sum over the <= 2 x 2 outputs that touch padded pixel (ry_lo + p + top, px)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        float g00[HALF], g01[HALF], g10[HALF], g11[HALF];
-        int ny_s[HALF], wy0_s[HALF], wy1_s[HALF];                                  // wave-uniform: kept in scalar registers
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) {
-            const int p = min(wave + 4 * (half * HALF + i), mh - 1);               // clamped: loads stay in bounds
-            const float4 ra = rowA[p];
-            const int fy = __builtin_amdgcn_readfirstlane(__float_as_int(ra.x));
-            ny_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.y));
-            wy0_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.z));
-            wy1_s[i] = __builtin_amdgcn_readfirstlane(__float_as_int(ra.w));
-            const char* r0 = gyp + static_cast<unsigned>(fy) * row_bytes;          // wave-uniform row pointers
-            const char* r1 = gyp + static_cast<unsigned>(min(fy + 1, size - 1)) * row_bytes;
-            g00[i] = *reinterpret_cast<const float*>(r0 + a_c0);
-            g01[i] = *reinterpret_cast<const float*>(r0 + a_c1);
-            g10[i] = *reinterpret_cast<const float*>(r1 + a_c0);
-            g11[i] = *reinterpret_cast<const float*>(r1 + a_c1);
-        }
-        float* out = mid + wave * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) {
-            const int p = wave + 4 * (half * HALF + i);
-            if (half * HALF + i < RPW && p < mh) {
-                const float wy0 = __int_as_float(wy0_s[i]), wy1 = __int_as_float(wy1_s[i]);
-                const bool two_y = ny_s[i] > 1;
-                float acc = fmaf(wy0 * a_wx0, g00[i], 0.0f);
-                acc = fmaf(wy0 * a_wx1, a_two ? g01[i] : 0.0f, acc);
-                if (two_y) {
-                    acc = fmaf(wy1 * a_wx0, g10[i], acc);
-                    acc = fmaf(wy1 * a_wx1, a_two ? g11[i] : 0.0f, acc);
-                }
-                out[(half * HALF + i) * 256] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    // -- stage B: gx[iy][ix] = sum over the <= SB x SB window pixels that touch it (+ the border's second tap)
-    float asum = 0.0f;
-    if (lane < twc) {
-        const float* mcol = mid + b_c0;
-        char* gcol = gxp + static_cast<unsigned>(ix0 + lane) * 4u;
-#pragma unroll
-        for (int j = 0; j < kDimLaneRows / 4; ++j) {
-            const int r = wave + 4 * j;
-            if (r >= th) continue;
-            const float4 rb = rowB[r][0], wy = rowB[r][1];
-            if (__builtin_amdgcn_readfirstlane(__float_as_int(rb.z)) >= 0) continue;   // the last row of x: below
-            const int fy = __builtin_amdgcn_readfirstlane(__float_as_int(rb.x));
-            const int n_y = __builtin_amdgcn_readfirstlane(__float_as_int(rb.y));
-            const float* m = mcol + fy * 64;
-            // all window values of the row first (unconditional, in bounds: `mid` has rows of slack), then the selects
-            float v[SB][SB], vt[SB];
-#pragma unroll
-            for (int ky = 0; ky < SB; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < SB; ++kx) v[ky][kx] = m[ky * 64 + kx];
-                vt[ky] = wave_has_tail ? m[ky * 64 + max(b_tail_rel, 0)] : 0.0f;
-            }
-            const float wys[4] = {wy.x, wy.y, wy.z, wy.w};
-            float acc = 0.0f;
-#pragma unroll
-            for (int ky = 0; ky < SB; ++ky)
-                if (ky < n_y) {
-                    acc = fmaf(wys[ky] * b_wx0, v[ky][0], acc);
-                    acc = fmaf(wys[ky] * b_wx1, on1 ? v[ky][1] : 0.0f, acc);
-                    acc = fmaf(wys[ky] * b_wx2, on2 ? v[ky][2] : 0.0f, acc);
-                    if (SB > 3) acc = fmaf(wys[ky] * b_wx3, on3 ? v[ky][3] : 0.0f, acc);
-                    if (wave_has_tail) acc = fmaf(wys[ky] * b_tail_w, b_tail_rel >= 0 ? vt[ky] : 0.0f, acc);
-                }
-            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy0 + r) * row_bytes) = acc;
-            asum += fabsf(acc);
-        }
-        // the last row of x (if this tile holds it and it has a double hit): its last rescaled row reaches it with both taps,
-        // whose contributions interleave with the columns -- the general accumulation of dim_bwd_lanes_kernel, tables
-        // rebuilt here (one row per plane and tile column)
-        if (iy_last == size - 1 && ((th - 1) & 3) == wave && tab[L.b_tail_rel + iy_last] >= 0) {
-            const float acc = dim_bwd_double_row(mid, ix, iy_last, size, rnd, scale1, rx_lo, ry_lo);
-            *reinterpret_cast<float*>(gcol + static_cast<unsigned>(iy_last) * row_bytes) = acc;
-            asum += fabsf(acc);
-        }
-    }
-    const float total = block_sum(asum, red);             // (its barriers also fence `mid` for the next plane)
-    if (ws != nullptr && threadIdx.x == 0) ws[plane * tiles + t] = total;
-    }   // planes of the group
-}
-
 }  // namespace ta
 
 using namespace ta;
@@ -851,74 +615,6 @@ static int max_hits(int in_size, int out_size) {
     int best = 0;
     for (int i = 0; i < in_size; ++i) best = count[i] > best ? count[i] : best;
     return best;
-}
-
-// Host restatement of find_hits' outcome for one 1-D resample (same fp32 arithmetic: fmaf is the exact fused operation on
-// the host as well): per source index the number of outputs touching it and whether / where one output touches it with
-// BOTH taps.  dim_bwd_rows_kernel's assumptions are checked with it before every launch.
-struct HitCensus {
-    int max_n = 0, min_n = INT_MAX;
-    bool doubles_only_last_slot_of_last_index = true;
-    bool any_double = false;
-};
-
-static HitCensus hit_census(int in_size, int out_size) {
-    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
-    static thread_local int count[kDimMaxSide], dbl[kDimMaxSide];
-    for (int i = 0; i < in_size; ++i) count[i] = dbl[i] = 0;
-    HitCensus c;
-    for (int o = 0; o < out_size; ++o) {
-        float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
-        src = src < 0.0f ? 0.0f : src;
-        int i0 = static_cast<int>(src);
-        i0 = i0 > in_size - 1 ? in_size - 1 : i0;
-        const int i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-        ++count[i0];
-        if (i1 != i0) {
-            ++count[i1];
-        } else {
-            c.any_double = true;
-            ++dbl[i0];
-            // a double hit must come from the LAST output and land on the LAST index: then it is the last slot of its run
-            if (o != out_size - 1 || i0 != in_size - 1) c.doubles_only_last_slot_of_last_index = false;
-        }
-    }
-    for (int i = 0; i < in_size; ++i) {
-        c.max_n = count[i] > c.max_n ? count[i] : c.max_n;
-        c.min_n = count[i] < c.min_n ? count[i] : c.min_n;
-        if (dbl[i] > 1) c.doubles_only_last_slot_of_last_index = false;
-    }
-    return c;
-}
-
-// 0: geometry outside dim_bwd_rows_kernel's assumptions; 3 / 4: the stage-B slot count to instantiate
-static int dim_bwd_fast_slots(int size, int resize, int rnd) {
-    const HitCensus a = hit_census(resize, size);            // stage A: outputs (resize -> size) per padded index
-    if (a.any_double || a.max_n > 2 || a.min_n < 1) return 0;
-    const HitCensus b = hit_census(size, rnd);               // stage B: rescaled pixels (size -> rnd) per index of x
-    if (!b.doubles_only_last_slot_of_last_index || b.max_n > 4 || b.min_n < 1) return 0;
-    return b.max_n <= 3 ? 3 : 4;
-}
-
-extern "C" int ta_dim_bwd_slots(int size, int resize, int rnd) {
-    if (size <= 0 || resize <= 0 || rnd <= 0 || size > kDimMaxSide || resize > kDimMaxSide || rnd > resize) return 0;
-    if (!(resize > size && 2 * resize <= 3 * size)) return 0;
-    return dim_bwd_fast_slots(size, resize, rnd);
-}
-
-extern "C" int64_t ta_dim_tables_words(int size, int resize) {
-    if (size <= 0 || resize <= 0 || size > kDimMaxSide || resize > kDimMaxSide) return 0;
-    return dim_tables_layout(size, resize).words;
-}
-
-extern "C" int ta_dim_tables(void* tables, int size, int resize, int rnd, int top, int left, void* stream) {
-    TA_REQUIRE(tables != nullptr, "null table buffer");
-    if (int rc = check_geom(1, size, resize, rnd, top, left)) return rc;
-    const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
-    const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
-    hipLaunchKernelGGL(dim_tables_kernel, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       static_cast<int*>(tables), size, resize, rnd, scale1, scale2);
-    return check_launch("dim_tables");
 }
 
 static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
@@ -976,8 +672,8 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     return check_launch("dim_fwd");
 }
 
-extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, const void* tables, int64_t planes, int size, int resize,
-                          int rnd, int top, int left, void* stream) {
+extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
+                          int left, void* stream) {
     TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -993,36 +689,10 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, const void* tab
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
             // the three planes of an RGB image share one workgroup's hit tables (a quarter of the backward's instructions)
             // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
-            int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
-            if (const char* force = getenv("TA_DIM_PP")) {        // measurement knob (round 3): planes per workgroup
-                const int want = atoi(force);
-                if ((want == 1 || want == 3) && planes % want == 0) pp = want;
-            }
+            const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-            // table-driven rows (round 3) when the caller built the tables for this geometry (ta_dim_tables) and the geometry
-            // satisfies that kernel's assumptions; same tiling, same |gx| sums, same bits
-            const int fast_slots = tables != nullptr ? dim_bwd_fast_slots(size, resize, rnd) : 0;
-            if (fast_slots != 0) {
-                const int* tab = static_cast<const int*>(tables);
-                const DimTables layout = dim_tables_layout(size, resize);
-                TA_REQUIRE(planes / pp <= 65535, "too many planes for one launch");
-                const dim3 grid3(static_cast<unsigned>(tiles_x), static_cast<unsigned>(tiles_y), static_cast<unsigned>(planes / pp));
-#define TA_DIM_ROWS(RPW, SB)                                                                                             \
-    do {                                                                                                                 \
-        if (pp == 3)                                                                                                     \
-            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 3>), grid3, dim3(kBlock), 0, st, gy, gx, ws, tab, layout,   \
-                               size, rnd, top, left, scale1, tw);                                                        \
-        else                                                                                                             \
-            hipLaunchKernelGGL((dim_bwd_rows_kernel<RPW, SB, 1>), grid3, dim3(kBlock), 0, st, gy, gx, ws, tab, layout,   \
-                               size, rnd, top, left, scale1, tw);                                                        \
-    } while (0)
-                if (rows <= 40) { if (fast_slots == 3) TA_DIM_ROWS(10, 3); else TA_DIM_ROWS(10, 4); }
-                else { if (fast_slots == 3) TA_DIM_ROWS(17, 3); else TA_DIM_ROWS(17, 4); }
-#undef TA_DIM_ROWS
-                return check_launch("dim_bwd_rows");
-            }
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
 #define TA_DIM_BWD(RPW, SB)                                                                                              \
     do {                                                                                                                 \

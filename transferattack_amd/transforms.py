@@ -42,8 +42,6 @@ class DimResizePad(torch.autograd.Function):
         y = torch.empty_like(x)
         _hip.dim_fwd(x, y, resize, rnd, top, left)
         ctx.geom = (resize, rnd, top, left)
-        # the backward's hit tables depend on the geometry only: built here, once, instead of by every workgroup of ta_dim_bwd
-        ctx.tables = _hip.dim_tables(x, resize, rnd, top, left) if x.requires_grad else None
         return y
 
     @staticmethod
@@ -51,7 +49,7 @@ class DimResizePad(torch.autograd.Function):
     def backward(ctx, gy):
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        _hip.dim_bwd(gy, gx, *ctx.geom, tables=ctx.tables)
+        _hip.dim_bwd(gy, gx, *ctx.geom)
         return gx, None, None, None, None
 
 
