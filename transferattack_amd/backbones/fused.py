@@ -56,6 +56,16 @@ def _conv(x, conv):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def _conv_bias_relu(x, conv):
+    """relu(conv(x) + bias).  Experiment (TA_GEMM_1X1=1): a pointwise convolution as ONE GEMM with bias + ReLU in its epilogue
+    (``torch._addmm_activation`` -> hipBLASLt) instead of GEMM / convolution + the fused glue pass"""
+    if _pointwise(conv, x):
+        n, _, h, w = x.shape
+        rows = torch._addmm_activation(conv.bias, _as_rows(x), conv.weight.view(conv.out_channels, -1).t())
+        return _from_rows(rows, n, conv.out_channels, h, w)
+    return _hip.bias_act_(_conv(x, conv), conv.bias)
+
+
 def _conv_input_grad(g, x_like, conv):
     """d/d(input) of ``conv`` for output gradient ``g``; ``x_like`` is the convolution's input (shape / memory format only)"""
     if _pointwise(conv, x_like) and g.is_contiguous(memory_format=torch.channels_last):
@@ -108,9 +118,9 @@ class _ResNetFn(torch.autograd.Function):
         saved, cur = [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
-                a = _hip.bias_act_(_conv(cur, blk.conv1), blk.conv1.bias)
+                a = _conv_bias_relu(cur, blk.conv1)
                 if bottleneck:
-                    b = _hip.bias_act_(_conv(a, blk.conv2), blk.conv2.bias)
+                    b = _conv_bias_relu(a, blk.conv2)
                     last_in, last = b, blk.conv3
                 else:
                     b, last_in, last = None, a, blk.conv2
