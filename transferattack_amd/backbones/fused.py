@@ -32,45 +32,12 @@ def _conv_spec(conv):
     return dict(stride=conv.stride, padding=conv.padding, dilation=conv.dilation, groups=conv.groups)
 
 
-def _pointwise(conv, x):
-    """a 1 x 1, stride-1 convolution on channels_last memory is a plain GEMM [N*H*W, Cin] x [Cin, Cout] (opt-in experiment:
-    TA_GEMM_1X1=1 sends those to rocBLAS / hipBLASLt instead of MIOpen's implicit-GEMM kernels)"""
-    return (os.environ.get("TA_GEMM_1X1", "0") == "1" and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-            and conv.padding == (0, 0) and conv.groups == 1 and x.dim() == 4
-            and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
-
-
-def _as_rows(t):
-    n, c, h, w = t.shape
-    return t.permute(0, 2, 3, 1).reshape(n * h * w, c)             # a view of channels_last memory
-
-
-def _from_rows(rows, n, c, h, w):
-    return rows.view(n, h, w, c).permute(0, 3, 1, 2)               # channels_last [n, c, h, w] without a copy
-
-
 def _conv(x, conv):
-    if _pointwise(conv, x):
-        n, _, h, w = x.shape
-        return _from_rows(_as_rows(x).mm(conv.weight.view(conv.out_channels, -1).t()), n, conv.out_channels, h, w)
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-
-
-def _conv_bias_relu(x, conv):
-    """relu(conv(x) + bias).  Experiment (TA_GEMM_1X1=1): a pointwise convolution as ONE GEMM with bias + ReLU in its epilogue
-    (``torch._addmm_activation`` -> hipBLASLt) instead of GEMM / convolution + the fused glue pass"""
-    if _pointwise(conv, x):
-        n, _, h, w = x.shape
-        rows = torch._addmm_activation(conv.bias, _as_rows(x), conv.weight.view(conv.out_channels, -1).t())
-        return _from_rows(rows, n, conv.out_channels, h, w)
-    return _hip.bias_act_(_conv(x, conv), conv.bias)
 
 
 def _conv_input_grad(g, x_like, conv):
     """d/d(input) of ``conv`` for output gradient ``g``; ``x_like`` is the convolution's input (shape / memory format only)"""
-    if _pointwise(conv, x_like) and g.is_contiguous(memory_format=torch.channels_last):
-        n, _, h, w = x_like.shape
-        return _from_rows(_as_rows(g).mm(conv.weight.view(conv.out_channels, -1)), n, conv.in_channels, h, w)
     return torch.ops.aten.convolution_backward(g, x_like, conv.weight, None, list(conv.stride), list(conv.padding),
                                                list(conv.dilation), False, [0, 0], conv.groups, [True, False, False])[0]
 
@@ -118,9 +85,9 @@ class _ResNetFn(torch.autograd.Function):
         saved, cur = [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
-                a = _conv_bias_relu(cur, blk.conv1)
+                a = _hip.bias_act_(_conv(cur, blk.conv1), blk.conv1.bias)
                 if bottleneck:
-                    b = _conv_bias_relu(a, blk.conv2)
+                    b = _hip.bias_act_(_conv(a, blk.conv2), blk.conv2.bias)
                     last_in, last = b, blk.conv3
                 else:
                     b, last_in, last = None, a, blk.conv2
