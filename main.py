@@ -70,6 +70,8 @@ def main():
     num_batches = (len(dataset) + args.batchsize - 1) // args.batchsize
 
     decoders = ThreadPoolExecutor(max_workers=args.io_threads)        # PNG decode (PIL releases the GIL)
+    import transferattack_amd.utils as ta_utils
+    ta_utils.IO_THREADS = args.io_threads                             # ... and as many for the encoder
     device = default_device()
     copy_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
 

@@ -140,6 +140,9 @@ def quantize_images(images, perturbations):
     return out.cpu().numpy()
 
 
+IO_THREADS = 4            # host threads of the PNG encoder (main.py sets it from --io_threads)
+
+
 def save_images(output_dir, adversaries, filenames, perturbations=None):
     """Write PNGs.  Reference signature ``save_images(output_dir, images + perturbations.cpu(), filenames)``
     (utils.py:63-66) is kept; passing ``perturbations`` separately lets the add + quantisation run fused on
@@ -153,7 +156,7 @@ def save_images(output_dir, adversaries, filenames, perturbations=None):
     def write(i):
         Image.fromarray(arr[i]).save(os.path.join(output_dir, filenames[i]))
 
-    with ThreadPoolExecutor(max_workers=4) as pool:            # zlib releases the GIL: PNG encodes run in parallel
+    with ThreadPoolExecutor(max_workers=max(1, IO_THREADS)) as pool:      # zlib releases the GIL: PNG encodes run in parallel
         list(pool.map(write, range(len(filenames))))
 
 
