@@ -103,6 +103,19 @@ def main():
             rec("bsr_fwd_x20", timed(lambda i: _hip.bsr_fwd(sets[i % 3][0], plan, stack, 20, 3), reps=6), 4 + 4 * 20)
             rec("bsr_bwd_x20", timed(lambda i: _hip.bsr_bwd(stack, plan, sets[i % 3][1], 20, 3), reps=6), 4 * 20 + 4)
             del stack
+            from transferattack_amd.transforms import SIA_NOISE, sia_draw
+            ns = 16
+            splan, _ = sia_draw((ns, 3, 224, 224), 3, 20, None)
+            splan = torch.from_numpy(splan).to(DEV)
+            sx = sets[0][0][:ns].contiguous()
+            sstack = torch.empty(20 * ns, 3, 224, 224, device=DEV)
+            sg = torch.empty(ns, 3, 224, 224, device=DEV)
+            es = ns / n                                        # relative to this batch, for the GB/s column
+            rec("sia_fwd_x20_n16", timed(lambda i: _hip.sia_fwd(sx, splan, sstack, 20, 3, SIA_NOISE, seed=1, offset=i), reps=6),
+                (4 + 4 * 20) * es)
+            rec("sia_bwd_x20_n16", timed(lambda i: _hip.sia_bwd(sstack, splan, sx, sg, 20, 3, SIA_NOISE, seed=1, offset=i), reps=6),
+                (4 * 20 + 8) * es)
+            del sstack
             members = [sets[k][0] for k in range(3)] + [sets[0][1]]
             rec("sum_members_x4", timed(lambda i: _hip.sum_members(members, sets[i % 3][2])), 20)
         if big is not None:

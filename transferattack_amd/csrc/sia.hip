@@ -42,22 +42,28 @@ __device__ __forceinline__ SiaBand sia_band(const int* __restrict__ plan, int nb
     return band;
 }
 
-// forward: y[copy][plane][r][c] = op(x[plane][source of (r, c)])
+// Where an output element of a copy comes from (band, segment, operation, source offset) is the same for every plane
+// (n, c) of the batch: a lane computes it ONCE and applies it to P planes -- the index map was ~20 VALU instructions per
+// element and plane, the kernels were bound by issuing them (0.8 / 0.6 TB/s in round 2).  Per plane what is left is one load
+// at a plane-strided address, the operation's arithmetic and the store; P loads are in flight per lane.
+template <int P>
 __global__ __launch_bounds__(kBlock) void sia_fwd_kernel(const float* __restrict__ x, const int* __restrict__ plan,
                                                          const float* __restrict__ noise, float* __restrict__ y,
                                                          int planes, int h, int w, int nb, int row_tiles, int col_tiles,
-                                                         float noise_radius, uint64_t seed, uint64_t offset) {
+                                                         int plane_groups, float noise_radius, uint64_t seed, uint64_t offset) {
     const int stride = sia_plan_stride(nb);
     const int ctile = blockIdx.x % col_tiles;
     const int tile = (blockIdx.x / col_tiles) % row_tiles;
-    const int plane = (blockIdx.x / (col_tiles * row_tiles)) % planes;
-    const int copy = blockIdx.x / (col_tiles * row_tiles * planes);
+    const int pg = (blockIdx.x / (col_tiles * row_tiles)) % plane_groups;
+    const int copy = blockIdx.x / (col_tiles * row_tiles * plane_groups);
+    const int plane0 = pg * P, np = min(P, planes - plane0);
     const int* cp = plan + copy * stride;
     const int* cols = cp + nb + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* xp = x + static_cast<int64_t>(plane) * h * w;
-    const int64_t out_plane = (static_cast<int64_t>(copy) * planes + plane) * h * w;
+    const int64_t hw = static_cast<int64_t>(h) * w;
+    const float* xp = x + static_cast<int64_t>(plane0) * hw;
+    const int64_t out0 = (static_cast<int64_t>(copy) * planes + plane0) * hw;
     for (int r = tile * kSiaRows + wave; r < min((tile + 1) * kSiaRows, h); r += kBlock / 64) {
         const SiaBand band = sia_band(cp, nb, r);
         const int lr0 = r - band.r_lo;
@@ -77,14 +83,26 @@ __global__ __launch_bounds__(kBlock) void sia_fwd_kernel(const float* __restrict
                     if (op == kRollCols) lc = lc - step + (lc < step ? bw : 0);
                     if (op == kFlipRows || op == kRotate180) lr = band.bh - 1 - lr;
                     if (op == kFlipCols || op == kRotate180) lc = bw - 1 - lc;
-                    float v = xp[(band.r_lo + lr) * w + c_lo + lc];
-                    const int64_t o = out_plane + static_cast<int64_t>(r) * w + c;
-                    if (op == kScale) v = scale * v;
-                    if (op == kNoise) {
-                        const float nz = noise ? noise[o] : uniform1(static_cast<uint64_t>(o), seed, offset, noise_radius);
-                        v = fminf(fmaxf(v + nz, 0.0f), 1.0f);
+                    const int src = (band.r_lo + lr) * w + c_lo + lc, dst = r * w + c;
+                    float v[P];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) v[q] = xp[static_cast<int64_t>(q < np ? q : 0) * hw + src];
+                    if (op == kScale) {
+#pragma unroll
+                        for (int q = 0; q < P; ++q) v[q] = scale * v[q];
                     }
-                    y[o] = v;
+                    if (op == kNoise) {                                 // one rectangle in seven: a rolled loop keeps the Philox
+#pragma unroll 1                                                        // state out of the common path's register budget
+                        for (int q = 0; q < np; ++q) {
+                            const int64_t o = out0 + static_cast<int64_t>(q) * hw + dst;
+                            const float nz = noise ? noise[o] : uniform1(static_cast<uint64_t>(o), seed, offset, noise_radius);
+                            y[o] = fminf(fmaxf(xp[static_cast<int64_t>(q) * hw + src] + nz, 0.0f), 1.0f);
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int q = 0; q < P; ++q)
+                        if (q < np) y[out0 + static_cast<int64_t>(q) * hw + dst] = v[q];
                 }
             }
         }
@@ -92,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void sia_fwd_kernel(const float* __restrict
 }
 
 // backward: gx[plane][r][c] = sum over the copies, last copy first, of what came back for the element's image
+template <int P>
 __global__ __launch_bounds__(kBlock) void sia_bwd_kernel(const float* __restrict__ gy, const int* __restrict__ plan,
                                                          const float* __restrict__ x, const float* __restrict__ noise,
                                                          float* __restrict__ gx, int planes, int h, int w, int copies,
@@ -100,20 +119,23 @@ __global__ __launch_bounds__(kBlock) void sia_bwd_kernel(const float* __restrict
     const int stride = sia_plan_stride(nb);
     const int ctile = blockIdx.x % col_tiles;
     const int tile = (blockIdx.x / col_tiles) % row_tiles;
-    const int plane = blockIdx.x / (col_tiles * row_tiles);
+    const int pg = blockIdx.x / (col_tiles * row_tiles);
+    const int plane0 = pg * P, np = min(P, planes - plane0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t plane_elems = static_cast<int64_t>(h) * w;
+    const int64_t hw = static_cast<int64_t>(h) * w;
     for (int r = tile * kSiaRows + wave; r < min((tile + 1) * kSiaRows, h); r += kBlock / 64) {
-        const int64_t here = static_cast<int64_t>(plane) * plane_elems + static_cast<int64_t>(r) * w;
-        float acc[kSiaChunks];
+        const int64_t here = static_cast<int64_t>(plane0) * hw + static_cast<int64_t>(r) * w;
+        float acc[kSiaChunks][P];
 #pragma unroll
-        for (int ch = 0; ch < kSiaChunks; ++ch) acc[ch] = 0.0f;
+        for (int ch = 0; ch < kSiaChunks; ++ch)
+#pragma unroll
+            for (int q = 0; q < P; ++q) acc[ch][q] = 0.0f;
         for (int copy = copies - 1; copy >= 0; --copy) {                // copies outer: one band lookup per (copy, row)
             const int* cp = plan + copy * stride;
             const int* cols = cp + nb + 1;
             const SiaBand band = sia_band(cp, nb, r);
-            const int64_t copy_plane = (static_cast<int64_t>(copy) * planes + plane) * plane_elems;
+            const int64_t copy0 = (static_cast<int64_t>(copy) * planes + plane0) * hw;
             const int lr0 = r - band.r_lo;
             for (int bj = 0; bj < nb; ++bj) {
                 const int c_lo = cols[bj], c_hi = cols[bj + 1];
@@ -131,15 +153,28 @@ __global__ __launch_bounds__(kBlock) void sia_bwd_kernel(const float* __restrict
                         if (op == kRollCols) { lc += step; lc -= lc >= bw ? bw : 0; }
                         if (op == kFlipRows || op == kRotate180) lr = band.bh - 1 - lr;
                         if (op == kFlipCols || op == kRotate180) lc = bw - 1 - lc;
-                        float g = gy[copy_plane + static_cast<int64_t>(band.r_lo + lr) * w + c_lo + lc];
-                        if (op == kScale) g = g * scale;
-                        if (op == kNoise) {
-                            const int64_t o = copy_plane + static_cast<int64_t>(r) * w + c;
-                            const float nz = noise ? noise[o] : uniform1(static_cast<uint64_t>(o), seed, offset, noise_radius);
-                            const float v = x[here + c] + nz;
-                            g = (v >= 0.0f && v <= 1.0f) ? g : 0.0f;
+                        const int src = (band.r_lo + lr) * w + c_lo + lc;
+                        float g[P];
+#pragma unroll
+                        for (int q = 0; q < P; ++q) g[q] = gy[copy0 + static_cast<int64_t>(q < np ? q : 0) * hw + src];
+                        if (op == kScale) {
+#pragma unroll
+                            for (int q = 0; q < P; ++q) g[q] = g[q] * scale;
                         }
-                        acc[ch] = copy == copies - 1 ? g : acc[ch] + g;
+                        if (op == kNoise) {
+                            unsigned pass = 0u;                           // bit q: plane q's sample stayed inside [0, 1]
+#pragma unroll 1
+                            for (int q = 0; q < np; ++q) {
+                                const int64_t o = copy0 + static_cast<int64_t>(q) * hw + static_cast<int64_t>(r) * w + c;
+                                const float nz = noise ? noise[o] : uniform1(static_cast<uint64_t>(o), seed, offset, noise_radius);
+                                const float v = x[here + static_cast<int64_t>(q) * hw + c] + nz;
+                                pass |= (v >= 0.0f && v <= 1.0f) ? (1u << q) : 0u;
+                            }
+#pragma unroll
+                            for (int q = 0; q < P; ++q) g[q] = ((pass >> q) & 1u) ? g[q] : 0.0f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < P; ++q) acc[ch][q] = copy == copies - 1 ? g[q] : acc[ch][q] + g[q];
                     }
                 }
             }
@@ -147,7 +182,11 @@ __global__ __launch_bounds__(kBlock) void sia_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int ch = 0; ch < kSiaChunks; ++ch) {
             const int c = (ctile * kSiaChunks + ch) * 64 + lane;
-            if (c < w) gx[here + c] = acc[ch];
+            if (c < w) {
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    if (q < np) gx[here + static_cast<int64_t>(q) * hw + c] = acc[ch][q];
+            }
         }
     }
 }
@@ -168,9 +207,17 @@ extern "C" int ta_sia_fwd(const float* x, const int32_t* plan, const float* nois
                           int copies, int nb, float noise_radius, uint64_t seed, uint64_t offset, void* stream) {
     if (int rc = check_sia(x, y, plan, planes, h, w, copies, nb)) return rc;
     const int row_tiles = static_cast<int>(ceil_div(h, kSiaRows)), col_tiles = static_cast<int>(ceil_div(w, 64 * kSiaChunks));
-    hipLaunchKernelGGL(sia_fwd_kernel, dim3(static_cast<unsigned>(copies * planes * row_tiles * col_tiles)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), x, plan, noise, y, static_cast<int>(planes), h, w, nb, row_tiles,
-                       col_tiles, noise_radius, seed, offset);
+    // planes per lane: as many as still leave >= 8 workgroups per CU (the geometry is shared, the loads are not)
+    const int64_t tiles = static_cast<int64_t>(copies) * row_tiles * col_tiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define TA_SIA_FWD(PP)                                                                                                        \
+    hipLaunchKernelGGL((sia_fwd_kernel<PP>), dim3(static_cast<unsigned>(tiles * ceil_div(planes, PP))), dim3(kBlock), 0, st, x, \
+                       plan, noise, y, static_cast<int>(planes), h, w, nb, row_tiles, col_tiles,                             \
+                       static_cast<int>(ceil_div(planes, PP)), noise_radius, seed, offset)
+    if (tiles * ceil_div(planes, 6) >= 2048) TA_SIA_FWD(6);
+    else if (tiles * ceil_div(planes, 3) >= 2048) TA_SIA_FWD(3);
+    else TA_SIA_FWD(1);
+#undef TA_SIA_FWD
     return check_launch("sia_fwd");
 }
 
@@ -180,8 +227,14 @@ extern "C" int ta_sia_bwd(const float* gy, const int32_t* plan, const float* x, 
     if (int rc = check_sia(gy, gx, plan, planes, h, w, copies, nb)) return rc;
     TA_REQUIRE(x != nullptr, "x is needed for the clip mask");
     const int row_tiles = static_cast<int>(ceil_div(h, kSiaRows)), col_tiles = static_cast<int>(ceil_div(w, 64 * kSiaChunks));
-    hipLaunchKernelGGL(sia_bwd_kernel, dim3(static_cast<unsigned>(planes * row_tiles * col_tiles)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), gy, plan, x, noise, gx, static_cast<int>(planes), h, w, copies, nb,
-                       row_tiles, col_tiles, noise_radius, seed, offset);
+    const int64_t tiles = static_cast<int64_t>(row_tiles) * col_tiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define TA_SIA_BWD(PP)                                                                                                        \
+    hipLaunchKernelGGL((sia_bwd_kernel<PP>), dim3(static_cast<unsigned>(tiles * ceil_div(planes, PP))), dim3(kBlock), 0, st, gy, \
+                       plan, x, noise, gx, static_cast<int>(planes), h, w, copies, nb, row_tiles, col_tiles, noise_radius,   \
+                       seed, offset)
+    if (tiles * ceil_div(planes, 3) >= 1024) TA_SIA_BWD(3);
+    else TA_SIA_BWD(1);
+#undef TA_SIA_BWD
     return check_launch("sia_bwd");
 }
