@@ -52,7 +52,6 @@ def install(monkeypatch, tag=None, env=None):
 
     monkeypatch.setattr(_hip, "_call", call)
     monkeypatch.setattr(_hip, "workspace", _hip.Workspace())
-    monkeypatch.setattr(_hip, "_partials", None)
     from transferattack_amd import attack as ta_attack, utils as ta_utils
     cpu = lambda: torch.device("cpu")            # noqa: E731  -- "the device this process drives" is the host here
     monkeypatch.setattr(ta_utils, "default_device", cpu)

@@ -164,21 +164,22 @@ def test_launch_timing():
 def _k1_sums(t):
     """per-image sum|t| the way K1 adds it: [n] float32 (the fixed-order total the fused update divides by E)"""
     n, e = t.shape[0], t[0].numel()
+    keep = getattr(t, _hip._ATTR, None)
     ws, slots = _hip.abs_sum_partials(t)
-    _hip.invalidate_partials()
+    _hip.invalidate_partials(t)
+    if keep is not None:
+        setattr(t, _hip._ATTR, keep)             # the K1 run above replaced the producer's sums: put them back
     return ws[:n * slots].view(n, slots)
 
 
 def _check_registered(out, exact):
     """the registry holds sums for ``out``; per image they add up to sum|out| (bit-identical per-tile sums to K1's for
     the kernels that use K1's tiling, else equal to an fp64 sum within fp32 summation error)"""
-    assert _hip._partials is not None and _hip._partials[0].data_ptr() == out.data_ptr()
-    entry = _hip._partials
-    ws, slots = entry[2], entry[3]
+    assert _hip.partials_of(out) is not None, "the producer attached no sums to its output"
+    ws, slots = _hip.partials_of(out)
     n = out.shape[0]
     sums = ws[:n * slots].view(n, slots).clone()
     k1 = _k1_sums(out)
-    _hip._partials = entry                       # the K1 run above replaced the producer's entry: put it back
     if exact:
         assert slots == k1.shape[1] and torch.equal(sums, k1)
     truth = out.double().abs().flatten(1).sum(1)
@@ -243,7 +244,7 @@ def test_producer_side_partials_all_kernels():
         # a kernel of the binding that overwrites the gradient drops the sums
         _hip.sum_members(members, gx)
         _hip.axpy(members[0], members[1], 0.5, gx)
-        assert _hip._partials is None
+        assert _hip.partials_of(gx) is None
 
 
 def test_sum_members():
@@ -313,11 +314,11 @@ def test_normalize_and_producer_side_partials(shape):
     assert np.array_equal(host(y), y_ref.detach().numpy())
     gx = torch.autograd.grad(y, xd, gy.to(DEV))[0]
     assert np.array_equal(host(gx), gx_ref.numpy())
-    assert _hip._partials is not None and _hip._partials[0].data_ptr() == gx.data_ptr()
+    assert _hip.partials_of(gx) is not None          # attached by the Normalize backward, survived autograd.grad
     mom, data = torch.randn(shape, generator=gen).to(DEV), torch.rand(shape, generator=gen).to(DEV)
     d1, m1 = torch.zeros(shape, device=DEV), mom.clone()
-    _hip.mi_update(gx, m1, m1, d1, data, 1.0, ALPHA, EPS)                 # consumes the registered partials
-    assert _hip._partials is None
+    _hip.mi_update(gx, m1, m1, d1, data, 1.0, ALPHA, EPS)                 # consumes the attached partials
+    assert _hip.partials_of(gx) is None
     d2, m2 = torch.zeros(shape, device=DEV), mom.clone()
     _hip.mi_update(gx.clone(), m2, m2, d2, data, 1.0, ALPHA, EPS)         # different tensor -> own K1 pass
     assert torch.equal(d1, d2) and torch.equal(m1, m2)

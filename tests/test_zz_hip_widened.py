@@ -225,8 +225,8 @@ def test_bsr_kernels_random(shape, nb, copies, monkeypatch):
     assert diff <= 1e-4 * float(x.abs().max()), diff
     gx = torch.empty(shape, device=DEV)
     _hip.bsr_bwd(gy_d, plan_d, gx, copies, nb)
-    assert _hip._partials is not None and _hip._partials[0].data_ptr() == gx.data_ptr()
-    sums = _hip._partials[2][:shape[0] * _hip._partials[3]].view(shape[0], -1).double().sum(1).cpu()
+    assert _hip.partials_of(gx) is not None
+    sums = _hip.partials_of(gx)[0][:shape[0] * _hip.partials_of(gx)[1]].view(shape[0], -1).double().sum(1).cpu()
     np.testing.assert_allclose(sums.numpy(), gx.double().abs().flatten(1).sum(1).cpu().numpy(), rtol=2e-6)
     assert float((gx.cpu() - gx_ref).abs().max()) <= 1e-4 * float(gx_ref.abs().max())
     lhs, rhs = float((y.double() * gy_d.double()).sum()), float((x_d.double() * gx.double()).sum())
@@ -262,7 +262,7 @@ def test_bsr_plane_groups(shape):
     _hip.bsr_fwd(x, plan, y, copies, nb)
     gx = torch.empty(shape, device=DEV)
     _hip.bsr_bwd(gy, plan, gx, copies, nb)
-    sums = _hip._partials[2][:n * _hip._partials[3]].view(n, -1).double().sum(1).cpu()
+    sums = _hip.partials_of(gx)[0][:n * _hip.partials_of(gx)[1]].view(n, -1).double().sum(1).cpu()
     np.testing.assert_allclose(sums.numpy(), gx.double().abs().flatten(1).sum(1).cpu().numpy(), rtol=2e-6)
     gx_chunks, y_chunks = torch.empty(shape, device=DEV), torch.empty_like(y)
     for lo in range(0, n, 16):
@@ -613,10 +613,9 @@ def test_dim_largest_ratio(size, rate, geoms):
 
 
 def test_partials_registry_rules(monkeypatch):
-    """NOT YET RUN ON MI355X (green through the host stand-in).  The hand-over of |g| tile sums is refused when anything
-    could have changed the gradient or its ordering: a kernel of the binding writing a VIEW of the gradient (not only its
-    base address), a torch in-place op, a consumer on another stream than the producer; it is taken when none of that
-    happened"""
+    """The hand-over of |g| tile sums (an attribute of the gradient tensor) is refused when anything could have changed the
+    gradient or its ordering: a kernel of the binding writing a VIEW of the gradient, a torch in-place op, a consumer on
+    another stream than the producer, a copy of the gradient (a new object); it is taken when none of that happened"""
     from transferattack_amd import _hip
     gen = torch.Generator().manual_seed(3)
     shape = (4, 3, 37, 41)
@@ -635,6 +634,14 @@ def test_partials_registry_rules(monkeypatch):
     assert not reused()
     _hip.abs_sum_partials(grad)
     grad.mul_(1.0)                                                             # torch in-place op: version bump
+    assert not reused()
+    _hip.abs_sum_partials(grad)
+    copy, before = grad.clone(), _hip.stats["partials_reused"]
+    _hip.mi_update(copy, None, torch.empty_like(grad), d, x, 1.0, 1.6 / 255, EPS)   # a copy carries no sums
+    assert _hip.stats["partials_reused"] == before and _hip.partials_of(grad) is not None
+    assert reused()                                                            # ... and the original still does
+    _hip.abs_sum_partials(grad)
+    _hip.invalidate_partials(grad)                                             # what dist.py calls after a collective
     assert not reused()
     _hip.abs_sum_partials(grad)
     monkeypatch.setattr(_hip, "_stream", lambda like=None: 12345)

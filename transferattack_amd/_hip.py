@@ -172,62 +172,62 @@ workspace = Workspace()
 
 # ---- producer-side |g| tile sums ("partials") -----------------------------------------------------------
 # The kernel that writes the input gradient LAST (ta_normalize_bwd for the plain attacks; TIM's convolution, the DIM /
-# SIM / Admix / EMI backward kernels, the ensemble's member sum otherwise) also leaves per-tile sums of |g| here;
-# mi_update consumes them -- and skips its own pass over g -- if and only if it is handed that very tensor, unmodified:
-#   * the entry holds a strong reference to the gradient, so its memory cannot be recycled while the entry is live;
-#   * pointer, shape and autograd version must match (torch in-place ops bump the version);
-#   * every wrapper of this module that WRITES a tensor drops the entry if it writes that memory, and code that
-#     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials()``;
+# SIM / Admix / EMI backward kernels, the ensemble's member sum otherwise) also leaves per-tile sums of |g|; mi_update
+# consumes them -- and skips its own pass over g -- if and only if it is handed that very tensor, unmodified.  The sums
+# travel WITH the gradient: the producer's wrapper attaches them to the tensor object it wrote (``tensor._ta_partials``;
+# autograd hands the same Python object on -- through ``autograd.grad``, identity Functions and AddBackward alike), and
+# there is no module-level state:
+#   * a copy (``.contiguous()`` of a strided gradient, ``.clone()``, a collective's fresh result) is a new object without
+#     the attribute: its consumer runs its own pass;
+#   * torch in-place operations bump ``_version``, which must still be the producer's;
+#   * every wrapper of this module that WRITES a tensor drops the attribute of that tensor and of its base, and code that
+#     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials(tensor)``;
 #   * producer and consumer must be on the same stream (the sums are ordered after the producer only there);
-#   * one slot only: the next producer overwrites it.
-_partials = None            # (grad tensor, grad._version, ws tensor, sums per image, stream of the producer,
-#                              variance tensor or None: the sums are of |grad + variance|, its _version)
+#   * the sums are of |g|, or of |g + variance| for exactly the variance tensor the producer was given (VMI-FGSM).
+_ATTR = "_ta_partials"     # (gradient's _version, ws tensor, sums per image, producer's stream, variance tensor | None, its _version)
 stats = {"partials_reused": 0, "k1_passes": 0}
 
 
 def _register_partials(grad, ws, slots, variance=None):
-    global _partials
-    _partials = (grad, grad._version, ws, int(slots), _stream(grad), variance, None if variance is None else variance._version)
+    setattr(grad, _ATTR, (grad._version, ws, int(slots), _stream(grad), variance, None if variance is None else variance._version))
 
 
-def invalidate_partials():
-    global _partials
-    _partials = None
+def partials_of(grad):
+    """(ws, sums per image) the producer of ``grad`` attached to it, or None -- read-only (tests, diagnostics)"""
+    entry = getattr(grad, _ATTR, None)
+    return None if entry is None else (entry[1], entry[2])
+
+
+def invalidate_partials(*tensors):
+    """``tensors`` were modified behind torch's back (a collective, a foreign kernel): their sums are stale"""
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            t.__dict__.pop(_ATTR, None)
+            base = t._base
+            if base is not None:
+                base.__dict__.pop(_ATTR, None)
 
 
 def _wrote(*tensors):
-    """A kernel of this module wrote ``tensors``: sums registered for that memory are stale."""
-    global _partials
-    entry = _partials                                # one read: another host thread (main.py's writer) may clear it meanwhile
-    if entry is not None:
-        for held in (entry[0], entry[5]):            # the gradient, and the variance the sums were taken with
-            if held is None:
-                continue
-            lo, hi = held.data_ptr(), held.data_ptr() + held.numel() * held.element_size()
-            for t in tensors:
-                if t is not None and t.device == held.device and t.data_ptr() < hi and lo < t.data_ptr() + t.numel() * t.element_size():
-                    if _partials is entry:
-                        _partials = None             # any overlap, not only the same base address (a view of the gradient)
-                    return
+    """A kernel of this module wrote ``tensors``: sums attached to that memory are stale."""
+    invalidate_partials(*tensors)
 
 
 def _take_partials(grad, variance=None):
-    """the sums a producer left for exactly this gradient (and, if ``variance`` is given, for exactly |grad + variance|)"""
-    global _partials
-    entry, _partials = _partials, None
+    """the sums the producer attached to exactly this gradient (and, if ``variance`` is given, taken of |grad + variance|
+    for exactly that variance tensor); the attribute is consumed either way"""
+    entry = grad.__dict__.pop(_ATTR, None)
     if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
         return None                                   # the reference-order sum is never taken from a producer
-    tensor, version, ws, slots, stream, var, var_version = entry
+    version, ws, slots, stream, var, var_version = entry
     same_variance = (var is None and variance is None) or (
         var is not None and variance is not None and var.data_ptr() == variance.data_ptr() and var.shape == variance.shape
         and variance._version == var_version and var._version == var_version)
-    if (same_variance and tensor.data_ptr() == grad.data_ptr() and tensor.shape == grad.shape and grad._version == version
-            and tensor._version == version and tensor.device == grad.device and stream == _stream(grad)):
+    if same_variance and grad._version == version and ws.device == grad.device and stream == _stream(grad):
         return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
-        print("partials not reused: ptr %x vs %x, shape %s vs %s, version %d/%d vs %d" % (
-            tensor.data_ptr(), grad.data_ptr(), tuple(tensor.shape), tuple(grad.shape), tensor._version,
-            grad._version, version), flush=True)
+        print("partials not reused: version %d vs %d, stream %s vs %s, variance match %s" % (
+            grad._version, version, stream, _stream(grad), same_variance), flush=True)
     return None
 
 

@@ -29,11 +29,11 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-def _invalidate_partials():
-    """Drop the |g| tile sums a HIP kernel may have registered for a gradient a collective has just replaced or
-    modified (transferattack_amd._hip partials registry)."""
+def _invalidate_partials(*tensors):
+    """Drop the |g| tile sums a HIP kernel attached to a gradient that a collective has just replaced or modified in place
+    (transferattack_amd._hip: the sums travel as an attribute of the gradient tensor)."""
     from . import _hip
-    _hip.invalidate_partials()
+    _hip.invalidate_partials(*tensors)
 
 
 def rank_world():
@@ -124,7 +124,7 @@ class _SumInputGrad(torch.autograd.Function):
     def backward(ctx, grad):
         total = grad.contiguous().clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
-        _invalidate_partials()
+        _invalidate_partials(total, grad)
         return total, None
 
 
@@ -183,7 +183,7 @@ class _OwnerCall(torch.autograd.Function):
         else:
             gx = torch.empty(ctx.x_shape, dtype=grad_logits.dtype, device=grad_logits.device)
         dist.broadcast(gx, src=handle.owner, group=handle.group)
-        _invalidate_partials()                    # every rank of the group must take the same path through the update
+        _invalidate_partials(gx)                  # every rank of the group must take the same path through the update
         return gx, None
 
 
@@ -232,7 +232,7 @@ class _GatherLogits(torch.autograd.Function):
         owner = ctx.owner
         gx = torch.autograd.grad(out, leaf, grad[owner.index].contiguous(), retain_graph=True)[0].contiguous()
         dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=owner.group)
-        _invalidate_partials()                    # gx was modified in place behind torch's back
+        _invalidate_partials(gx)                  # gx was modified in place behind torch's back
         return gx, None
 
 
@@ -275,7 +275,7 @@ class ShardedMembers(nn.Module):
             mine = torch.autograd.grad(loss_of_logits(out), leaf, retain_graph=True)[0].contiguous()
         parts = [torch.empty_like(mine) for _ in range(self.num_models)]
         dist.all_gather(parts, mine, group=self.group)
-        _invalidate_partials()
+        _invalidate_partials(mine, *parts)
         return parts
 
     def member_losses(self, inputs, loss_of_logits):
