@@ -9,9 +9,12 @@
 Workload (BASELINE.json configs[1]): MI-FGSM on ResNet-50, eps=16/255, alpha=1.6/255, K=10 iterations,
 synthetic 3x224x224 images.  One "step" = one batch of 125 images (1000/8: the per-GPU shard of the 1000-image
 set; 8 steps = the whole set) through ``attacker(images, labels)`` = 10 x (surrogate forward + input-gradient
-backward + fused HIP update).  Host-side arrangement of the surrogate (both reported in ``config``, both
+backward + fused HIP update).  Host-side arrangement of the surrogate (all reported in ``config``, all
 switchable): eval-mode BatchNorm folded into the convolutions, NHWC memory format (profiles/r01/backbone_probe.jsonl:
-+46% over plain NCHW at this batch); ``--batch 32 --fold-bn 0 --channels-last 0`` is the reference's literal setup.
++46% over plain NCHW at this batch), and -- with both -- the fused execution of backbones/fused.py (same MIOpen
+convolutions, the memory-bound passes between them fused, the stem's input gradient on the fp32-MFMA kernel:
+TA_FUSED_GLUE / TA_STEM_KERNEL = 0 switch them off); ``--batch 32 --fold-bn 0 --channels-last 0`` is the reference's
+literal setup.
 Inputs are resident in HBM before the timed region; the surrogate is the ResNet-50 architecture with seeded
 random weights (no checkpoints offline); arithmetic is fp32 throughout, as in the reference.
 
@@ -478,6 +481,11 @@ def main(argv=None):
             "config": {"fold_bn": os.environ.get("TA_FOLD_BN", "0") == "1",
                        "images_per_step": args.batch,
                        "channels_last": os.environ.get("TA_CHANNELS_LAST", "0") == "1",
+                       # execution strategy of a folded ResNet surrogate (backbones/fused.py): same MIOpen convolutions, the
+                       # bias / ReLU / residual / threshold passes between them fused, the stem's input gradient on csrc/stem.hip
+                       "fused_glue": os.environ.get("TA_FUSED_GLUE", "1") != "0" and os.environ.get("TA_FOLD_BN", "0") == "1",
+                       "stem_kernel": os.environ.get("TA_STEM_KERNEL", "1") != "0" and os.environ.get("TA_FOLD_BN", "0") == "1"
+                       and os.environ.get("TA_FUSED_GLUE", "1") != "0" and os.environ.get("TA_CHANNELS_LAST", "0") == "1",
                        "workload": "%s on %s (seeded random init), eps=16/255, alpha=1.6/255, K=10, synthetic "
                                    "3x%dx%d, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,

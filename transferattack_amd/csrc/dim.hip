@@ -437,7 +437,9 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     return acc;
 }
 
-template <int RPW, int SB, int PP>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
+template <int RPW, int SB, int PP, int SA>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
+                                        // SA: hit slots of stage A (2 when no padded index is touched by 3 outputs: always so when the
+                                        // second resample shrinks, resize > size -- 4 instead of 9 gathers per window pixel);
                                         // PP: planes per workgroup (they share the tile's hit tables)
 __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                float* __restrict__ ws, int size, int resize, int rnd,
@@ -487,43 +489,43 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
         Hit hx = colA[lane < mw ? lane : 0];
         if (lane >= mw) hx.n = 0;
         const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        unsigned col[kHitSlots - 1];                                    // byte offsets of the lane's output columns
+        unsigned col[SA];                                    // byte offsets of the lane's output columns
 #pragma unroll
-        for (int k = 0; k < kHitSlots - 1; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
+        for (int k = 0; k < SA; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
         // software pipeline over the wave's rows: the 9 loads of row p + 4 are in flight while row p is accumulated
-        auto fetch = [&](int p, float (&g)[kHitSlots - 1][kHitSlots - 1]) {
+        auto fetch = [&](int p, float (&g)[SA][SA]) {
             const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
 #pragma unroll
-            for (int ky = 0; ky < kHitSlots - 1; ++ky) {
+            for (int ky = 0; ky < SA; ++ky) {
                 const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
 #pragma unroll
-                for (int kx = 0; kx < kHitSlots - 1; ++kx) g[ky][kx] = *reinterpret_cast<const float*>(gyp + (row + col[kx]));
+                for (int kx = 0; kx < SA; ++kx) g[ky][kx] = *reinterpret_cast<const float*>(gyp + (row + col[kx]));
             }
         };
-        auto reduce = [&](int p, const float (&g)[kHitSlots - 1][kHitSlots - 1]) {
+        auto reduce = [&](int p, const float (&g)[SA][SA]) {
             const Hit* hy = &rowA[p];
             const int n_y = __builtin_amdgcn_readfirstlane(hy->n);                    // <= 3: scale2 >= 1
             const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
             float acc = 0.0f;
             if (!any_both_x && both_y == 0u) {
 #pragma unroll
-                for (int ky = 0; ky < kHitSlots - 1; ++ky)
+                for (int ky = 0; ky < SA; ++ky)
                     if (ky < n_y)
 #pragma unroll
-                        for (int kx = 0; kx < kHitSlots - 1; ++kx)
+                        for (int kx = 0; kx < SA; ++kx)
                             acc = hit_accumulate<true>(acc, g[ky][kx], hy->w[ky], 0.0f, false, hx, kx);
             } else {
 #pragma unroll
-                for (int ky = 0; ky < kHitSlots - 1; ++ky)
+                for (int ky = 0; ky < SA; ++ky)
                     if (ky < n_y)
 #pragma unroll
-                        for (int kx = 0; kx < kHitSlots - 1; ++kx)
+                        for (int kx = 0; kx < SA; ++kx)
                             acc = hit_accumulate<false>(acc, g[ky][kx], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
             }
             mid[p * 64 + lane] = acc;
         };
-        float ga[kHitSlots - 1][kHitSlots - 1], gb[kHitSlots - 1][kHitSlots - 1];
+        float ga[SA][SA], gb[SA][SA];
         // the prefetch is unconditional (row index clamped to the window) so that the compiler's wait counters know,
         // on every path, that the nine newest loads are not the ones being consumed
         int p = wave;
@@ -694,18 +696,21 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
-#define TA_DIM_BWD(RPW, SB)                                                                                              \
+            const bool two_a = max_hits(resize, size) <= 2;    // stage A: outputs per padded index (<= 2 whenever resize > size)
+#define TA_DIM_BWD_PP(RPW, SB, SA)                                                                                       \
     do {                                                                                                                 \
         if (pp == 3)                                                                                                     \
-            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize,  \
-                               rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                                    \
+            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
         else                                                                                                             \
-            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize,  \
-                               rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                                    \
+            hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
     } while (0)
+#define TA_DIM_BWD(RPW, SB) do { if (two_a) TA_DIM_BWD_PP(RPW, SB, 2); else TA_DIM_BWD_PP(RPW, SB, 3); } while (0)
             if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }
             else { if (three) TA_DIM_BWD(17, 3); else TA_DIM_BWD(17, 4); }
 #undef TA_DIM_BWD
+#undef TA_DIM_BWD_PP
             return check_launch("dim_bwd_lanes");
         }
     }
