@@ -204,6 +204,11 @@ int ta_bias_act(float* y, const float* bias, int relu, int64_t numel, int channe
 int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, int64_t numel, int channels,
                      int64_t inner, void* stream);
 int ta_relu_mask(const float* ga, const float* gb, const float* y, float* out, int64_t numel, void* stream);
+/*   ta_maxpool_bwd_relu  out = threshold_backward(max_pool2d_with_indices_backward(ga [+ gb], idx), y, 0) in ONE gather pass (the
+ *                        stem of the ResNets: conv -> ReLU -> max-pool; no zero fill, no atomics, deterministic).  channels_last
+ *                        buffers: ga / gb / idx [n, ph, pw, c], y / out [n, h, w, c]; idx = ATen's argmax index h * w_ + w. */
+int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64_t* idx, const float* y, float* out, int64_t n, int channels,
+                        int h, int w, int ph, int pw, int k, int s, int p, void* stream);
 
 /* ---- the stem convolution's input gradient (7 x 7, stride 2, padding 3, 3 -> 64 channels: ResNet / ImageNet CNN stems) ----
  * The last convolution of the surrogate's backward, producer of the gradient the update consumes (attack.py:118-122).

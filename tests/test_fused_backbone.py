@@ -81,6 +81,26 @@ def test_stem_input_grad_kernel(monkeypatch, n, oh, ow):
     assert err_got <= max(4 * err_ref, 2e-6), (err_got, err_ref)
 
 
+@pytest.mark.parametrize("shape,k,s,p", [((2, 8, 16, 16), 3, 2, 1), ((1, 4, 9, 13), 3, 2, 1), ((2, 8, 12, 12), 2, 2, 0), ((1, 4, 11, 7), 3, 1, 1)])
+def test_maxpool_backward_relu_kernel(monkeypatch, shape, k, s, p):
+    """ta_maxpool_bwd_relu (junction add + max-pool backward + ReLU threshold as one gather) against the ATen passes it replaces"""
+    host_kernels.install(monkeypatch)
+    gen = torch.Generator().manual_seed(11)
+    cl = torch.channels_last
+    pre = torch.randn(shape, generator=gen)
+    y = pre.clamp_min(0).contiguous(memory_format=cl)                       # post-ReLU map: plenty of exact zeros and ties at 0
+    pooled, idx = torch.nn.functional.max_pool2d(y, k, s, p, return_indices=True)
+    ga = torch.randn(pooled.shape, generator=gen).contiguous(memory_format=cl)
+    gb = torch.randn(pooled.shape, generator=gen).contiguous(memory_format=cl)
+    for second in (gb, None):
+        g = ga if second is None else ga + second
+        ref = torch.ops.aten.max_pool2d_with_indices_backward(g, y, [k, k], [s, s], [p, p], [1, 1], False, idx)
+        ref = torch.ops.aten.threshold_backward(ref, y, 0)
+        got = _hip.maxpool_bwd_relu(ga, idx.contiguous(memory_format=cl), y, torch.full_like(y, float("nan")), k, s, p, gb=second)
+        assert not torch.isnan(got).any()
+        assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
 def test_fused_path_steps_aside(monkeypatch):
     """hooks anywhere in the backbone, an unfolded BatchNorm, training mode or a trainable weight: the module path runs"""
     host_kernels.install(monkeypatch)

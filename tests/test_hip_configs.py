@@ -296,3 +296,22 @@ def test_stem_input_grad_kernel_on_device(n, oh, ow):
         print("  first offenders (n, c, y, x):", idx)
     assert not torch.isnan(got).any() and torch.equal(got, again)
     assert e_got <= max(4 * e_ref, 2e-6)
+
+
+@pytest.mark.parametrize("shape,k,s,p", [((4, 64, 112, 112), 3, 2, 1), ((2, 8, 9, 13), 3, 2, 1), ((2, 16, 12, 12), 2, 2, 0)])
+def test_maxpool_backward_relu_kernel_on_device(shape, k, s, p):
+    """ta_maxpool_bwd_relu on MI355X against the three ATen passes it replaces (junction add, max_pool2d_with_indices_backward
+    -- atomic adds, so only equal to fp32 summation order -- and threshold_backward); deterministic itself"""
+    gen = torch.Generator().manual_seed(11)
+    cl = torch.channels_last
+    y = torch.randn(shape, generator=gen).clamp_min(0).to(DEV).contiguous(memory_format=cl)
+    pooled, idx = torch.nn.functional.max_pool2d(y, k, s, p, return_indices=True)
+    ga = torch.randn(pooled.shape, generator=gen).to(DEV).contiguous(memory_format=cl)
+    gb = torch.randn(pooled.shape, generator=gen).to(DEV).contiguous(memory_format=cl)
+    ref = torch.ops.aten.max_pool2d_with_indices_backward(ga + gb, y, [k, k], [s, s], [p, p], [1, 1], False, idx)
+    ref = torch.ops.aten.threshold_backward(ref, y, 0)
+    idx = idx.contiguous(memory_format=cl)
+    got = _hip.maxpool_bwd_relu(ga, idx, y, torch.full_like(y, float("nan")), k, s, p, gb=gb)
+    again = _hip.maxpool_bwd_relu(ga, idx, y, torch.full_like(y, float("nan")), k, s, p, gb=gb)
+    assert not torch.isnan(got).any() and torch.equal(got, again)
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ta_bias_act": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "ta_maxpool_bwd_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_scale_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ta_sum_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
@@ -592,6 +593,24 @@ def stem7s2_input_grad(dy, w2, dx):
     _wrote(dx)
     _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), n, oh, ow)
     return dx
+
+
+def maxpool_bwd_relu(ga, idx, y, out, kernel, stride, padding, gb=None):
+    """out <- threshold_backward(max_pool2d_with_indices_backward(ga [+ gb], idx), y, 0): the backward of ReLU -> max-pool in one
+    gather pass.  channels_last tensors: ga / gb / idx [n, c, ph, pw], y / out [n, c, h, w]."""
+    n, c, h, w = y.shape
+    ph, pw = ga.shape[-2:]
+    cl = torch.channels_last
+    ok = (y.is_contiguous(memory_format=cl) and out.is_contiguous(memory_format=cl) and ga.is_contiguous(memory_format=cl)
+          and idx.is_contiguous(memory_format=cl) and (gb is None or gb.is_contiguous(memory_format=cl))
+          and idx.dtype == torch.int64 and tuple(idx.shape) == tuple(ga.shape) and out.shape == y.shape and c % 4 == 0)
+    if not ok:
+        raise ValueError("maxpool_bwd_relu needs channels_last operands with channels % 4 == 0")
+    _wrote(out)
+    flat = lambda t, dt: _ptr(t.detach().as_strided((t.numel(),), (1,)), dt, "operand")       # noqa: E731
+    _call("ta_maxpool_bwd_relu", y, flat(ga, torch.float32), None if gb is None else flat(gb, torch.float32),
+          flat(idx, torch.int64), flat(y, torch.float32), flat(out, torch.float32), n, c, h, w, ph, pw, kernel, stride, padding)
+    return out
 
 
 def _ptr_any(t, name):

@@ -134,11 +134,19 @@ class _ResNetFn(torch.autograd.Function):
             g_main = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in)
             g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
             g, pending = g_main, g_skip                                        # summed inside the next threshold pass
-        g_pooled = g + pending                                                 # the stem's ReLU sits before the max-pool
-        g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(
-            g_pooled, ctx.stem, _pair(net.maxpool.kernel_size), _pair(net.maxpool.stride), _pair(net.maxpool.padding),
-            [1, 1], False, ctx.idx), ctx.stem)
-        _hip.relu_mask(g_stem, ctx.stem, g_stem)
+        # the stem's ReLU sits before the max-pool: junction add + max-pool backward + threshold
+        mp = net.maxpool
+        k, st, pd = _pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding)
+        cl = torch.channels_last
+        if (os.environ.get("TA_POOL_KERNEL", "1") != "0" and k[0] == k[1] and st[0] == st[1] and pd[0] == pd[1]
+                and _pair(mp.dilation) == [1, 1] and not mp.ceil_mode and ctx.stem.shape[1] % 4 == 0
+                and all(t.is_contiguous(memory_format=cl) and not t.is_contiguous() for t in (ctx.stem, ctx.idx, g, pending))):
+            g_stem = _hip.maxpool_bwd_relu(g, ctx.idx, ctx.stem, torch.empty_like(ctx.stem), k[0], st[0], pd[0], gb=pending)
+        else:
+            g_pooled = g + pending
+            g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(g_pooled, ctx.stem, k, st, pd, [1, 1], False, ctx.idx),
+                           ctx.stem)
+            _hip.relu_mask(g_stem, ctx.stem, g_stem)
         gx = _stem_input_grad(net, g_stem, ctx.x)
         ctx.saved = ctx.stem = ctx.pooled = ctx.idx = ctx.x = None
         return gx, None

@@ -176,3 +176,69 @@ extern "C" int ta_relu_mask(const float* ga, const float* gb, const float* y, fl
         hipLaunchKernelGGL(relu_mask_kernel<false>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, ga, gb, y, out, static_cast<unsigned>(numel));
     return check_launch("relu_mask");
 }
+
+// ---- max-pool backward + junction add + the ReLU threshold in front of the pool, one pass ---------------------------------
+// The stem of the ResNets is conv -> ReLU -> max-pool(3, stride 2, padding 1).  Its backward on PyTorch-ROCm is four passes:
+// the add that joins the two branches of the first block's input (pooled size), a zero fill, max_pool2d_with_indices_backward
+// (channels_last: atomic adds into the filled buffer) and threshold_backward over the full-size map.  Gather form, no
+// atomics, deterministic: every input pixel looks at the <= ceil(K/S)^2 windows that cover it and takes the gradient of those
+// whose recorded argmax (ATen's index h * W + w within the plane) is this pixel, windows in row-major order; then the ReLU
+// threshold (out = y <= 0 ? 0 : sum).  channels_last only: a lane owns four consecutive channels of one pixel.
+namespace ta {
+
+__global__ __launch_bounds__(kBlock) void maxpool_bwd_relu_kernel(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                  const int64_t* __restrict__ idx, const float* __restrict__ y,
+                                                                  float* __restrict__ out, int channels, int h, int w, int ph,
+                                                                  int pw, int k, int s, int p, unsigned total4) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;              // one float4 group: (n, hh, ww, c4)
+    if (q >= total4) return;
+    const unsigned c4n = static_cast<unsigned>(channels) / 4u;
+    const unsigned c4 = q % c4n, pix = q / c4n;
+    const int ww = static_cast<int>(pix % static_cast<unsigned>(w));
+    const unsigned t = pix / static_cast<unsigned>(w);
+    const int hh = static_cast<int>(t % static_cast<unsigned>(h));
+    const unsigned n = t / static_cast<unsigned>(h);
+    // windows (i, j) with i*s - p <= hh <= i*s - p + k - 1
+    const int i_hi = min((hh + p) / s, ph - 1), j_hi = min((ww + p) / s, pw - 1);
+    const int i_lo = max(0, (hh + p - k + s) / s), j_lo = max(0, (ww + p - k + s) / s);     // ceil((hh + p - k + 1) / s), >= 0 operands
+    const int64_t here = static_cast<int64_t>(hh) * w + ww;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = i_lo; i <= i_hi; ++i)
+        for (int j = j_lo; j <= j_hi; ++j) {
+            const int64_t o = ((static_cast<int64_t>(n) * ph + i) * pw + j) * channels + 4 * c4;
+            float4 g = *reinterpret_cast<const float4*>(ga + o);
+            if (gb != nullptr) {
+                const float4 g2 = *reinterpret_cast<const float4*>(gb + o);
+                g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+            }
+            const int64_t* ip = idx + o;
+            acc.x += ip[0] == here ? g.x : 0.0f;
+            acc.y += ip[1] == here ? g.y : 0.0f;
+            acc.z += ip[2] == here ? g.z : 0.0f;
+            acc.w += ip[3] == here ? g.w : 0.0f;
+        }
+    const int64_t at = ((static_cast<int64_t>(n) * h + hh) * w + ww) * channels + 4 * c4;
+    const float4 r = *reinterpret_cast<const float4*>(y + at);
+    acc.x = r.x <= 0.0f ? 0.0f : acc.x;
+    acc.y = r.y <= 0.0f ? 0.0f : acc.y;
+    acc.z = r.z <= 0.0f ? 0.0f : acc.z;
+    acc.w = r.w <= 0.0f ? 0.0f : acc.w;
+    *reinterpret_cast<float4*>(out + at) = acc;
+}
+
+}  // namespace ta
+
+extern "C" int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64_t* idx, const float* y, float* out, int64_t n,
+                                   int channels, int h, int w, int ph, int pw, int k, int s, int p, void* stream) {
+    TA_REQUIRE(ga && idx && y && out && aligned16(ga) && aligned16(y) && aligned16(out) && aligned16(idx) &&
+               (gb == nullptr || aligned16(gb)), "null or unaligned pointer");
+    TA_REQUIRE(n > 0 && channels > 0 && channels % 4 == 0 && h > 0 && w > 0 && ph > 0 && pw > 0 && k > 0 && s > 0 && p >= 0 && p < k,
+               "shape (n=%lld, c=%d, %dx%d <- %dx%d, k=%d s=%d p=%d)", (long long)n, channels, h, w, ph, pw, k, s, p);
+    TA_REQUIRE((ph - 1) * s - p < h && (pw - 1) * s - p < w, "pooled size does not belong to this input size");
+    const int64_t total4 = n * h * w * (channels / 4);
+    TA_REQUIRE(total4 < (1ll << 32) - kBlock, "too many elements for one launch");
+    hipLaunchKernelGGL(maxpool_bwd_relu_kernel, dim3(static_cast<unsigned>(ceil_div(total4, kBlock))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), ga, gb, idx, y, out, channels, h, w, ph, pw, k, s, p,
+                       static_cast<unsigned>(total4));
+    return check_launch("maxpool_bwd_relu");
+}
