@@ -149,6 +149,11 @@ class Attack(object):
         return -self.loss(logits, label) if self.targeted else self.loss(logits, label)
 
     def get_grad(self, loss, delta, **kwargs):
+        """d(loss)/d(delta) (attack.py:118-122).  Contract for overrides: the kernel that wrote the returned tensor may have
+        attached per-tile sums of |g| to it (``tensor._ta_partials``, see ``_hip``), which the fused update uses instead of
+        reading g again.  torch in-place operations invalidate them by themselves (version counter); code that changes the
+        gradient's memory behind torch's back (a foreign kernel, a collective, a numpy / dlpack alias, ``.data``) must call
+        ``_hip.invalidate_partials(grad)`` -- or simply return a new tensor, which carries no sums."""
         return torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0]
 
     def get_momentum(self, grad, momentum, **kwargs):

@@ -4,6 +4,8 @@ the VIEW itself (not back through the transform), then runs the MI-FGSM update.
 Mirror of transferattack/input_transformation/ssm.py:34-99.  HIP: the spectrum view itself (``spectrum.spectrum_view``:
 two launches of the fp32-MFMA kernel ``ta_dct_pair`` instead of ~60 FFT-path launches), gradient accumulation, momentum +
 projected step.  The reference hard-codes a 3 x 224 x 224 Gaussian (ssm.py:48); so does the shape check here."""
+import os
+
 import torch
 
 from .. import _hip, spectrum
@@ -26,7 +28,11 @@ class SSM(MIFGSM):
             return self.noise_source(shape, None, None) if normal else self.noise_source(shape, 0.0, 1.0)
         # product mode: both tensors from the DEVICE generator.  (The reference draws the Gaussian on the host and uploads
         # it, ssm.py:48-49 -- 2.4 M normals per view on one core, which at 200 views per batch costs more than the
-        # surrogate; the distribution is the same, and seeded parity runs inject the host stream through noise_source.)
+        # surrogate; the distribution is the same.)  TA_SSM_HOST_NOISE=1 restores the reference's host draw of the Gaussian
+        # for seeded comparisons with it (its mask is a device draw there too, ssm.py:51); tests inject both through
+        # noise_source.
+        if normal and os.environ.get("TA_SSM_HOST_NOISE", "0") == "1":
+            return torch.randn(shape)
         return torch.randn(shape, device=self.device) if normal else torch.rand(shape, device=self.device)
 
     def transform(self, x, **kwargs):
