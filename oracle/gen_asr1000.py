@@ -4,6 +4,9 @@ Run in the build container only (needs /root/reference):
 
     python oracle/gen_asr1000.py mifgsm          # configs[1]: MI-FGSM on ResNet-50, ~30 min on 8 cores
     python oracle/gen_asr1000.py dts             # configs[2]: DIM + TIM + SIM on ResNet-50, 5 copies, ~2.5 h
+    python oracle/gen_asr1000.py ens             # configs[4]: ensemble MI-FGSM (RN50 + VGG-16 + Inc-v3 + ViT-B/16), first 320 images
+    python oracle/gen_asr1000.py vmifgsm         # configs[3]: VMI-FGSM on ViT-B/16, 20 neighbours, first 96 images (210 surrogate
+                                                 # evaluations per batch: the full set would take a day of CPU time)
 
 What it does, following /root/reference/main.py line by line with synthetic data in place of the ImageNet subset:
 
@@ -42,6 +45,10 @@ from transferattack_amd import backbones  # noqa: E402  (surrogate / victim defi
 
 N_IMAGES, BATCH, SEED_BASE, SIGN_IMAGES = 1000, 32, 5000, 16
 SURROGATE = ("resnet50", 0)
+# per configuration: (surrogates as (name, weight seed), images of the set that are attacked)
+CONFIGS = {"mifgsm": ([("resnet50", 0)], 1000), "dts": ([("resnet50", 0)], 1000),
+           "ens": ([("resnet50", 0), ("vgg16", 0), ("inception_v3", 0), ("vit_base_patch16_224", 0)], 320),
+           "vmifgsm": ([("vit_base_patch16_224", 0)], 96)}
 # (name, weight seed): the white-box row, the same architecture with other weights, and six held-out victims
 VICTIMS = (("resnet50", 0), ("resnet50", 1), ("resnet18", 0), ("resnet101", 0), ("vgg16", 0), ("mobilenet_v2", 0),
            ("inception_v3", 0), ("vit_base_patch16_224", 0))
@@ -62,8 +69,10 @@ def predictions(net, x, chunk=50):
 
 
 def make_attack(config, surrogate):
-    if config == "mifgsm":
-        return ref_shim.make_reference_attack("mifgsm", surrogate)
+    if config in ("mifgsm", "vmifgsm"):
+        return ref_shim.make_reference_attack(config, surrogate)
+    if config == "ens":
+        return ref_shim.make_reference_attack("ens", list(surrogate))
     if config == "dts":
         import gen_golden
         DTS = gen_golden._dts_class()
@@ -75,18 +84,21 @@ def make_attack(config, surrogate):
 
 def main():
     config = sys.argv[1] if len(sys.argv) > 1 else "mifgsm"
-    n_images = int(os.environ.get("TA_ASR_IMAGES", N_IMAGES))
+    members, default_images = CONFIGS[config]
+    n_images = int(os.environ.get("TA_ASR_IMAGES", default_images))
     torch.set_num_threads(int(os.environ.get("TA_ASR_THREADS", "8")))
     scratch = os.path.join(SCRATCH, config)
     os.makedirs(scratch, exist_ok=True)
     xu8 = images_u8()[:n_images]
     x = xu8.float() / 255
-    surrogate = backbones.create(SURROGATE[0], seed=SURROGATE[1], verbose=False)
-    label_path = os.path.join(SCRATCH, "labels_%d.npy" % n_images)
+    nets = [backbones.create(m, seed=sd, verbose=False) for m, sd in members]
+    surrogate = nets[0] if len(nets) == 1 else nets
+    tag = "+".join("%s%d" % ms for ms in members)
+    label_path = os.path.join(SCRATCH, "labels_%s_%d.npy" % (tag, n_images))
     if os.path.isfile(label_path):
         label = torch.from_numpy(np.load(label_path))
     else:
-        label = predictions(surrogate, x)
+        label = predictions(surrogate, x)          # the (mean-logit) prediction of the surrogate(s) on the clean image
         np.save(label_path, label.numpy())
     atk = make_attack(config, surrogate)
     first_grad = []
@@ -120,12 +132,14 @@ def main():
     adv = np.concatenate([np.load(os.path.join(scratch, "adv_%03d.npy" % b)) for b in range(num_batches)])
     x_adv = torch.from_numpy(adv).permute(0, 3, 1, 2).float() / 255          # what AdvDataset reads back (utils.py:127-137)
     out = dict(label=label.numpy().astype(np.int16), n_images=n_images, batch=BATCH, seed_images=0, seed_base=SEED_BASE,
-               surrogate="%s:%d" % SURROGATE, victims=np.array(["%s:%d" % v for v in VICTIMS]),
+               surrogate=",".join("%s:%d" % ms for ms in members), victims=np.array(["%s:%d" % v for v in VICTIMS]),
                sign_images=SIGN_IMAGES, sign_bits=np.load(os.path.join(scratch, "sign_bits.npy")),
                sign_zeros=np.load(os.path.join(scratch, "sign_zeros.npy")),
                adv_crc32=np.array([__import__("zlib").crc32(adv.tobytes())], dtype=np.uint32))
     clean_path = os.path.join(SCRATCH, "clean_pred_%d.npy" % n_images)
-    clean = np.load(clean_path) if os.path.isfile(clean_path) else None
+    full_path = os.path.join(SCRATCH, "clean_pred_%d.npy" % N_IMAGES)          # the first n images of the same set
+    clean = np.load(clean_path) if os.path.isfile(clean_path) else (
+        np.load(full_path)[:, :n_images] if os.path.isfile(full_path) else None)
     if clean is None:
         clean = np.stack([predictions(backbones.create(m, seed=s, verbose=False), x).numpy() for m, s in VICTIMS])
         np.save(clean_path, clean)
@@ -134,7 +148,7 @@ def main():
     for (m, s), c, a in zip(VICTIMS, clean, advp):
         print("%-24s seed %d   ASR vs label %.1f %%   ASR vs the victim's clean prediction %.1f %%" % (
             m, s, 100 * (a != label.numpy()).mean(), 100 * (a != c).mean()))
-    path = os.path.join(ROOT, "tests", "golden", "asr1000_%s.npz" % config if n_images == N_IMAGES
+    path = os.path.join(ROOT, "tests", "golden", "asr1000_%s.npz" % config if n_images == default_images
                         else "asr%d_%s.npz" % (n_images, config))
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))

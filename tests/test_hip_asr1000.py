@@ -45,16 +45,22 @@ def fixture(config):
     return np.load(path)
 
 
-def product_attack(name, backbone, fold_bn=False, channels_last=False):
+def product_attack(name, nets, fold_bn=False, channels_last=False):
+    """the product's class ``name`` around the given seeded backbone(s) -- a list becomes an EnsembleModel (utils.py:82-105)"""
+    from transferattack_amd.utils import EnsembleModel
     base = ta.load_attack_class(name)
+    nets = nets if isinstance(nets, (list, tuple)) else [nets]
 
     def load_model(self, model_name):
-        for p in backbone.parameters():
-            p.requires_grad_(False)
-        if fold_bn:
-            backbones.fold_batchnorm(backbone)
-        wrapped = wrap_model(backbone.eval().to(DEV))
-        return wrapped.to(memory_format=torch.channels_last) if channels_last else wrapped
+        wrapped = []
+        for backbone in nets:
+            for p in backbone.parameters():
+                p.requires_grad_(False)
+            if fold_bn:
+                backbones.fold_batchnorm(backbone)
+            w = wrap_model(backbone.eval().to(DEV))
+            wrapped.append(w.to(memory_format=torch.channels_last) if channels_last else w)
+        return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
 
     return type("Gpu" + base.__name__, (base,), {"load_model": load_model})(model_name="injected")
 
@@ -74,17 +80,25 @@ def run_config(config, name, arrangement, g):
     xu8 = u8_images(n, 224, int(g["seed_images"]))
     x = xu8.float() / 255
     label = torch.from_numpy(g["label"].astype(np.int64))
-    sname, sseed = str(g["surrogate"]).split(":")
-    atk = product_attack(name, backbones.create(sname, seed=int(sseed), verbose=False), **arrangement)
+    nets = [backbones.create(spec.split(":")[0], seed=int(spec.split(":")[1]), verbose=False) for spec in str(g["surrogate"]).split(",")]
+    atk = product_attack(name, nets, **arrangement)
     first = []
-    inner = type(atk).get_grad
+    k = int(g["sign_images"])
+    if name == "vmifgsm":
+        # the folded VMI loop never calls get_grad (gradient/vmifgsm.py): its first-iteration gradient is the plain input
+        # gradient at delta = 0, taken here through the same surrogate before the attack runs
+        xs = x[:k].to(DEV).requires_grad_(True)
+        loss = atk.get_loss(atk.get_logits(xs), label[:k].to(DEV))
+        first.append(torch.autograd.grad(loss, xs)[0].detach())
+    else:
+        inner = type(atk).get_grad
 
-    def get_grad(self, loss, delta, **kw):
-        grad = inner(self, loss, delta, **kw)
-        if not first:
-            first.append(grad.detach().clone())
-        return grad
-    type(atk).get_grad = get_grad
+        def get_grad(self, loss, delta, **kw):
+            grad = inner(self, loss, delta, **kw)
+            if not first:
+                first.append(grad.detach().clone())
+            return grad
+        type(atk).get_grad = get_grad
 
     adv = np.empty((n, 224, 224, 3), np.uint8)
     torch.cuda.synchronize()
@@ -96,7 +110,6 @@ def run_config(config, name, arrangement, g):
         adv[lo:hi] = quantize_images(x[lo:hi], delta)         # utils.py:64 on the device
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
-    k = int(g["sign_images"])
     got = first[0][:k].cpu().numpy()
     ref_pos = np.unpackbits(g["sign_bits"])[:got.size].reshape(got.shape).astype(bool)
     agree = float(((got > 0) == ref_pos).mean())
@@ -157,3 +170,28 @@ def test_asr1000_dts_resnet50():
           "reference %.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
     assert agree >= 0.99
     check_rates("configs[2] DTS / ResNet-50", "reference-literal surrogate", g, x, label, adv)
+
+
+def test_asr_ens_four_members():
+    """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
+    utils.py:94-101), the first 320 images of the set (10 reference batches; the reference needs ~40 s of CPU time per image
+    here).  NOT YET RUN ON MI355X: the fixture was generated after this round's GPU minutes were spent."""
+    g = fixture("ens")
+    x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(), g)
+    print("\nconfigs[4]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the reference "
+          "%.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
+    assert agree >= 0.99
+    check_rates("configs[4] ensemble MI-FGSM / RN50 + VGG-16 + Inc-v3 + ViT-B/16", "reference-literal surrogates", g, x, label, adv)
+
+
+def test_asr_vmifgsm_vit():
+    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 96 images of the set (3 reference
+    batches = 630 surrogate evaluations of 32 images: ~1.5 h of reference CPU time).  The neighbours come from different
+    generators on the two paths (torch's CPU generator in the reference run, the in-kernel Philox stream here) -- as they would
+    between any two runs of the reference itself, which seeds nothing.  NOT YET RUN ON MI355X (see above)."""
+    g = fixture("vmifgsm")
+    x, label, adv, agree, seconds = run_config("configs[3]", "vmifgsm", dict(), g)
+    print("\nconfigs[3]: %d images in %.1f s (%.1f images/s); first-iteration gradient sign agreement with the reference "
+          "%.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
+    assert agree >= 0.99
+    check_rates("configs[3] VMI-FGSM / ViT-B/16", "reference-literal surrogate", g, x, label, adv)
