@@ -48,9 +48,8 @@ bsr)
   timeout 120 python tools/bsr_microbench.py 2> $OUT/bsr_microbench.err | tee $OUT/bsr_microbench.json
   timeout 200 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -k "bsr" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/bsr_pytest.txt ;;
 late)
-  # the GPU tests written after round 2's GPU minutes were spent (end of tests/test_zz_hip_widened.py): run these first
-  timeout 600 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
-      -k "ops_gpu or dim_largest or registry_rules or l2t_gpu or su_gpu or everywhere_gpu" 2>&1 | grep -v Warning | tail -15 | tee $OUT/late_pytest.txt ;;
+  # the GPU tests written after round 3's GPU minutes were spent: run these first
+  timeout 900 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "ens or vmifgsm" 2>&1 | grep -v Warning | tail -40 | tee $OUT/late_pytest.txt ;;
 dispatch)
   timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
