@@ -4,9 +4,9 @@ Run in the build container only (needs /root/reference):
 
     python oracle/gen_asr1000.py mifgsm          # configs[1]: MI-FGSM on ResNet-50, ~30 min on 8 cores
     python oracle/gen_asr1000.py dts             # configs[2]: DIM + TIM + SIM on ResNet-50, 5 copies, ~2.5 h
-    python oracle/gen_asr1000.py ens             # configs[4]: ensemble MI-FGSM (RN50 + VGG-16 + Inc-v3 + ViT-B/16), first 320 images
-    python oracle/gen_asr1000.py vmifgsm         # configs[3]: VMI-FGSM on ViT-B/16, 20 neighbours, first 96 images (210 surrogate
-                                                 # evaluations per batch: the full set would take a day of CPU time)
+    python oracle/gen_asr1000.py ens             # configs[4]: ensemble MI-FGSM (RN50 + VGG-16 + Inc-v3 + ViT-B/16), ~1 h
+    python oracle/gen_asr1000.py vmifgsm         # configs[3]: VMI-FGSM on ViT-B/16, 20 neighbours, first 320 images (210 surrogate
+                                                 # evaluations per batch, ~13 min each: the full set would take 7 h of CPU time)
 
 What it does, following /root/reference/main.py line by line with synthetic data in place of the ImageNet subset:
 
@@ -47,8 +47,8 @@ N_IMAGES, BATCH, SEED_BASE, SIGN_IMAGES = 1000, 32, 5000, 16
 SURROGATE = ("resnet50", 0)
 # per configuration: (surrogates as (name, weight seed), images of the set that are attacked)
 CONFIGS = {"mifgsm": ([("resnet50", 0)], 1000), "dts": ([("resnet50", 0)], 1000),
-           "ens": ([("resnet50", 0), ("vgg16", 0), ("inception_v3", 0), ("vit_base_patch16_224", 0)], 320),
-           "vmifgsm": ([("vit_base_patch16_224", 0)], 96)}
+           "ens": ([("resnet50", 0), ("vgg16", 0), ("inception_v3", 0), ("vit_base_patch16_224", 0)], 1000),
+           "vmifgsm": ([("vit_base_patch16_224", 0)], 320)}
 # (name, weight seed): the white-box row, the same architecture with other weights, and six held-out victims
 VICTIMS = (("resnet50", 0), ("resnet50", 1), ("resnet18", 0), ("resnet101", 0), ("vgg16", 0), ("mobilenet_v2", 0),
            ("inception_v3", 0), ("vit_base_patch16_224", 0))

@@ -155,3 +155,29 @@ def test_glue_kernels_against_aten(monkeypatch):
         ref = torch.ops.aten.threshold_backward(ga, res, 0)
         got = _hip.relu_mask(ga.clone(memory_format=torch.preserve_format), res, ga)
         assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+
+
+def test_attack_loops_through_the_fused_surrogate(monkeypatch):
+    """whole loops (MI-FGSM; DTS = DIM o SIM on the input + TIM on the gradient; ensemble of a fused and an unfused member) with the fused
+    ResNet execution against the same loops through the module path: identical perturbations on the CPU tier (with MIOpen's
+    stem backward; the MFMA stem kernel has its own summation order)"""
+    import transferattack_amd as ta
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("TA_FOLD_BN", "1")
+    monkeypatch.setenv("TA_CHANNELS_LAST", "1")
+    monkeypatch.setenv("TA_STEM_KERNEL", "0")
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 64, generator=gen)
+    label = torch.randint(0, 1000, (2,), generator=gen)
+    for name, model, kw in (("mifgsm", "resnet18", dict(epoch=3)), ("dts", "resnet18", dict(epoch=2, diversity_prob=1.0)),
+                            ("ens", ["resnet18", "mobilenet_v2"], dict(epoch=2))):
+        out = {}
+        for tag, flag in (("module", "0"), ("fused", "1")):
+            monkeypatch.setenv("TA_FUSED_GLUE", flag)
+            torch.manual_seed(123)
+            atk = ta.load_attack_class(name)(model_name=model, **kw)
+            for net in (atk.model.models if hasattr(atk.model, "models") else [atk.model]):
+                bias_as_on_rocm(net)
+            torch.manual_seed(456)
+            out[tag] = atk(x, label)
+        assert torch.equal(out["module"], out["fused"]), name
