@@ -174,8 +174,8 @@ def test_asr1000_dts_resnet50():
 
 def test_asr_ens_four_members():
     """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
-    utils.py:94-101), the first 320 images of the set (10 reference batches; the reference needs ~40 s of CPU time per image
-    here).  NOT YET RUN ON MI355X: the fixture was generated after this round's GPU minutes were spent."""
+    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here).  NOT YET RUN ON MI355X: the
+    fixture was generated after this round's GPU minutes were spent."""
     g = fixture("ens")
     x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(), g)
     print("\nconfigs[4]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the reference "
