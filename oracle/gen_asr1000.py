@@ -44,7 +44,6 @@ import fgsm_oracle as O  # noqa: E402
 from transferattack_amd import backbones  # noqa: E402  (surrogate / victim definitions only)
 
 N_IMAGES, BATCH, SEED_BASE, SIGN_IMAGES = 1000, 32, 5000, 16
-SURROGATE = ("resnet50", 0)
 # per configuration: (surrogates as (name, weight seed), images of the set that are attacked)
 CONFIGS = {"mifgsm": ([("resnet50", 0)], 1000), "dts": ([("resnet50", 0)], 1000),
            "ens": ([("resnet50", 0), ("vgg16", 0), ("inception_v3", 0), ("vit_base_patch16_224", 0)], 1000),

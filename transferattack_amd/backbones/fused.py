@@ -28,10 +28,6 @@ from torch.autograd.function import once_differentiable
 from .. import _hip
 
 
-def _conv_spec(conv):
-    return dict(stride=conv.stride, padding=conv.padding, dilation=conv.dilation, groups=conv.groups)
-
-
 def _conv(x, conv):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
