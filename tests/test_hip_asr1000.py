@@ -185,8 +185,8 @@ def test_asr_ens_four_members():
 
 
 def test_asr_vmifgsm_vit():
-    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 320 images of the set (10 reference
-    batches = 2100 surrogate evaluations of 32 images: ~2 h of reference CPU time).  The neighbours come from different
+    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 640 images of the set (20 reference
+    batches = 4200 surrogate evaluations of 32 images: ~4 h of reference CPU time).  The neighbours come from different
     generators on the two paths (torch's CPU generator in the reference run, the in-kernel Philox stream here) -- as they would
     between any two runs of the reference itself, which seeds nothing.  NOT YET RUN ON MI355X (see above)."""
     g = fixture("vmifgsm")
