@@ -47,7 +47,7 @@ N_IMAGES, BATCH, SEED_BASE, SIGN_IMAGES = 1000, 32, 5000, 16
 # per configuration: (surrogates as (name, weight seed), images of the set that are attacked)
 CONFIGS = {"mifgsm": ([("resnet50", 0)], 1000), "dts": ([("resnet50", 0)], 1000),
            "ens": ([("resnet50", 0), ("vgg16", 0), ("inception_v3", 0), ("vit_base_patch16_224", 0)], 1000),
-           "vmifgsm": ([("vit_base_patch16_224", 0)], 640)}
+           "vmifgsm": ([("vit_base_patch16_224", 0)], 1000)}
 # (name, weight seed): the white-box row, the same architecture with other weights, and six held-out victims
 VICTIMS = (("resnet50", 0), ("resnet50", 1), ("resnet18", 0), ("resnet101", 0), ("vgg16", 0), ("mobilenet_v2", 0),
            ("inception_v3", 0), ("vit_base_patch16_224", 0))
