@@ -26,7 +26,38 @@ def pytest_configure(config):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
 
 
+# Collection order of the -m gpu tier.  The driver runs it with -x, so ONE failure hides everything collected after it
+# (round 3: a surrogate-conditioning bound tripped at test 60 and the 106 kernel tests behind it never ran).  Order by
+# how deterministic the checked quantity is: bit-exact kernel parity first, loops with replayed reference gradients next,
+# whole surrogates on the device (MIOpen algorithm choice, atomics: run-to-run noise) last, statistics (ASR) at the very end.
+_GPU_TIERS = (
+    ("test_hip_kernels.py", None, 0),
+    ("test_hip_configs.py", ("kernel_on_device",), 0),
+    ("test_zz_hip_widened.py", ("kernels", "plane_groups", "properties", "full_size", "spectrum", "largest_ratio",
+                                "registry_rules", "reference_sum_order"), 0),
+    ("test_hip_loops_golden.py", None, 1),
+    ("test_hip_attacks.py", ("replay",), 1),
+    ("test_hip_configs.py", ("replay",), 2),
+    ("test_zz_hip_widened.py", None, 3),
+    ("test_hip_attacks.py", ("gradient_accuracy",), 6),
+    ("test_hip_attacks.py", None, 4),
+    ("test_hip_rccl.py", None, 5),
+    ("test_hip_configs.py", None, 6),
+    ("test_hip_asr1000.py", None, 7),
+)
+
+
+def _gpu_tier(item):
+    fname = os.path.basename(str(item.fspath))
+    for f, keys, tier in _GPU_TIERS:
+        if f == fname and (keys is None or any(k in item.name for k in keys)):
+            return tier
+    return 4
+
+
 def pytest_collection_modifyitems(config, items):
+    order = {id(it): i for i, it in enumerate(items)}
+    items.sort(key=lambda it: ((_gpu_tier(it), order[id(it)]) if "gpu" in it.keywords else (-1, order[id(it)])))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

@@ -123,8 +123,70 @@ def test_fused_path_steps_aside(monkeypatch):
     net.fc.weight.requires_grad_(True)
     assert not fused.usable(net, x)
     net.fc.weight.requires_grad_(False)
+    # sub-modules swapped, not hooked: the modules' own path must run
+    for swap in (lambda n: setattr(n.layer1[0], "relu", torch.nn.LeakyReLU(0.1)),
+                 lambda n: setattr(n, "maxpool", torch.nn.MaxPool2d(3, 2, 1, ceil_mode=True)),
+                 lambda n: setattr(n, "avgpool", torch.nn.AdaptiveMaxPool2d(1)),
+                 lambda n: setattr(n.layer2[0], "downsample", torch.nn.Sequential(*n.layer2[0].downsample, torch.nn.Dropout(0.0))),
+                 lambda n: setattr(n.layer3[1], "conv2", torch.nn.Sequential(n.layer3[1].conv2))):
+        other = backbones.create("resnet18", seed=0, verbose=False)
+        for p in other.parameters():
+            p.requires_grad_(False)
+        backbones.fold_batchnorm(other)
+        assert fused.usable(other, x)
+        swap(other)
+        assert not fused.usable(other, x)
+        other(x)
     monkeypatch.setenv("TA_FUSED_GLUE", "0")
     assert not fused.usable(net, x)
+
+
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_fused_path_backpropagates_twice(monkeypatch, name):
+    """two gradients through ONE forward with retain_graph (vaifgsm.py:49: one per auxiliary loss; adaea.py:44,51: per-member
+    gradients, then the fused-logit gradient): the saved maps live in save_for_backward, not in ctx attributes cleared by the
+    first backward; and without retain_graph the second backward is autograd's own error, not a TypeError"""
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("TA_FUSED_GLUE", "1")
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 64, 64, generator=gen)
+    label = torch.randint(0, 1000, (2,), generator=gen)
+    net = backbones.create(name, seed=0, verbose=False)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    backbones.fold_batchnorm(net)
+    bias_as_on_rocm(net)
+    xin = x.clone().requires_grad_(True)
+    assert fused.usable(net, xin)
+    logits = net(xin)
+    loss_a = torch.nn.functional.cross_entropy(logits, label)
+    loss_b = logits.logsumexp(1).sum()
+    g_a = torch.autograd.grad(loss_a, xin, retain_graph=True)[0].clone()
+    g_b = torch.autograd.grad(loss_b, xin, retain_graph=True)[0].clone()
+    g_a2 = torch.autograd.grad(loss_a, xin)[0]
+    assert torch.equal(g_a, g_a2) and not torch.equal(g_a, g_b)
+    monkeypatch.setenv("TA_FUSED_GLUE", "0")
+    xm = x.clone().requires_grad_(True)
+    g_bm = torch.autograd.grad(net(xm).logsumexp(1).sum(), xm)[0]
+    assert torch.equal(g_b, g_bm)
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(loss_a, xin)                               # graph freed: autograd says so
+
+
+@pytest.mark.parametrize("attack,kw", [("vaifgsm", dict(epoch=2)), ("mifgsm", dict(epoch=2))])
+def test_retaining_attacks_run_in_the_bench_arrangement(monkeypatch, attack, kw):
+    """TA_FOLD_BN=1 (bench.py's arrangement) with an attack that backpropagates more than once per forward"""
+    import transferattack_amd as ta
+    host_kernels.install(monkeypatch)
+    monkeypatch.setenv("TA_FOLD_BN", "1")
+    monkeypatch.setenv("TA_FUSED_GLUE", "1")
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 64, generator=gen)
+    label = torch.randint(0, 1000, (2,), generator=gen)
+    atk = ta.load_attack_class(attack)(model_name="resnet18", **kw)
+    assert getattr(atk.model[1], "_bn_folded", False)
+    delta = atk(x, label)
+    assert float(delta.abs().max()) <= 16 / 255 + 1e-7 and float(delta.abs().max()) > 0
 
 
 def test_glue_kernels_against_aten(monkeypatch):

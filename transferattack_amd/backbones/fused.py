@@ -54,7 +54,47 @@ def usable(net, x):
         return False
     if any(p.requires_grad for p in net.parameters()):
         return False                                    # only the input gradient is implemented
-    return not observed(net)
+    return not observed(net) and topology_ok(net)
+
+
+def topology_ok(net):
+    """The fused forward hard-codes the topology of backbones.resnet (ReLU after every convolution, the stem's MaxPool2d, a
+    mean-pool + fc head, a projection shortcut of one convolution).  A surrogate whose sub-modules were SWAPPED rather than
+    hooked (a custom activation or pool for LinBP / BPA-style attacks, a ghost / dropout wrapper, an extra shortcut layer)
+    must run as the modules say: exact types are checked on every call (a few dozen isinstance tests), anything else gets the
+    module path."""
+    from . import resnet
+    nn = torch.nn
+    if type(net) is not resnet.ResNet or type(net.relu) is not nn.ReLU or type(net.bn1) is not nn.Identity:
+        return False
+    mp = net.maxpool
+    if type(mp) is not nn.MaxPool2d or _pair(mp.dilation) != [1, 1] or mp.ceil_mode or mp.return_indices:
+        return False
+    if type(net.avgpool) is not nn.AdaptiveAvgPool2d or net.avgpool.output_size not in (1, (1, 1)):
+        return False
+    if type(net.conv1) is not nn.Conv2d or type(net.fc) is not nn.Linear:
+        return False
+    kind = None
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        if type(layer) is not nn.Sequential:
+            return False
+        for blk in layer:
+            if type(blk) not in (resnet.BasicBlock, resnet.Bottleneck) or (kind is not None and type(blk) is not kind):
+                return False
+            kind = type(blk)
+            names = ("conv1", "conv2", "conv3") if kind is resnet.Bottleneck else ("conv1", "conv2")
+            if set(dict(blk.named_children())) - set(names) - {"bn1", "bn2", "bn3", "relu", "downsample"}:
+                return False
+            if type(blk.relu) is not nn.ReLU:
+                return False
+            for cname in names:
+                if type(getattr(blk, cname)) is not nn.Conv2d or type(getattr(blk, cname.replace("conv", "bn"))) is not nn.Identity:
+                    return False
+            ds = blk.downsample
+            if ds is not None and not (isinstance(ds, nn.Sequential) and len(ds) == 2 and type(ds[0]) is nn.Conv2d
+                                       and type(ds[1]) is nn.Identity):
+                return False
+    return True
 
 
 def mark_folded(net):
@@ -96,14 +136,24 @@ class _ResNetFn(torch.autograd.Function):
                 cur = y
         feat = cur.mean(dim=(2, 3))                                            # AdaptiveAvgPool2d(1) + flatten
         logits = F.linear(feat, net.fc.weight, net.fc.bias)
-        ctx.net, ctx.x, ctx.stem, ctx.pooled, ctx.idx, ctx.saved = net, x, stem, pooled, idx, saved
+        # through save_for_backward: autograd frees the maps itself after a backward without retain_graph, a second backward
+        # with retain_graph (vaifgsm.py:49 -- one gradient per auxiliary loss; adaea.py:44,51) finds them still there, and
+        # an in-place write to a saved map by anybody is caught by the version check
+        ctx.net, ctx.bottleneck = net, bottleneck
+        flat = [x, stem, pooled, idx]
+        for a, b, y in saved:
+            flat += [a, b, y] if bottleneck else [a, y]
+        ctx.save_for_backward(*flat)
         return logits
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_logits):
-        net, saved = ctx.net, ctx.saved
-        bottleneck = hasattr(net.layer1[0], "conv3")
+        net, bottleneck = ctx.net, ctx.bottleneck
+        flat = ctx.saved_tensors
+        x, stem, pooled, idx = flat[:4]
+        per = 3 if bottleneck else 2
+        saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(4, len(flat), per)]
         blocks = [blk for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for blk in layer]
         last_y = saved[-1][2]
         n, c, h, w = last_y.shape
@@ -116,7 +166,7 @@ class _ResNetFn(torch.autograd.Function):
         for i in range(len(blocks) - 1, -1, -1):
             blk = blocks[i]
             a, b, y = saved[i]
-            x_in = saved[i - 1][2] if i > 0 else ctx.pooled
+            x_in = saved[i - 1][2] if i > 0 else pooled
             # threshold of the block's output ReLU on the sum of the junction's two branches, in place on ``g`` (a fresh
             # convolution output nobody else holds; ``pending`` -- possibly the previous ``gm`` -- is only read)
             gm = _hip.relu_mask(g, y, g, gb=pending)
@@ -135,17 +185,14 @@ class _ResNetFn(torch.autograd.Function):
         k, st, pd = _pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding)
         cl = torch.channels_last
         if (os.environ.get("TA_POOL_KERNEL", "1") != "0" and k[0] == k[1] and st[0] == st[1] and pd[0] == pd[1]
-                and _pair(mp.dilation) == [1, 1] and not mp.ceil_mode and ctx.stem.shape[1] % 4 == 0
-                and all(t.is_contiguous(memory_format=cl) and not t.is_contiguous() for t in (ctx.stem, ctx.idx, g, pending))):
-            g_stem = _hip.maxpool_bwd_relu(g, ctx.idx, ctx.stem, torch.empty_like(ctx.stem), k[0], st[0], pd[0], gb=pending)
+                and _pair(mp.dilation) == [1, 1] and not mp.ceil_mode and stem.shape[1] % 4 == 0
+                and all(t.is_contiguous(memory_format=cl) and not t.is_contiguous() for t in (stem, idx, g, pending))):
+            g_stem = _hip.maxpool_bwd_relu(g, idx, stem, torch.empty_like(stem), k[0], st[0], pd[0], gb=pending)
         else:
             g_pooled = g + pending
-            g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(g_pooled, ctx.stem, k, st, pd, [1, 1], False, ctx.idx),
-                           ctx.stem)
-            _hip.relu_mask(g_stem, ctx.stem, g_stem)
-        gx = _stem_input_grad(net, g_stem, ctx.x)
-        ctx.saved = ctx.stem = ctx.pooled = ctx.idx = ctx.x = None
-        return gx, None
+            g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(g_pooled, stem, k, st, pd, [1, 1], False, idx), stem)
+            _hip.relu_mask(g_stem, stem, g_stem)
+        return _stem_input_grad(net, g_stem, x), None
 
 
 def _stem_input_grad(net, g_stem, x):
