@@ -195,6 +195,85 @@ def gen_loops():
     save("loops_toy", **out)
 
 
+def _record_hooks(atk, rec):
+    """wrap the reference instance's own hooks (attack.py:118-153) so that every call of the loop leaves its inputs and
+    outputs in ``rec`` in call order: (hook, {argument: tensor / float})"""
+    def clone(v):
+        return v.detach().clone() if torch.is_tensor(v) else v
+
+    for hook in ("init_delta", "get_grad", "get_momentum", "update_delta"):
+        orig = getattr(atk, hook)
+
+        def wrapped(*args, _orig=orig, _hook=hook, **kw):
+            out = _orig(*args, **kw)
+            if _hook == "init_delta":
+                rec.append((_hook, dict(out=clone(out))))
+            elif _hook == "get_grad":
+                rec.append((_hook, dict(out=clone(out))))
+            elif _hook == "get_momentum":
+                rec.append((_hook, dict(grad=clone(args[0]), momentum=clone(args[1]), out=clone(out))))
+            else:
+                rec.append((_hook, dict(delta=clone(args[0]), grad=clone(args[2]), alpha=clone(args[3]), out=clone(out))))
+            return out
+        setattr(atk, hook, wrapped)
+
+
+def gen_loops_hooks():
+    """Loop-level goldens for the branches of the base hooks that the plain L-inf / scalar-alpha loops never take: the REAL
+    reference runs whole attacks on the toy CNN and every hook call of the loop is recorded (inputs and outputs, in order):
+      * MI-FGSM with norm='l2' (update_delta's L2 branch, attack.py:148-151), zero start and random start (init_delta's
+        L2 branch, attack.py:136-140);
+      * MI-FGSM with random_start on the L-inf ball (attack.py:133-134);
+      * GRA -- update_delta with a TENSOR step M * alpha (gra.py:149);
+      * CWA on two members -- update_delta with a NEGATIVE step (cwa.py:69), random start by default.
+    tests/test_hip_loops_golden.py replays them on MI355X."""
+    n, size = 2, 32
+    xu8 = u8_images(n, size, 20)
+    x = xu8.float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(21))
+    out = dict(x_u8=xu8, label=label, seed=1234)
+    toy = lambda seed=3: backbones.create("toy_cnn", seed=seed, verbose=False)        # noqa: E731
+    cases = (
+        ("mifgsm_l2", "mifgsm", dict(norm="l2", epsilon=3.0, alpha=0.6), False),
+        ("mifgsm_l2_random", "mifgsm", dict(norm="l2", epsilon=3.0, alpha=0.6, random_start=True), False),
+        ("mifgsm_linf_random", "mifgsm", dict(random_start=True), False),
+        ("gra", "gra", dict(num_neighbor=2, epoch=5), False),
+        ("cwa", "cwa", dict(epoch=4), True),
+    )
+    for tag, name, kw, ens in cases:
+        if ens:
+            members = [toy(3), toy(4)]
+            ta = ref_shim.import_reference()
+            from transferattack.utils import wrap_model, EnsembleModel
+            base = ta.load_attack_class(name)
+            cls = type("Ref_" + name, (base,), {"load_model": lambda self, mn: EnsembleModel([wrap_model(m.eval()) for m in members])})
+            atk = cls(model_name=["a", "b"], **kw)
+        else:
+            atk = ref_shim.make_reference_attack(name, toy(), **kw)
+        rec = []
+        _record_hooks(atk, rec)
+        torch.manual_seed(1234)
+        delta = atk(x, label)
+        out[tag + ".delta"] = delta
+        out[tag + ".hooks"] = np.array([h for h, _ in rec])
+        seen = {}                                    # a tensor that is bit-identical to an earlier one is stored as its key
+        for k, (hook, args) in enumerate(rec):
+            for a, v in args.items():
+                key = "%s.%d.%s" % (tag, k, a)
+                if torch.is_tensor(v):
+                    h = v.numpy().tobytes()
+                    if h in seen:
+                        out[key] = np.array(seen[h])
+                    else:
+                        seen[h] = key
+                        out[key] = v
+                elif a == "alpha":
+                    out[key] = np.float64(v)
+                # a Python 0 / 0. momentum is simply absent
+        print(tag, "hook calls:", {h: sum(1 for hh, _ in rec if hh == h) for h in ("init_delta", "get_grad", "get_momentum", "update_delta")})
+    save("loops_hooks", **out)
+
+
 def gen_loops_more():
     """further gradient-family attacks riding on the same kernels -- whole loops by the
     reference's own classes on the toy CNN (same inputs / seeds as gen_loops)."""
@@ -480,6 +559,6 @@ ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_more", "loops_tail", "loops_tail2", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
+    which = sys.argv[1:] or ["update_stack", "tim", "dim", "copies", "loops", "loops_hooks", "loops_more", "loops_tail", "loops_tail2", "loops_ens", "sia", "bsr", "config1", "config2", "config3", "config4", "config5"]
     for w in which:
         globals()["gen_" + w]()

@@ -13,6 +13,7 @@ import torch
 
 import host_kernels
 import test_hip_attacks as A
+import test_hip_loops_golden as L
 from transferattack_amd import _hip
 
 
@@ -20,6 +21,7 @@ from transferattack_amd import _hip
 def host_backend(monkeypatch):
     host_kernels.install(monkeypatch)
     monkeypatch.setattr(A, "DEV", "cpu")
+    monkeypatch.setattr(L, "DEV", "cpu")
 
 
 import os
@@ -220,6 +222,7 @@ def reference_sum_order(monkeypatch):
     """TA_ATEN_SUM_LANES=8: |g| summed in the order of the AVX2 reference that wrote the goldens"""
     host_kernels.install(monkeypatch, tag="aten8", env={"TA_ATEN_SUM_LANES": "8"})
     monkeypatch.setattr(A, "DEV", "cpu")
+    monkeypatch.setattr(L, "DEV", "cpu")
 
 
 @pytest.mark.parametrize("name", _subset(["mifgsm", "nifgsm", "vmifgsm", "vnifgsm", "dim", "tim", "sim", "admix", "dts", "ens"],
@@ -293,3 +296,14 @@ def test_sia_bit_exact_in_reference_sum_order(golden, reference_sum_order):
     np.random.seed(99)
     torch.manual_seed(1234)
     assert np.array_equal(atk(x, label).numpy(), g["delta_sia"])
+
+
+@pytest.mark.parametrize("tag", list(L.CASES))
+def test_recorded_hook_calls(golden, tag):
+    """L2 branch, random starts, tensor and negative step: every hook call of the reference's loops (loops_hooks.npz)"""
+    L.test_recorded_hook_calls(golden, tag)
+
+
+@pytest.mark.parametrize("tag", list(L.CASES))
+def test_loop_with_replayed_gradients(golden, tag):
+    L.test_loop_with_replayed_gradients(golden, tag)

@@ -11,7 +11,7 @@ lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket" > $OUT/host.txt
 for step in $STEPS; do
 case $step in
 tests)
-  timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider -s --durations=25 > $OUT/pytest_gpu.log 2>&1
   grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -30 ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;

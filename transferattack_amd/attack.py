@@ -64,6 +64,8 @@ class Attack(object):
         self.rng_offset = 0
         # test hook: callable(shape, low, high) -> device tensor replacing an in-kernel uniform draw
         self.noise_source = None
+        # test hook: callable(shape, mean, std) -> tensor replacing the normal draw of the L2 random start
+        self.normal_source = None
 
     # ------------------------------------------------------------------------------------------ model
     def load_model(self, model_name):
@@ -176,10 +178,16 @@ class Attack(object):
                 _hip.init_delta_uniform(delta, data.contiguous(), self.epsilon, self.rng_seed, self._next_offset(),
                                         noise=noise)
             else:
-                delta.normal_(-self.epsilon, self.epsilon)
+                if self.normal_source is not None:          # test hook: the reference's CPU draws, in its order
+                    delta.copy_(self.normal_source(data.shape, -self.epsilon, self.epsilon))
+                else:
+                    delta.normal_(-self.epsilon, self.epsilon)
                 d_flat = delta.view(delta.size(0), -1)
                 n = d_flat.norm(p=2, dim=-1).view(delta.size(0), 1, 1, 1)
-                r = torch.zeros_like(data).uniform_(0, 1).to(self.device)
+                if self.noise_source is not None:
+                    r = self.noise_source(data.shape, 0, 1).to(self.device)
+                else:
+                    r = torch.zeros_like(data).uniform_(0, 1).to(self.device)
                 delta *= r / n * self.epsilon
                 delta = clamp(delta, img_min - data, img_max - data)
         delta.requires_grad = True
