@@ -62,7 +62,7 @@ def parse(argv=None):
     p.add_argument("--fold-bn", type=int, default=1,
                    help="fold the surrogate's eval-mode BatchNorm into its convolutions (algebraically exact)")
     p.add_argument("--channels-last", type=int, default=1, help="run the surrogate in NHWC memory format")
-    p.add_argument("--cpu-images", type=int, default=8, help="images of the CPU-baseline sample (0 = skip)")
+    p.add_argument("--cpu-images", type=int, default=32, help="images of the CPU-baseline sample (0 = skip); 32 = the reference's batch")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
     p.add_argument("--kernel-times", type=int, default=0,
                    help="time every HIP kernel call of the loop with events (config.kernels); for the transform attacks")
@@ -175,18 +175,34 @@ def summarise_kernels(records):
     return out
 
 
+def physical_cores():
+    """physical cores of this host (unique (socket, core) pairs of /proc/cpuinfo); hardware threads if that fails"""
+    try:
+        pairs, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+        return len(pairs) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(args):
-    """The reference's CPU path on this host's cores, on a bounded sample: ``cpu_images`` images x ``CPU_ITERS`` of the
-    K=10 iterations (every iteration costs the same: one surrogate forward/backward + the 13-kernel update stack),
-    scaled to K=10.  kind "reference": the reference's OWN ``Attack.forward`` (imported from /root/reference through
-    oracle/ref_shim.py -- only where that tree exists, i.e. the build container); kind "port": the oracle
-    (oracle/fgsm_oracle.py, the same ATen ops in the same order) -- what runs on the GPU box."""
+    """The reference's CPU path on this host's cores: ``cpu_images`` images (default 32, the reference's batch,
+    main.py:15) through ALL K=10 iterations (one surrogate forward/backward + the 13-kernel update stack each), at the
+    best of a thread sweep from 8 up to every hardware thread of the host (one iteration per count).  A slow host (one
+    iteration > 6 s) gets a proportionally shorter timed run, scaled to K=10 and said so in ``sample``.
+    kind "reference": the reference's OWN ``Attack.forward`` (imported from /root/reference through oracle/ref_shim.py --
+    only where that tree exists, i.e. the build container); kind "port": the oracle (oracle/fgsm_oracle.py, the same ATen
+    ops in the same order) -- what runs on the GPU box."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fgsm_oracle as O
     import ref_shim
     from transferattack_amd import backbones
-    cpu_iters = 3
-    cores = os.cpu_count() or 1
+    hw_threads = os.cpu_count() or 1
+    cores = physical_cores()
     model = backbones.create(args.model, seed=0, verbose=False)
     x, y = synthetic_batch(args.cpu_images, 0)
     kind = "port"
@@ -203,18 +219,23 @@ def cpu_baseline(args):
             kind = "reference"
         except Exception as exc:  # noqa: BLE001
             print("reference attack class unavailable (%r): timing the oracle port" % (exc,), file=sys.stderr)
-    # give the CPU path its best thread count (on a 2-socket host the default of one thread per core is far from
-    # the fastest for an 8-image batch): probe a few counts on one iteration, keep the quickest
-    default_threads = torch.get_num_threads()
-    best = (float("inf"), default_threads)
-    for th in sorted({min(t, default_threads) for t in (8, 16, 32, 64, default_threads)}):
+    # thread sweep: torch's default (one thread per hardware thread) is rarely the fastest on a 2-socket host
+    sweep, best = {}, (float("inf"), torch.get_num_threads())
+    counts = sorted({min(t, hw_threads) for t in (8, 16, 32, 64, 128, cores, hw_threads)})
+    budget_s, t_sweep = 45.0, time.time()
+    for th in counts:
+        if time.time() - t_sweep > budget_s:
+            break
         torch.set_num_threads(th)
         run(1)                                                         # warm-up at this count
         t0 = time.time()
         run(1)
-        best = min(best, (time.time() - t0, th))
+        dt1 = time.time() - t0
+        sweep[th] = round(args.cpu_images / (dt1 * 10), 3)             # images/s if all 10 iterations ran at this pace
+        best = min(best, (dt1, th))
     threads = best[1]
     torch.set_num_threads(threads)
+    cpu_iters = 10 if best[0] <= 6.0 else max(1, int(60.0 / best[0]))
     t0 = time.time()
     run(cpu_iters)
     dt = (time.time() - t0) / cpu_iters * 10
@@ -230,10 +251,13 @@ def cpu_baseline(args):
         mm = O.momentum_step(g, m, 1.0)
         O.delta_step(d, xx, mm, 1.6 / 255, 16 / 255)
     upd_ms = (time.time() - t1) / 5 * 1e3
-    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": threads, "kind": kind,
-            "sample": "%d synthetic images, %s on %s, %d of the K=10 iterations timed and scaled to 10, torch CPU "
-                      "with %d threads on a %d-hw-thread host (%s)" % (
-                          args.cpu_images, args.attack, args.model, cpu_iters, threads, cores,
+    return {"value": round(args.cpu_images / dt, 4), "unit": "images/s", "cores": cores, "threads_used": threads,
+            "hw_threads": hw_threads, "kind": kind, "thread_sweep_images_per_s": sweep,
+            "sample": "%d synthetic images (the reference's batch), %s on %s, %s, torch CPU with %d threads -- the best of the "
+                      "sweep -- on a host with %d physical cores / %d hardware threads (%s)" % (
+                          args.cpu_images, args.attack, args.model,
+                          "all K=10 iterations timed" if cpu_iters == 10 else
+                          "%d of the K=10 iterations timed and scaled to 10" % cpu_iters, threads, cores, hw_threads,
                           "the reference's own Attack.forward via oracle/ref_shim.py" if kind == "reference"
                           else "oracle/fgsm_oracle.py; /root/reference is not present on this host"),
             "update_stack_ms_n32": round(upd_ms, 3),
@@ -338,22 +362,28 @@ def over_ranks(dt, rate, world, dev):
     return float(tmax.item()), [round(float(r.item()), 2) for r in rates], dist.get_world_size(), dist.get_backend()
 
 
-def roofline(args, sink, dispatch_ms, timing_note, _hip):
+def roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken=False):
     """The fused update's launches of the timed region -> the ``roofline`` object (module docstring)."""
     # two clocks over the same launches: hipEventRecord markers before / after each call (they include the ~3 us the
     # command processor spends between a marker and a dependent kernel) and events bound to the kernels' own dispatch
     # packets (begin of the call's first kernel -> end of the update kernel: what rocprofv3 --kernel-trace reports).
     # The roofline figure uses the dispatch clock when it is sane, and always reports the marker clock beside it.
-    marker_us = [s.elapsed_time(e) * 1e3 for s, e, _, _, _ in sink]
+    marker_us = [rec[0].elapsed_time(rec[1]) * 1e3 for rec in sink]
     durs_us, clock = marker_us, "hipEventRecord markers around each call"
     if len(dispatch_ms) == len(sink) and all(0.0 < 1e3 * d <= m + 1.0 for d, m in zip(dispatch_ms, marker_us)):
         durs_us, clock = [1e3 * d for d in dispatch_ms], "HIP events bound to the kernels' dispatch packets"
-    launch_bytes = [n_ * e_ * b_ for _, _, n_, e_, b_ in sink]
+    launch_bytes = [rec[2] * rec[3] * rec[4] for rec in sink]
     mean_us = sum(durs_us) / len(durs_us)
     mean_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = sum(launch_bytes) / sum(durs_us) / 1e3            # GB/s over the launches of the timed region
     full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
     pmc = committed_pmc_traffic(sink, _hip)
+    # bytes the launches EXECUTE: with the byte source (ta_mi_update_u8; the probe's device flag said "byte-valued", checked
+    # by the caller after the run) the image operand costs 1 B instead of 4 B per element
+    u8 = [len(rec) > 5 and rec[5] and byte_source_taken for rec in sink]
+    executed = [b - 3 * rec[2] * rec[3] * int(t) for b, rec, t in zip(launch_bytes, sink, u8)]
+    contract = [rec[2] * rec[3] * BYTES_PER_ELEM for rec in sink]       # SURVEY 8(d): 24 B/element, nothing else counted
+    steady = [i for i, b in enumerate(launch_bytes) if b == max(launch_bytes)]
     return {"bound": "hbm", "kernel": ("ta_mi_update (mi_update_kernel; |g| tile sums left by the kernel "
                                        "that produced g)" if _hip.stats["k1_passes"] == 0 else
                                        "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
@@ -373,7 +403,28 @@ def roofline(args, sink, dispatch_ms, timing_note, _hip):
                                     "GBps": round(sum(b for _, b in full) / sum(d for d, _ in full) / 1e3, 1)},
             "k1_pass_skipped_launches": _hip.stats["partials_reused"],
             "k1_passes": _hip.stats["k1_passes"],
-            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4),
+            # the same launches priced three ways.  ``frac`` above: the algorithmic bytes of what each launch does (24 B
+            # per element for the update of SURVEY 8(d), -4 without a momentum to read, +4 when it also writes x + delta:
+            # the add of attack.py:88 that the reference runs as a 12-B pass).  ``frac_at_24B_contract``: 24 B per element
+            # and nothing else, steady-state launches only (the x + delta write is then unpaid work).  ``executed``: the
+            # bytes the kernel really requests -- with the byte source 1 B instead of 4 B for the image operand.
+            "frac_at_24B_contract": round(sum(contract[i] for i in steady) / sum(durs_us[i] for i in steady) / 1e3 / HBM_PEAK_GBS, 4),
+            "executed": {"byte_source_launches": sum(u8), "bytes_per_launch": int(sum(executed) / len(executed)),
+                         "GBps": round(sum(executed) / sum(durs_us) / 1e3, 1),
+                         "frac": round(sum(executed) / sum(durs_us) / 1e3 / HBM_PEAK_GBS, 4),
+                         "frac_of_measured_copy_peak_6290": round(sum(executed) / sum(durs_us) / 1e3 / 6290.0, 4)}}
+
+
+def byte_source_taken(batches):
+    """did the probe of the bench's image batches find them byte-valued (device flag 0)?  Read AFTER the timed region."""
+    from transferattack_amd import _hip
+    if os.environ.get("TA_U8_SOURCE", "1") == "0" or not batches[0][0].is_cuda:
+        return False
+    try:
+        return all(int(_hip.u8_source_probe(x.contiguous())[1].item()) == 0 for x, _ in batches)
+    except (_hip.HipExtensionError, ValueError):
+        return False
 
 
 def committed_pmc_traffic(sink, _hip):
@@ -390,14 +441,15 @@ def committed_pmc_traffic(sink, _hip):
         if "mi_update_kernel<" not in name:
             continue
         flags = [f.strip() for f in name[name.index("<") + 1:name.rindex(">")].split(",")]
-        # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV>
-        key = tuple(f == "true" for f in flags[4:8])
+        # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV[, X_U8]>
+        key = tuple(f == "true" for f in flags[4:8]) + (len(flags) > 8 and flags[8] == "true",)
         per_shape[key] = c["fetch_B_per_elem_corrected"] + c["write_B_per_elem"]
     k1 = next((c["fetch_B_per_elem_corrected"] for name, c in kernels.items() if "abs_sum_partials" in name), 4.0)
     total, priced = 0.0, 0
-    for _, _, n_l, e_l, b_l in sink:
+    for rec in sink:
+        n_l, e_l, b_l = rec[2], rec[3], rec[4]
         # bytes/element -> which operands moved: 12 (g, d, x read; d written... ) + 4 each for m_in, m_out, x_adv
-        shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k)) == b_l and not k[0]]
+        shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k[:4])) == b_l and not k[0] and k[4] == (len(rec) > 5 and bool(rec[5]))]
         if shapes:
             total += per_shape[shapes[0]] * n_l * e_l
             priced += 1
@@ -490,10 +542,11 @@ def main(argv=None):
                                    "3x%dx%d, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
                                       args.image_size, args.image_size, args.batch, layout),
+                       "byte_source": os.environ.get("TA_U8_SOURCE", "1") != "0",
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "parallelism": layout, "gpus_requested": args.gpus, "ranks_observed": observed_world,
                        "collective_backend": backend, "images_per_s_per_rank": per_rank},
-            "roofline": roofline(args, sink, dispatch_ms, timing_note, _hip) if sink else None,
+            "roofline": roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken(batches)) if sink else None,
         }
         if kernel_records:
             result["config"]["kernels"] = summarise_kernels(kernel_records)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 7
+#define TA_ABI_VERSION 8
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -80,6 +80,28 @@ int ta_update_delta_l2(const float* delta_in, const float* x, const float* g, fl
 int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
                  const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
                  float eps, int64_t n, int64_t e, void* stream);
+/* PreprocessingModel WITH a Resize (transferattack/utils.py:50-53: Inception-v3 takes 299 x 299, mean = std = 0.5;
+ * utils.py:72-79): y = (bilinear_{in->out}(x) - mean[c]) / std[c] over [n, c, in, in] -> [n, c, out, out], ATen's
+ * upsample_bilinear2d arithmetic (align_corners=False; width first, then height), and its backward
+ * gx = upsample_bilinear2d_backward(gy / std[c]) in ATen's accumulation order -- one kernel each way.  The backward
+ * writes n * c * ta_resize_tiles(in) sums of |gx| to ws (nullable): c * tiles consecutive per image, a layout
+ * ta_mi_update takes.  Backward needs out <= ~1.5 * in (at most 4 outputs per input index), else TA_EINVAL. */
+int64_t ta_resize_tiles(int side);
+int ta_resize_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
+                            int in_size, int out_size, void* stream);
+int ta_resize_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int in_size,
+                            int out_size, void* stream);
+/* The byte source of the fused update.  The images of this path are PNG-decoded (transferattack/utils.py:136:
+ * `image.astype(np.float32) / 255`), so x[i] == float(k) / 255 for a byte k.  ta_u8_source_probe writes k =
+ * round(x * 255) for every element to x_u8 and sets *mismatch (device int, zeroed by the call) to 1 if any element is NOT
+ * reproduced bit for bit by that division -- once per batch, asynchronous.  ta_mi_update_u8 is ta_mi_update with that
+ * pair: the kernel reads *mismatch itself and takes 1 B/element from x_u8 when it is 0 (x rebuilt with the division's
+ * bits; 21 (+4) B/element instead of 24 (+4)), the fp32 x otherwise -- same results either way, no host round trip,
+ * hipGraph-capturable.  Needs e % 4 == 0 and 16-byte aligned fp32 operands to use the bytes. */
+int ta_u8_source_probe(const float* x, uint8_t* x_u8, int* mismatch, int64_t numel, void* stream);
+int ta_mi_update_u8(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                    const float* x, const uint8_t* x_u8, const int* u8_mismatch, float* x_adv, float* ws,
+                    int ws_slots, float decay, float alpha, float eps, int64_t n, int64_t e, void* stream);
 /* PreprocessingModel's Normalize (transferattack/utils.py:72-79, torchvision Normalize): y = (x - mean[c]) / std[c]
  * over [n, c, hw]; mean/std: device fp32 [c].  Backward gx = gy / std[c] (the last kernel of the surrogate's
  * backward, i.e. the producer of the gradient) also writes the |gx| tile sums to ws in K1's layout. */

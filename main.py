@@ -9,8 +9,10 @@ parsed but, as in the reference (main.py:41), not forwarded -- every attack runs
 Added flags: --seed (per-batch seeding so results do not depend on the GPU count), --resume (skip finished batches),
 --coalesce K (attacks that treat the images of a batch independently -- transferattack_amd.BATCH_INDEPENDENT -- run K
 reference batches per device batch: the per-image L1 normalisation and the sign step make the result independent of how the
-loss is averaged over the batch, and a 128-image launch uses the GPU better than four 32-image ones; DIM / Admix / ... keep
-the reference's batches), --profile (seconds per pipeline stage at the end).
+loss is averaged over the batch, and a 128-image launch uses the GPU better than four 32-image ones -- at 4x the activation
+memory, and MIOpen may pick other algorithms for the larger batch, so "same result" means same arithmetic per image, not a
+bit guarantee on the device; DIM / Admix / ... keep the reference's batches, and attacks that draw noise on the device
+(VMI / VNI neighbours, random starts) default to K = 1 so that an image's draws do not depend on the grouping), --profile (seconds per pipeline stage at the end).
 Input pipeline: threaded PNG decode -> page-locked staging buffer -> asynchronous upload on a side stream while the previous
 batch runs; output: GPU quantiser -> uint8 download -> threaded PNG encode, also overlapped.  With several processes the
 dataset is sharded by whole batches (transferattack_amd.dist.shard_batches); for ``--attack ens`` every group of
@@ -145,8 +147,12 @@ def main():
             if world > 1:                      # every rank decides from the same directory listing before anyone writes
                 torch.distributed.barrier()
         # device batches: K reference batches at a time where the attack does not couple the images of a batch
+        # default: 4 for the batch-independent attacks that draw nothing on the device; 1 for those that do (VMI / VNI
+        # neighbours, --random_start: the in-kernel Philox counter runs over the flat element index of the DEVICE batch, so
+        # an image's draws would depend on how batches were grouped -- i.e. on the GPU count and on what --resume skipped)
+        draws_on_device = args.attack in transferattack.DEVICE_NOISE or getattr(attacker, "random_start", False)
         k = args.coalesce if args.coalesce > 0 else (4 if args.attack in transferattack.BATCH_INDEPENDENT
-                                                     and not isinstance(args.model, list) else 1)
+                                                     and not isinstance(args.model, list) and not draws_on_device else 1)
         if args.attack not in transferattack.BATCH_INDEPENDENT:
             k = 1
         # groups of 4 / 2 / 1 FULL reference batches (a short last batch stays alone): the batch-mean loss then carries

@@ -38,8 +38,17 @@ def update_delta_l2(delta_in, data, grad, alpha, epsilon, delta_out):
     delta_out.copy_(O.delta_step(delta_in, data, grad, alpha, epsilon, norm="l2"))
 
 
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None):
+def u8_source_probe(data):
+    calls.append("u8_source_probe")
+    u8 = torch.round(data * 255).clamp(0, 255).to(torch.uint8)
+    exact = bool(torch.equal(u8.float() / 255, data))
+    return u8, torch.tensor([0 if exact else 1], dtype=torch.int32)
+
+
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None):
     calls.append("mi_update")
+    if data_u8 is not None and int(data_u8[1]) == 0:            # the byte source stands for exactly these floats
+        assert torch.equal(data_u8[0].float() / 255, data)
     g = grad if variance is None else grad + variance
     m = O.momentum_step(g, 0 if momentum_in is None else momentum_in, decay)
     d = O.delta_step(delta, data, m, alpha, epsilon)
@@ -48,6 +57,20 @@ def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilo
     delta.copy_(d)
     if x_adv is not None:
         x_adv.copy_(data + d)
+
+
+def resize_normalize_fwd(x, y, mean, std):
+    calls.append("resize_normalize_fwd")
+    v = torch.nn.functional.interpolate(x, size=tuple(y.shape[-2:]), mode="bilinear", align_corners=False)
+    y.copy_((v - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
+
+
+def resize_normalize_bwd(gy, gx, std):
+    calls.append("resize_normalize_bwd")
+    with torch.enable_grad():
+        xin = torch.zeros_like(gx).requires_grad_(True)
+        v = torch.nn.functional.interpolate(xin, size=tuple(gy.shape[-2:]), mode="bilinear", align_corners=False)
+        gx.copy_(torch.autograd.grad(v, xin, gy / std.view(1, -1, 1, 1))[0])
 
 
 def init_delta_uniform(delta, data, epsilon, seed=0, offset=0, noise=None):
@@ -220,10 +243,10 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
         gx.copy_(torch.autograd.grad(y, xin, gy)[0])
 
 
-_NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "init_delta_uniform",
+_NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "u8_source_probe", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
-          "normalize_bwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate"]
+          "normalize_bwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate", "resize_normalize_fwd", "resize_normalize_bwd"]
 
 
 def _fft_spectrum_view(x, noise, mask):

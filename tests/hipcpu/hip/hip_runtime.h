@@ -64,6 +64,9 @@ static inline void __syncthreads() { hipcpu::barrier(); }
 static inline float __shfl_xor(float v, int lane_mask, int width = 64) { return hipcpu::shfl_xor(v, lane_mask, width); }
 
 /* one workgroup = one OS thread: LDS atomics need no hardware atomicity here */
+/* global-memory flag shared by workgroups on different OS threads */
+static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) { memset(p, value, bytes); return hipSuccess; }
 static inline int atomicMin(int* p, int v) { const int old = *p; if (v < old) *p = v; return old; }
 static inline int atomicMax(int* p, int v) { const int old = *p; if (v > old) *p = v; return old; }
 

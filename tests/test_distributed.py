@@ -113,6 +113,48 @@ def _rank_ensemble(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _rank_ensemble_ind(rank, world, port, out):
+    """mode 'ind' (utils.py:101-103): the [M, N, classes] stack and the gradient of a loss that treats the members differently"""
+    tadist = _setup(rank, world, port)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import wrap_model
+    from conftest import u8_images
+    x = (u8_images(4, 32, 5).float() / 255).requires_grad_(True)
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    grp, idx, _, _ = tadist.model_groups(world, 2)
+    member = wrap_model(backbones.create("toy_cnn", seed=3 + rank, verbose=False).eval())
+    ens = tadist.ShardedEnsemble(member, grp, 2, mode='ind')
+    stack = ens(x)
+    loss = torch.nn.functional.cross_entropy(stack[0], y) + 3.0 * torch.nn.functional.cross_entropy(stack[1], y)
+    grad = torch.autograd.grad(loss, x)[0]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (stack.detach().numpy(), grad.numpy()))
+    if rank == 0:
+        np.savez(out, s0=gathered[0][0], g0=gathered[0][1], s1=gathered[1][0], g1=gathered[1][1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ensemble_mode_ind(tmp_path, monkeypatch):
+    """ShardedEnsemble(mode='ind') on 2 ranks == EnsembleModel(mode='ind') in one process: same stack, same input gradient"""
+    got = _run(_rank_ensemble_ind, tmp_path)
+    assert np.array_equal(got["s0"], got["s1"]) and np.array_equal(got["g0"], got["g1"])
+    import fake_hip
+    fake_hip.install(monkeypatch)
+    from transferattack_amd import backbones
+    from transferattack_amd.utils import EnsembleModel, wrap_model
+    from conftest import u8_images
+    x = (u8_images(4, 32, 5).float() / 255).requires_grad_(True)
+    y = torch.randint(0, 10, (4,), generator=torch.Generator().manual_seed(6))
+    ens = EnsembleModel([wrap_model(backbones.create("toy_cnn", seed=3 + k, verbose=False).eval()) for k in range(2)], mode='ind')
+    stack = ens(x)
+    loss = torch.nn.functional.cross_entropy(stack[0], y) + 3.0 * torch.nn.functional.cross_entropy(stack[1], y)
+    grad = torch.autograd.grad(loss, x)[0]
+    assert stack.shape == (2, 4, 10)
+    np.testing.assert_allclose(got["s0"], stack.detach().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["g0"], grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def _rank_ensemble_bsr(rank, world, port, out):
     """a transform attack that draws from Python's ``random`` (BSR: axis order, strips, permutations) on a model list:
     every rank of the group must apply the SAME transform or the all-reduced gradient mixes pixel arrangements"""

@@ -8,19 +8,30 @@ applied to its output on the device.
 
 Bit equality of the images is unattainable end to end (a random-init ReLU network's fp32 input gradient differs between
 ANY two machines by ~1e-2, and the sign step amplifies that: DESIGN.md section 4), so the statement that can hold -- and
-the one north_star asks for -- is equality of the attack success rate within the sampling error of 1000 images.  Both
-paths attack the SAME images, so the right statistic is the paired one (McNemar): with b / c the images only one of the
-two paths fools,
+the one north_star asks for -- is equality of the attack success rate within the sampling error of 1000 images.
 
-    z = |b - c| / sqrt(b + c)        asserted:  z <= 3.5   (and |ASR_gpu - ASR_ref| <= 3 images when b + c < 9)
+WHAT IS COUNTED.  Surrogates AND victims are seeded random-init networks (no checkpoints offline): every ASR here is a
+statement about the two code paths on the same synthetic job, not about the published rows of the reference's README.  ASR
+is counted two ways (gen_asr1000.py's docstring): "vs label" -- main.py:90 literally, against the label the attack used --
+and "vs clean prediction" -- against the victim's own clean prediction.  With random-init victims the first is
+information-free (a victim agrees with the surrogate's label on ~0 % of the clean images, so the rate is ~100 % on both
+paths whatever the attack does): those rows are printed and NOT asserted unless the reference's rate is below 99 %, i.e.
+unless the row can tell the paths apart (it would with trained weights).
 
-3.5 rather than 3 because 8 victims x 2 definitions x 3 runs are tested at once (Bonferroni: 1 % false alarms overall).
-The review's unpaired bound 3 * sqrt(p (1 - p) / n) is printed beside it: the trajectories of the two paths decorrelate
-(78 % of the pixels differ), so which individual images fall differs in ~2 p (1 - p) n cases and that bound is only ~2.1
-standard deviations of the difference -- a correct implementation would trip it in 1 of 30 comparisons.  (r3a: every one
-of the 32 comparisons also met it.)  Plus agreement of the FIRST-iteration gradient sign with the reference's (>= 99 %:
-the inputs of both surrogates are identical there, whatever happens later).  ASR is counted two ways (gen_asr1000.py's docstring): against the label the
-attack used (main.py:90 literally) and against the victim's own clean prediction (the informative one for seeded victims).
+WHAT IS ASSERTED, per informative row.  Both paths attack the SAME images, so the exact test is the paired one (McNemar):
+with b / c the images only one of the two paths fools, b ~ Binomial(b + c, 1/2) under "same success rate".
+  * paired: the exact two-sided binomial p-value of (b, c) must be >= P_MIN = 6.3e-5 (|z| = 4 for large counts).  Round 3
+    used z <= 3.5 plus "|b - c| <= 3 when b + c < 9", and the latter tripped on the driver's box at (b, c) = (0, 4) -- a
+    1-in-8 event under the null, on an information-free row.  The exact p-value needs no small-count patch.
+  * unpaired: |ASR_gpu - ASR_ref| <= 4 * sqrt(2 p (1 - p) / n) -- the two-SAMPLE bound (two runs, each with its own
+    sampling error).  The review's one-sample 3 * sqrt(p (1 - p) / n) is printed beside it and not asserted: the
+    trajectories of the two paths decorrelate (78 % of the pixels differ), which images fall differs in ~2 p (1 - p) n
+    cases, so that bound is only ~2.1 standard deviations of the difference and a correct implementation trips it in ~1 of
+    30 comparisons (it was met by every comparison so far).
+  False alarms: ~50 asserted rows per tier run x 2 x 6.3e-5 at most ~ 0.6 % per run that a correct implementation fails; a
+  wrong sign, a stale momentum or a broken transform moves the rate by tens of points (|z| > 10).
+Plus agreement of the FIRST-iteration gradient sign with the reference's (>= 99 %: the inputs of both surrogates are
+identical there, whatever happens later).
 """
 import os
 import time
@@ -85,11 +96,12 @@ def run_config(config, name, arrangement, g):
     first = []
     k = int(g["sign_images"])
     if name == "vmifgsm":
-        # the folded VMI loop never calls get_grad (gradient/vmifgsm.py): its first-iteration gradient is the plain input
-        # gradient at delta = 0, taken here through the same surrogate before the attack runs
-        xs = x[:k].to(DEV).requires_grad_(True)
-        loss = atk.get_loss(atk.get_logits(xs), label[:k].to(DEV))
-        first.append(torch.autograd.grad(loss, xs)[0].detach())
+        # the folded VMI loop never calls get_grad (gradient/vmifgsm.py): its own first-iteration gradient -- normalize_fwd,
+        # the surrogate, normalize_bwd inside _forward_folded -- is taken through the loop's probe hook
+        def probe(it, grad):
+            if it == 0 and not first:
+                first.append(grad.detach().clone())
+        atk.grad_probe = probe
     else:
         inner = type(atk).get_grad
 
@@ -116,40 +128,58 @@ def run_config(config, name, arrangement, g):
     return x, label.numpy(), adv, agree, seconds
 
 
+P_MIN = 6.3e-5          # two-sided tail of |z| = 4
+
+
+def paired_p_value(b, c):
+    """exact two-sided binomial (sign / McNemar) test of "b and c are draws of the same coin" """
+    from scipy.stats import binomtest
+    return 1.0 if b + c == 0 else float(binomtest(b, b + c, 0.5).pvalue)
+
+
 def check_rates(config, tag, g, x, label, adv):
     n = len(label)
     x_adv = torch.from_numpy(adv).permute(0, 3, 1, 2).float() / 255
-    rows, worst = [], 0.0
+    rows = []
     for v, name in enumerate(g["victims"]):
         vname, vseed = str(name).split(":")
         net = backbones.create(vname, seed=int(vseed), verbose=False)
         clean_gpu, adv_gpu = predictions(net, x), predictions(net, x_adv)
-        clean_ref, adv_ref = g["clean_pred"][v].astype(np.int64), g["adv_pred"][v].astype(np.int64)
+        clean_ref, adv_ref = g["clean_pred"][v].astype(np.int64)[:n], g["adv_pred"][v].astype(np.int64)[:n]
         for kind, fooled_gpu, fooled_ref in (("vs label", adv_gpu != label, adv_ref != label),
                                              ("vs clean prediction", adv_gpu != clean_gpu, adv_ref != clean_ref)):
-            p_gpu, p_ref = fooled_gpu.mean(), fooled_ref.mean()
+            p_gpu, p_ref = float(fooled_gpu.mean()), float(fooled_ref.mean())
             p = 0.5 * (p_gpu + p_ref)
-            bound = max(3 * np.sqrt(p * (1 - p) / n), 3.0 / n)                       # the unpaired bound, reported
+            one_sample = max(3 * np.sqrt(p * (1 - p) / n), 3.0 / n)                  # the review's bound: printed
+            two_sample = max(4 * np.sqrt(2 * p * (1 - p) / n), 4.0 / n)              # asserted
             only_gpu, only_ref = int((fooled_gpu & ~fooled_ref).sum()), int((~fooled_gpu & fooled_ref).sum())
-            z = abs(only_gpu - only_ref) / np.sqrt(only_gpu + only_ref) if only_gpu + only_ref >= 9 else 0.0
-            rows.append((name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, float((clean_gpu == clean_ref).mean()), z))
-            worst = max(worst, z)
-    print("\n%s [%s], %d images: attack success rate, reference (CPU) vs product (MI355X)" % (config, tag, n))
-    for name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, same_clean, z in rows:
-        print("  %-26s %-20s ref %6.2f %%   gpu %6.2f %%   |diff| %5.2f (unpaired 3-sigma bound %5.2f: %s)   discordant "
-              "images %d / %d   paired z %.2f   clean predictions equal %.1f %%"
-              % (name, kind, 100 * p_ref, 100 * p_gpu, 100 * abs(p_gpu - p_ref), 100 * bound,
-                 "met" if abs(p_gpu - p_ref) <= bound else "EXCEEDED", only_gpu, only_ref, z, 100 * same_clean))
-    for name, kind, p_ref, p_gpu, bound, only_gpu, only_ref, same_clean, z in rows:
-        assert z <= 3.5, "%s %s: ASR %.2f %% on the GPU vs %.2f %% by the reference (paired z = %.2f)" % (
-            name, kind, 100 * p_gpu, 100 * p_ref, z)
-        if only_gpu + only_ref < 9:
-            assert abs(only_gpu - only_ref) <= 3, (name, kind, only_gpu, only_ref)
+            z = abs(only_gpu - only_ref) / np.sqrt(only_gpu + only_ref) if only_gpu + only_ref else 0.0
+            informative = kind == "vs clean prediction" or p_ref < 0.99
+            rows.append(dict(victim=str(name), kind=kind, p_ref=p_ref, p_gpu=p_gpu, one_sample=one_sample, two_sample=two_sample,
+                             b=only_gpu, c=only_ref, z=float(z), p_value=paired_p_value(only_gpu, only_ref),
+                             same_clean=float((clean_gpu == clean_ref).mean()), asserted=informative))
+    print("\n%s [%s], %d images (seeded random-init surrogate and victims): attack success rate, reference (CPU) vs product "
+          "(MI355X)" % (config, tag, n))
+    for r in rows:
+        print("  %-26s %-20s ref %6.2f %%   gpu %6.2f %%   |diff| %5.2f (two-sample 4-sigma bound %5.2f; one-sample 3-sigma "
+              "%5.2f: %s)   discordant images %d / %d   paired z %.2f, exact p %.3g   clean predictions equal %.1f %%   %s"
+              % (r["victim"], r["kind"], 100 * r["p_ref"], 100 * r["p_gpu"], 100 * abs(r["p_gpu"] - r["p_ref"]),
+                 100 * r["two_sample"], 100 * r["one_sample"],
+                 "met" if abs(r["p_gpu"] - r["p_ref"]) <= r["one_sample"] else "exceeded", r["b"], r["c"], r["z"], r["p_value"],
+                 100 * r["same_clean"], "asserted" if r["asserted"] else "not asserted: information-free for random-init victims"))
+    assert any(r["asserted"] and 0.02 < r["p_ref"] < 0.98 for r in rows), "no victim can tell the two paths apart"
+    for r in rows:
+        if not r["asserted"]:
+            continue
+        assert r["p_value"] >= P_MIN, "%s %s: ASR %.2f %% on the GPU vs %.2f %% by the reference (discordant %d / %d, p = %.2g)" % (
+            r["victim"], r["kind"], 100 * r["p_gpu"], 100 * r["p_ref"], r["b"], r["c"], r["p_value"])
+        assert abs(r["p_gpu"] - r["p_ref"]) <= r["two_sample"], "%s %s: ASR %.2f %% vs %.2f %% (two-sample 4-sigma bound %.2f)" % (
+            r["victim"], r["kind"], 100 * r["p_gpu"], 100 * r["p_ref"], 100 * r["two_sample"])
     return rows
 
 
 @pytest.mark.parametrize("tag,arrangement", [("reference-literal surrogate", dict()),
-                                             ("folded BatchNorm + NHWC, as bench.py", dict(fold_bn=True, channels_last=True))])
+                                             ("folded BatchNorm + NHWC + fused glue, as bench.py", dict(fold_bn=True, channels_last=True))])
 def test_asr1000_mifgsm_resnet50(tag, arrangement):
     """BASELINE.json configs[1]: MI-FGSM, ResNet-50, eps 16/255, alpha 1.6/255, K = 10, the 1000-image set"""
     g = fixture("mifgsm")
@@ -162,20 +192,21 @@ def test_asr1000_mifgsm_resnet50(tag, arrangement):
     check_rates("configs[1] MI-FGSM / ResNet-50", tag, g, x, label, adv)
 
 
-def test_asr1000_dts_resnet50():
+@pytest.mark.parametrize("tag,arrangement", [("reference-literal surrogate", dict()),
+                                             ("folded BatchNorm + NHWC + fused glue, as bench.py", dict(fold_bn=True, channels_last=True))])
+def test_asr1000_dts_resnet50(tag, arrangement):
     """BASELINE.json configs[2]: DIM + TIM + SIM (5 scale copies), ResNet-50, K = 10, the 1000-image set"""
     g = fixture("dts")
-    x, label, adv, agree, seconds = run_config("configs[2]", "dts", dict(), g)
-    print("\nconfigs[2]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the "
-          "reference %.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
+    x, label, adv, agree, seconds = run_config("configs[2]", "dts", arrangement, g)
+    print("\nconfigs[2] [%s]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the "
+          "reference %.3f %%" % (tag, len(label), seconds, len(label) / seconds, 100 * agree))
     assert agree >= 0.99
-    check_rates("configs[2] DTS / ResNet-50", "reference-literal surrogate", g, x, label, adv)
+    check_rates("configs[2] DTS / ResNet-50", tag, g, x, label, adv)
 
 
 def test_asr_ens_four_members():
     """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
-    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here).  NOT YET RUN ON MI355X: the
-    fixture was generated after this round's GPU minutes were spent."""
+    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here)."""
     g = fixture("ens")
     x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(), g)
     print("\nconfigs[4]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the reference "
@@ -188,7 +219,7 @@ def test_asr_vmifgsm_vit():
     """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 640 images of the set (20 reference
     batches = 4200 surrogate evaluations of 32 images: ~4 h of reference CPU time).  The neighbours come from different
     generators on the two paths (torch's CPU generator in the reference run, the in-kernel Philox stream here) -- as they would
-    between any two runs of the reference itself, which seeds nothing.  NOT YET RUN ON MI355X (see above)."""
+    between any two runs of the reference itself, which seeds nothing."""
     g = fixture("vmifgsm")
     x, label, adv, agree, seconds = run_config("configs[3]", "vmifgsm", dict(), g)
     print("\nconfigs[3]: %d images in %.1f s (%.1f images/s); first-iteration gradient sign agreement with the reference "

@@ -324,3 +324,44 @@ def test_per_member_ensemble_attacks_gpu(golden, name):
     mismatch = float((quantize_images(x, delta) != O.quantize_u8(x + t(g["delta_" + name]))).mean())
     print("%s: uint8 mismatch rate GPU-vs-reference %.4f%%" % (name, 100 * mismatch))
     assert mismatch <= 0.002          # measured on MI355X: <= 0.033 % (profiles/r02/pytest_gpu_summary_r2e.txt)
+
+
+def test_ensemble_members_on_streams(monkeypatch):
+    """EnsembleModel runs member k on HIP stream k (utils.py: _members_on_streams; autograd runs each member's backward on
+    that stream too): same kernels, same per-member order -> the logits and the summed input gradient of the one-stream run,
+    repeated to give an ordering bug between the streams a chance to show.  ResNet-18 + VGG-16 + ViT-B/16 at 224 px (the
+    stem / glue / Normalize kernels and the |g| sums of ta_sum_members included); the bound is 4x the run-to-run spread of
+    the one-stream run itself (MIOpen's atomically accumulated backward-data kernels), at least 1e-4 of the gradient's norm."""
+    names = ("resnet18", "vgg16", "vit_base_patch16_224")
+    nets = [wrap_model(backbones.create(n, seed=0, verbose=False).eval().to(DEV)) for n in names]
+    for net in nets:
+        for p in net.parameters():
+            p.requires_grad_(False)
+    ens = EnsembleModel(nets)
+    x = (u8_images(4, 224, 9).float() / 255).to(DEV)
+    label = torch.randint(0, 1000, (4,), generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run():
+        xin = x.clone().requires_grad_(True)
+        logits = ens(xin)
+        grad = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xin)[0]
+        sums = _hip.partials_of(grad)
+        assert sums is not None, "ta_sum_members left no |g| sums"
+        total = sums[0][:4 * sums[1]].view(4, -1).sum(1)
+        return logits.detach().clone(), grad.clone(), total.clone()
+
+    monkeypatch.setenv("TA_ENS_STREAMS", "0")
+    logits0, grad0, sums0 = run()
+    spread = max(float((run()[1] - grad0).norm() / grad0.norm()) for _ in range(3))      # the one-stream run against itself
+    assert torch.allclose(sums0.double(), grad0.double().abs().flatten(1).sum(1), rtol=1e-4)
+    monkeypatch.setenv("TA_ENS_STREAMS", "1")
+    worst = 0.0
+    for _ in range(6):
+        logits1, grad1, sums1 = run()
+        assert float((logits1 - logits0).abs().max()) <= 1e-5 * float(logits0.abs().max())
+        worst = max(worst, float((grad1 - grad0).norm() / grad0.norm()))
+        assert torch.allclose(sums1.double(), grad1.double().abs().flatten(1).sum(1), rtol=1e-4)
+    torch.cuda.synchronize()
+    print("ensemble on 3 member streams vs one stream: input-gradient rel-L2 difference <= %.2e over 6 runs (one stream "
+          "against itself: %.2e)" % (worst, spread))
+    assert worst <= max(1e-4, 4 * spread)

@@ -196,7 +196,7 @@ def _truth(name, x, label):
     return logits.detach(), grad
 
 
-@pytest.mark.parametrize("name", ["resnet18", "resnet50", "mobilenet_v2", "inception_v3", "vgg16", "vit_base_patch16_224"])
+@pytest.mark.parametrize("name", ["resnet18", "resnet50", "mobilenet_v2", "inception_v3", "vgg16", "vgg16_nhwc", "vit_base_patch16_224"])
 def test_fold_bn_channels_last_is_the_same_surrogate(monkeypatch, name):
     """bench.py's arrangement (TA_FOLD_BN=1 TA_CHANNELS_LAST=1, through Attack.load_model exactly as bench.py builds it)
     against the reference-literal one (separate BatchNorm, NCHW): both on the device in fp32, both against the fp64
@@ -204,13 +204,14 @@ def test_fold_bn_channels_last_is_the_same_surrogate(monkeypatch, name):
     >= 99% of the gradient -- everything the attack uses -- and an input-gradient error within 4x the literal one's OR below an
     absolute floor of 3e-2.  The floor is there because the gradient error of a seeded random-init surrogate is a run-to-run
     noisy quantity on the device (MIOpen's algorithm choice per fresh find-db, atomic accumulation in backward-data): for
-    VGG-16 the ratio bench / literal was 1.36, 2.06, 2.88, 3.02, 3.25 in rounds 2-3 and 4.002 on the round-3 driver box, where
-    a bare 4x bound stopped the -x run.  What is real under the noise, and REPORTED by the print below rather than hidden:
-    VGG-16's input gradient in NHWC is 2-4x further from the fp64 truth than in NCHW (4.4e-3 -> <= 1.75e-2; 5 conv + ReLU
-    stacks without normalisation amplify the different accumulation order of the NHWC kernels) -- harmless for the attack
-    (sign flips << 1 %, and tests/test_hip_asr1000.py::test_asr_ens_four_members runs VGG-16 in this arrangement against the
-    reference's ASR)."""
+    VGG-16 in NHWC the ratio bench / literal was 1.36, 2.06, 2.88, 3.02, 3.25 in rounds 2-3 and 4.002 on the round-3 driver
+    box, where a bare 4x bound stopped the -x run.  The finding under that noise -- VGG-16's input gradient is 2-4x further
+    from the fp64 truth in NHWC than in NCHW (4.4e-3 -> <= 1.75e-2) -- is acted on, not hidden: ``Attack.load_model`` no longer
+    puts the VGGs in NHWC (attack.py; ``TA_VGG_CHANNELS_LAST=1`` restores it), and the ``vgg16_nhwc`` case below keeps
+    measuring and printing the pair so the number stays on record."""
     n = 2
+    monkeypatch.setenv("TA_VGG_CHANNELS_LAST", "1" if name.endswith("_nhwc") else "0")
+    name = name.replace("_nhwc", "")
     x = u8_images(n, 224, 5).float() / 255
     label = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(6))
     logits64, grad64 = _truth(name, x, label)

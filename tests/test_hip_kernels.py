@@ -124,6 +124,87 @@ def test_update_without_momentum():
             assert torch.equal(d_full, d_lean) and torch.equal(xa, x + d_lean)
 
 
+def test_byte_source_of_the_fused_update():
+    """ta_u8_source_probe + ta_mi_update_u8: PNG-decoded images are float(byte) / 255 (utils.py:136); the fused update may then
+    read the byte (1 B instead of 4 B per element) and must produce the SAME momentum, delta and x + delta, bit for bit, in
+    every instantiation (first iteration, no momentum kept, variance term, with / without x_adv, cached and streaming loads).
+    A batch that is not byte-valued raises the device-side flag and the same launch reads the fp32 operand."""
+    every = (torch.arange(256, dtype=torch.float32) / 255).to(DEV).contiguous()          # the IEEE quotients
+    u8, flag = _hip.u8_source_probe(every)
+    assert int(flag.item()) == 0 and torch.equal(u8.cpu(), torch.arange(256, dtype=torch.uint8))
+    gen = torch.Generator().manual_seed(23)
+    for shape in ((2, 3, 224, 224), (125, 3, 224, 224), (3, 1, 6, 6)):                     # the middle one streams (NT)
+        if DEV == "cpu" and shape[0] > 8:
+            continue
+        xb = torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8)
+        x = (xb.float() / 255).to(DEV)
+        src = _hip.u8_source_probe(x)
+        assert int(src[1].item()) == 0 and torch.equal(src[0].cpu(), xb)
+        grad = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+        var = (torch.randn(shape, generator=gen) * 1e-5).to(DEV)
+        mom = torch.randn(shape, generator=gen).to(DEV)
+        delta = O.box_clamp((torch.randint(-10, 11, shape, generator=gen).float() * ALPHA).clamp(-EPS, EPS), 0 - x.cpu(), 1 - x.cpu()).to(DEV)
+        before = _hip.stats["u8_source_launches"]
+        for m_in, keep, use_var, want_xadv in ((mom, True, False, True), (mom, True, False, False), (None, True, False, True),
+                                               (None, False, False, True), (mom, True, True, True), (None, False, True, False)):
+            out = {}
+            for tag, source in (("fp32", None), ("bytes", src)):
+                d = delta.clone()
+                m_out = torch.empty_like(x) if keep else None
+                xa = torch.full_like(x, float("nan")) if want_xadv else None
+                _hip.abs_sum_partials(grad, var if use_var else None)
+                _hip.mi_update(grad, None if m_in is None else m_in.clone(), m_out, d, x, 1.0 if keep else 0.0, ALPHA, EPS,
+                               variance=var if use_var else None, x_adv=xa, data_u8=source)
+                out[tag] = (d, m_out, xa)
+            for a, b in zip(out["fp32"], out["bytes"]):
+                assert (a is None and b is None) or torch.equal(a, b)
+        assert _hip.stats["u8_source_launches"] == before + 6
+        # not byte-valued: the flag goes up, the launch reads the floats
+        y = x.clone()
+        y.view(-1)[y.numel() // 2] = 0.123456
+        src_y = _hip.u8_source_probe(y)
+        assert int(src_y[1].item()) == 1
+        d1, d2 = delta.clone(), delta.clone()
+        m1, m2 = torch.empty_like(x), torch.empty_like(x)
+        _hip.mi_update(grad, mom, m1, d1, y, 1.0, ALPHA, EPS)
+        _hip.mi_update(grad, mom, m2, d2, y, 1.0, ALPHA, EPS, data_u8=src_y)
+        assert torch.equal(d1, d2) and torch.equal(m1, m2)
+    for bad in (float("nan"), 1.5, -0.25, 1e-9):                                           # out of range / NaN: mismatch
+        z = torch.full((1, 3, 4, 4), 0.5 if bad != bad else bad, device=DEV)
+        z.view(-1)[5] = bad
+        assert int(_hip.u8_source_probe(z)[1].item()) == 1
+
+
+@pytest.mark.parametrize("n,in_size,out_size", [(2, 224, 299), (3, 37, 50), (1, 8, 11), (2, 64, 96), (1, 100, 101)])
+def test_resize_normalize_kernels(n, in_size, out_size):
+    """PreprocessingModel with a Resize (utils.py:50-53, 72-79: Inception-v3, 224 -> 299, mean = std = 0.5) as one kernel each
+    way, against the ops the reference runs: F.interpolate(bilinear, align_corners=False) + Normalize on torch's CPU path and
+    their autograd backward.  Forward: ATen's own result depends on its thread partitioning in the last bit (SURVEY 8c'),
+    so within 2.4e-7 / std (+ 1 ulp of the result) after the Normalize; backward: bit-exact (ATen's accumulation
+    order is thread-count invariant), and the |gx| tile sums equal K1's to summation order."""
+    gen = torch.Generator().manual_seed(n * 1000 + in_size)
+    x = torch.randint(0, 256, (n, 3, in_size, in_size), generator=gen).float() / 255
+    mean, std = torch.tensor([0.5, 0.45, 0.4]), torch.tensor([0.5, 0.25, 0.2])
+    xr = x.clone().requires_grad_(True)
+    v = torch.nn.functional.interpolate(xr, size=(out_size, out_size), mode="bilinear", align_corners=False)
+    y_ref = (v - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    gy = torch.randn(y_ref.shape, generator=gen)
+    gx_ref = torch.autograd.grad(y_ref, xr, gy)[0]
+    y = torch.full(y_ref.shape, float("nan"), device=DEV)
+    _hip.resize_normalize_fwd(x.to(DEV), y, mean.to(DEV), std.to(DEV))
+    err = (host(y).astype(np.float64) - y_ref.detach().numpy()).__abs__()
+    # ATen's bilinear on [0, 1] data moves by <= 1.8e-7 with its thread partitioning (SURVEY 8c'); then one division by std
+    bound = 2.4e-7 / std.view(1, 3, 1, 1).numpy() + 2.0 ** -23 * np.abs(y_ref.detach().numpy())
+    assert (err <= bound).all(), "forward off by %.3e" % float(err.max())
+    gx = torch.full(x.shape, float("nan"), device=DEV)
+    _hip.resize_normalize_bwd(gy.to(DEV), gx, std.to(DEV))
+    assert np.array_equal(host(gx), gx_ref.numpy()), "backward differs: max %.3e" % float(np.abs(host(gx) - gx_ref.numpy()).max())
+    ws, slots = _hip.partials_of(gx)
+    sums = host(ws)[:n * slots].reshape(n, slots).astype(np.float64).sum(1)
+    want = np.abs(gx_ref.numpy().astype(np.float64)).reshape(n, -1).sum(1)
+    assert np.allclose(sums, want, rtol=1e-5)
+
+
 def test_launch_timing():
     """ta_timing_begin / ta_timing_end: the fused update carries HIP events on its own dispatch packets -- same results
     as an untimed call, one positive duration per call (two-launch and handed-over forms), never longer than the

@@ -47,6 +47,8 @@ def test_fused_update_random(shape):
 test_producer_side_partials_all_kernels = G.test_producer_side_partials_all_kernels
 test_sum_members = G.test_sum_members
 test_update_without_momentum = G.test_update_without_momentum
+test_byte_source_of_the_fused_update = G.test_byte_source_of_the_fused_update
+test_resize_normalize_kernels = G.test_resize_normalize_kernels
 
 
 def test_bad_arguments_fail_loudly():

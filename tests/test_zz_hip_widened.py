@@ -596,7 +596,7 @@ def test_ssm_tricks_gpu_vs_reference(golden, name, kw):
 # ------------------------------------------------------------------ written after round 2's GPU minutes were spent
 def test_ops_gpu_vs_reference(golden):
     """OPS end to end on the GPU against the reference's golden loop (bit-exact on the host-logic tier; through the
-    kernels' code on the host: 0.000 %).  NOT YET RUN ON MI355X -- the bound is the tier's (0.5 %); on the device the
+    kernels' code on the host: 0.000 %).  The bound is the tier's (0.5 %); on the device the
     nearest-neighbour rotations can pick the other neighbour where a sampling point falls within rounding of a pixel
     boundary, which moves single pixels of single views out of the 7 a gradient is averaged over here."""
     _run_more_attack(golden, OPS[0], OPS[1], BOUND)
@@ -607,7 +607,7 @@ def test_ops_gpu_vs_reference(golden):
 def test_dim_largest_ratio(size, rate, geoms):
     """OPS's largest resize-pad rate: the table-driven DIM kernels at their limit (a 102-pixel window of the padded image
     per 32-pixel tile, 62.5 KB of LDS in the backward) -- bit-exact against the C oracle, as at every other ratio.
-    NOT YET RUN ON MI355X (green on the host stand-in)."""
+    (Green on MI355X since r4a.)"""
     import test_hip_kernels as K
     K.test_dim_random(size, rate, geoms)
 
@@ -643,6 +643,16 @@ def test_partials_registry_rules(monkeypatch):
     _hip.abs_sum_partials(grad)
     _hip.invalidate_partials(grad)                                             # what dist.py calls after a collective
     assert not reused()
+    # the trap the version counter cannot see: a write through .data (or dlpack / numpy / a foreign kernel).  The sums are
+    # taken (stale!) -- unless TA_DEBUG_PARTIALS=verify recomputes them, which refuses loudly
+    _hip.abs_sum_partials(grad)
+    grad.data[0].mul_(3.0)
+    monkeypatch.setenv("TA_DEBUG_PARTIALS", "verify")
+    with pytest.raises(_hip.HipExtensionError, match="stale"):
+        reused()
+    _hip.abs_sum_partials(grad)
+    assert reused()                                                            # fresh sums pass the verification
+    monkeypatch.delenv("TA_DEBUG_PARTIALS")
     _hip.abs_sum_partials(grad)
     monkeypatch.setattr(_hip, "_stream", lambda like=None: 12345)
     assert not reused()                                                        # consumer "on another stream"
@@ -650,7 +660,7 @@ def test_partials_registry_rules(monkeypatch):
 
 def test_l2t_gpu_vs_reference(golden):
     """L2T end to end on the GPU against the reference's golden loop (policy draws, drawn operation pairs on the HIP
-    kernels / device gathers, policy step, MI-FGSM step).  NOT YET RUN ON MI355X (bit-exact on the host-logic tier;
+    kernels / device gathers, policy step, MI-FGSM step).  (Green on MI355X since r4a; bit-exact on the host-logic tier;
     every operation pinned against the reference's own in tests/test_reference_live.py)."""
     import random
     from conftest import u8_images
@@ -671,7 +681,7 @@ def test_l2t_gpu_vs_reference(golden):
 
 def test_su_gpu_vs_reference(golden):
     """SU (targeted) end to end on the GPU against the reference's golden loop: local crop + DI on the device, feature
-    hook, TI smoothing through ta_depthwise_conv2d_same (5 x 5), fused update.  NOT YET RUN ON MI355X (bit-exact on the
+    hook, TI smoothing through ta_depthwise_conv2d_same (5 x 5), fused update.  (Green on MI355X since r4a; bit-exact on the
     host-logic tier)."""
     import random
     from conftest import u8_images
@@ -691,7 +701,7 @@ def test_su_gpu_vs_reference(golden):
 
 def test_everywhere_gpu_vs_reference(golden):
     """Everywhere Attack end to end on the GPU against the reference's golden loop (feature-mixup hooks, cell masks, DI,
-    TI through ta_depthwise_conv2d_same, its own momentum / box arithmetic).  NOT YET RUN ON MI355X (bit-exact on the
+    TI through ta_depthwise_conv2d_same, its own momentum / box arithmetic).  (Green on MI355X since r4a; bit-exact on the
     host-logic tier)."""
     import random
     from conftest import u8_images

@@ -100,6 +100,32 @@ rocprof)
   tail -1 $OUT/rocprof.log
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && (head -1 "$f"; grep -E "ta::" "$f"; grep -v naive "$f" | head -12 | cut -c1-160)
   find $OUT/prof -name "*kernel_trace.csv" -size +8M -delete; find $OUT/prof -name "*.db" -delete ;;
+newtests4)
+  # round 4: byte source of the fused update, loop-level goldens (L2 / tensor / negative step, random starts), partials verify mode
+  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_loops_golden.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
+      -k "test_hip_kernels or loops_golden or registry_rules" 2>&1 | grep -v Warning | tee $OUT/newtests4_pytest.txt | tail -25 ;;
+asr4)
+  timeout 1200 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "mifgsm_resnet50 or dts" 2>&1 | grep -v Warning | tee $OUT/asr4_pytest.txt | tail -60 ;;
+bench32)
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_b32.json
+  TA_U8_SOURCE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_b125_fp32_source.json ;;
+ens4)
+  # configs[4] on one GPU at the reference's batch and at the per-GPU shard (ensemble MI-FGSM treats images independently)
+  for b in 32 125; do
+  timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
+  done ;;
+members)
+  # one member at a time (MI-FGSM, batch 32): where configs[4]'s time goes
+  for m in vgg16 inception_v3 vit_base_patch16_224 mobilenet_v2; do
+  timeout 600 python bench.py --model $m --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_member_$m.json
+  done ;;
+dimpmc)
+  for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/dimpmc_$tag -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_$tag.log 2>&1 )
+  python tools/pmc_kernels.py $OUT/dimpmc_$tag | tee -a $OUT/dimpmc_summary.txt
+  done
+  find $OUT -name "*.db" -delete ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/tools/update_microbench.py > $R/$OUT/pmc_$c.log 2>&1 )

@@ -114,6 +114,96 @@ __global__ __launch_bounds__(BLOCK) void k2_persistent(const float* __restrict__
     }
 }
 
+// round 4: the byte source (x as uint8, rebuilt with the IEEE quotient's bits), with / without the x + delta write
+__device__ __forceinline__ float u8_to_unit(unsigned k) {
+    const float kf = (float)k, r255 = 1.0f / 255.0f, q = kf * r255;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, kf), r255, q);
+}
+template <int BLOCK, bool NT, bool XU8, bool XADV>
+__global__ __launch_bounds__(BLOCK) void k2b(const float* __restrict__ g, float* m, float* delta, const float* __restrict__ x,
+                                             const unsigned char* __restrict__ xb, float* __restrict__ xadv,
+                                             const float* __restrict__ ws, int tiles_ws, float decay, float alpha, float eps) {
+    constexpr int TILE = BLOCK * 4;
+    const long img = blockIdx.y;
+    const long off = (long)blockIdx.x * TILE + (long)threadIdx.x * 4;
+    if (off + 4 > E) return;
+    const long base = img * E + off;
+    const float4 pg = ld<NT>(g + base), pm = ld<NT>(m + base), pd = ld<NT>(delta + base);
+    float4 px;
+    if (XU8) {
+        const unsigned b = NT ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(xb + base))
+                              : *reinterpret_cast<const unsigned*>(xb + base);
+        px = make_float4(u8_to_unit(b & 255u), u8_to_unit((b >> 8) & 255u), u8_to_unit((b >> 16) & 255u), u8_to_unit(b >> 24));
+    } else px = ld<NT>(x + base);
+    const int lane = threadIdx.x & 63;
+    float t = 0.f;
+    for (int i = lane; i < tiles_ws; i += 64) t += ws[img * tiles_ws + i];
+    const float mean = wave_sum(t) / (float)E;
+    float4 om, od, oa;
+    const float* gm = &pg.x; const float* mm = &pm.x; const float* dd = &pd.x; const float* xx = &px.x;
+    float* o1 = &om.x; float* o2 = &od.x; float* o3 = &oa.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float mn = mm[k] * decay + gm[k] / mean;
+        o1[k] = mn;
+        o2[k] = project(dd[k] + alpha * sign_of(mn), xx[k], -eps, eps);
+        o3[k] = xx[k] + o2[k];
+    }
+    st<NT>(m + base, om);
+    st<NT>(delta + base, od);
+    if (XADV) st<false>(xadv + base, oa);
+}
+
+// persistent + software-pipelined: a workgroup walks tiles w, w + G, ...; the loads of the next tile are in flight while
+// the current one is computed and stored
+template <int BLOCK, bool NT, bool XU8, bool XADV>
+__global__ __launch_bounds__(BLOCK) void k2p(const float* __restrict__ g, float* m, float* delta, const float* __restrict__ x,
+                                             const unsigned char* __restrict__ xb, float* __restrict__ xadv,
+                                             const float* __restrict__ ws, int tiles_ws, int n, float decay, float alpha, float eps) {
+    constexpr int TILE = BLOCK * 4;
+    const int tiles = (E + TILE - 1) / TILE;
+    const long total = (long)n * tiles;
+    auto where = [&](long w, long& img, long& base, bool& ok) {
+        img = w / tiles;
+        const long off = (w % tiles) * TILE + (long)threadIdx.x * 4;
+        ok = w < total && off + 4 <= E;
+        base = img * E + off;
+    };
+    long img, base; bool ok;
+    where(blockIdx.x, img, base, ok);
+    float4 pg, pm, pd, px; unsigned pb = 0;
+    auto fetch = [&](long b) {
+        pg = ld<NT>(g + b); pm = ld<NT>(m + b); pd = ld<NT>(delta + b);
+        if (XU8) pb = *reinterpret_cast<const unsigned*>(xb + b); else px = ld<NT>(x + b);
+    };
+    if (ok) fetch(base);
+    for (long w = blockIdx.x; w < total; w += gridDim.x) {
+        const float4 cg = pg, cm = pm, cd = pd; float4 cx = px; const unsigned cb = pb;
+        const long cimg = img, cbase = base; const bool cok = ok;
+        where(w + gridDim.x, img, base, ok);
+        if (ok) fetch(base);
+        if (!cok) continue;
+        if (XU8) cx = make_float4(u8_to_unit(cb & 255u), u8_to_unit((cb >> 8) & 255u), u8_to_unit((cb >> 16) & 255u), u8_to_unit(cb >> 24));
+        const int lane = threadIdx.x & 63;
+        float t = 0.f;
+        for (int i = lane; i < tiles_ws; i += 64) t += ws[cimg * tiles_ws + i];
+        const float mean = wave_sum(t) / (float)E;
+        float4 om, od, oa;
+        const float* gm = &cg.x; const float* mm = &cm.x; const float* dd = &cd.x; const float* xx = &cx.x;
+        float* o1 = &om.x; float* o2 = &od.x; float* o3 = &oa.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mn = mm[k] * decay + gm[k] / mean;
+            o1[k] = mn;
+            o2[k] = project(dd[k] + alpha * sign_of(mn), xx[k], -eps, eps);
+            o3[k] = xx[k] + o2[k];
+        }
+        st<NT>(m + cbase, om);
+        st<NT>(delta + cbase, od);
+        if (XADV) st<false>(xadv + cbase, oa);
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void copy4(const float* __restrict__ a, const float* __restrict__ b,
                                              const float* __restrict__ c, const float* __restrict__ d, float* o1,
@@ -142,7 +232,7 @@ __global__ __launch_bounds__(256) void read4(const float* __restrict__ a, const 
     if (acc == 12345.678f) o[0] = acc;
 }
 
-struct Set { float *g, *m, *d, *x; };
+struct Set { float *g, *m, *d, *x, *xa; unsigned char* xb; };
 
 int main() {
     const int REPS = 40;
@@ -154,10 +244,12 @@ int main() {
         std::vector<float> host(numel);
         for (long i = 0; i < numel; ++i) host[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
         for (auto& s : sets) {
-            for (float** p : {&s.g, &s.m, &s.d, &s.x}) {
+            for (float** p : {&s.g, &s.m, &s.d, &s.x, &s.xa}) {
                 CHECK(hipMalloc(p, numel * 4));
                 CHECK(hipMemcpy(*p, host.data(), numel * 4, hipMemcpyHostToDevice));
             }
+            CHECK(hipMalloc(&s.xb, numel));
+            CHECK(hipMemcpy(s.xb, host.data(), numel, hipMemcpyHostToDevice));
         }
         float* ws; CHECK(hipMalloc(&ws, 4 * n * 256)); CHECK(hipMemset(ws, 0, 4 * n * 256));
         std::vector<float> wsh(n * 256, 100.0f); CHECK(hipMemcpy(ws, wsh.data(), 4 * n * 256, hipMemcpyHostToDevice));
@@ -209,7 +301,40 @@ int main() {
         run_bytes("copy 1in/1out 8192 blocks nt", 8.0, [&](Set& s) { hipLaunchKernelGGL((copy1<true>), dim3(8192), dim3(256), 0, 0, s.g, s.m, numel / 4); });
         run_bytes("read 4 streams 8192 blocks", 16.0, [&](Set& s) { hipLaunchKernelGGL((read4<false>), dim3(8192), dim3(256), 0, 0, s.g, s.m, s.d, s.x, ws, numel / 4); });
         run_bytes("read 4 streams 8192 blocks nt", 16.0, [&](Set& s) { hipLaunchKernelGGL((read4<true>), dim3(8192), dim3(256), 0, 0, s.g, s.m, s.d, s.x, ws, numel / 4); });
-        for (auto& s : sets) for (float* p : {s.g, s.m, s.d, s.x}) CHECK(hipFree(p));
+        // ---- round 4 variants: bytes per element executed / algorithmic (24 contract, +4 with the x + delta write)
+        auto run2 = [&](const char* name, double exec_b, double alg_b, auto launch) {
+            for (int i = 0; i < 4; ++i) launch(sets[i % 4]);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < REPS; ++i) launch(sets[i % 4]);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / REPS;
+            printf("n=%-4d %-44s %8.2f us  executed %4.0f B/el %7.1f GB/s   algorithmic %4.0f B/el %7.1f GB/s (%.3f of 8 TB/s)\n", n, name, us,
+                   exec_b, exec_b * numel / us / 1e3, alg_b, alg_b * numel / us / 1e3, alg_b * numel / us / 1e3 / 8000.0);
+        };
+        const int t512 = (E + 2047) / 2048;
+#define K2B(B, NTF, U8, XA)                                                                                               \
+        run2("k2b block" #B " nt" #NTF " u8=" #U8 " xadv=" #XA, 20.0 + (U8 ? 1 : 4) + (XA ? 4 : 0), 24.0 + (XA ? 4 : 0), [&](Set& s) { \
+            hipLaunchKernelGGL((k2b<B, NTF, U8, XA>), dim3((E + B * 4 - 1) / (B * 4), n), dim3(B), 0, 0, s.g, s.m, s.d, s.x, s.xb, s.xa, ws, 49, \
+                               1.0f, 0.00627f, 0.0627f);                                                                  \
+        })
+        (void)t512;
+        K2B(512, false, false, true); K2B(512, false, true, true); K2B(512, false, false, false); K2B(512, false, true, false);
+        K2B(512, true, false, true); K2B(512, true, true, true); K2B(512, true, false, false); K2B(512, true, true, false);
+        K2B(256, false, true, true); K2B(256, true, true, true); K2B(1024, false, true, true); K2B(1024, true, true, true);
+        for (int blocks : {512, 1024, 1536, 2048}) {
+            char name[96];
+#define K2P(B, NTF, U8, XA)                                                                                               \
+            snprintf(name, sizeof name, "k2p %d wgs block" #B " nt" #NTF " u8=" #U8 " xadv=" #XA, blocks);               \
+            run2(name, 20.0 + (U8 ? 1 : 4) + (XA ? 4 : 0), 24.0 + (XA ? 4 : 0), [&](Set& s) {                              \
+                hipLaunchKernelGGL((k2p<B, NTF, U8, XA>), dim3(blocks), dim3(B), 0, 0, s.g, s.m, s.d, s.x, s.xb, s.xa, ws, 49, n, \
+                                   1.0f, 0.00627f, 0.0627f);                                                              \
+            })
+            K2P(512, false, true, true); K2P(512, true, true, true); K2P(256, false, true, true); K2P(512, false, true, false);
+        }
+        for (auto& s : sets) { for (float* p : {s.g, s.m, s.d, s.x, s.xa}) CHECK(hipFree(p)); CHECK(hipFree(s.xb)); }
         CHECK(hipFree(ws));
     }
     return 0;

@@ -40,6 +40,23 @@ def main():
         g, m, d, x, xa = sets[i % 4]
         _hip.abs_sum_partials(g)
         _hip.mi_update(g, None, None, d, x, 0.0, 1.6 / 255, 16 / 255, x_adv=xa)
+    # the byte source (ta_mi_update_u8): byte-valued images, 1 B instead of 4 B per element of x
+    bsets = []
+    for g, m, d, x, xa in sets:
+        xb = (torch.randint(0, 256, x.shape, device="cuda", dtype=torch.uint8).float() / 255).contiguous()
+        bsets.append((g, m, d, xb, xa, _hip.u8_source_probe(xb)))
+    for i in range(REPS):                               # steady state with the byte source (25 B/element executed)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa, data_u8=src)
+    for i in range(REPS):                               # last iteration with the byte source (21 B/element executed)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, data_u8=src)
+    for i in range(REPS):                               # first iteration with the byte source
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials(g)
+        _hip.mi_update(g, None, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa, data_u8=src)
     torch.cuda.synchronize()
     print("microbench done N=%d" % N)
 

@@ -73,6 +73,9 @@ attack_zoo = {
 # partner, no batch statistic): the loop normalises the gradient per image (attack.py:124-128) and steps by its sign, so
 # even the 1/N of the batch-mean loss drops out.  main.py may run several reference batches of these per device batch.
 BATCH_INDEPENDENT = frozenset(['fgsm', 'ifgsm', 'mifgsm', 'nifgsm', 'vmifgsm', 'vnifgsm', 'tim', 'sim'])
+# ... of which these draw noise on the device (in-kernel Philox over the flat element index of the device batch): their
+# draws for one image depend on where the image sits in the device batch, so main.py does not regroup them by default
+DEVICE_NOISE = frozenset(['vmifgsm', 'vnifgsm'])
 
 
 def load_attack_class(attack_name):

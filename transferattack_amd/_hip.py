@@ -38,6 +38,11 @@ SIGNATURES = {
     "ta_update_delta_linf": (_int, [_vp, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _i64, _vp]),
     "ta_update_delta_l2": (_int, [_vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _i64, _vp]),
     "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
+    "ta_mi_update_u8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
+    "ta_u8_source_probe": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ta_resize_tiles": (_i64, [_int]),
+    "ta_resize_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
+    "ta_resize_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
     "ta_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_vmi_neighbor_normalized": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _int, _i64, _vp]),
@@ -71,7 +76,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipExtensionError(RuntimeError):
@@ -186,7 +191,7 @@ workspace = Workspace()
 #   * producer and consumer must be on the same stream (the sums are ordered after the producer only there);
 #   * the sums are of |g|, or of |g + variance| for exactly the variance tensor the producer was given (VMI-FGSM).
 _ATTR = "_ta_partials"     # (gradient's _version, ws tensor, sums per image, producer's stream, variance tensor | None, its _version)
-stats = {"partials_reused": 0, "k1_passes": 0}
+stats = {"partials_reused": 0, "k1_passes": 0, "u8_source_launches": 0}
 
 
 def _register_partials(grad, ws, slots, variance=None):
@@ -225,11 +230,30 @@ def _take_partials(grad, variance=None):
         var is not None and variance is not None and var.data_ptr() == variance.data_ptr() and var.shape == variance.shape
         and variance._version == var_version and var._version == var_version)
     if same_variance and grad._version == version and ws.device == grad.device and stream == _stream(grad):
+        if os.environ.get("TA_DEBUG_PARTIALS") == "verify":
+            _verify_partials(grad, variance, ws, slots)
         return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
         print("partials not reused: version %d vs %d, stream %s vs %s, variance match %s" % (
             grad._version, version, stream, _stream(grad), same_variance), flush=True)
     return None
+
+
+def _verify_partials(grad, variance, ws, slots):
+    """``TA_DEBUG_PARTIALS=verify``: the validity of the attached sums rests on object identity + ``_version``, which a write
+    through ``.data``, a dlpack / numpy alias or a foreign kernel does not move.  This debug mode recomputes sum|g (+ v)| per
+    image (fp64, one synchronising pass) and refuses sums that are not the gradient's -- run a new attack class under it once."""
+    n = grad.shape[0]
+    g = grad.detach().double() if variance is None else grad.detach().double() + variance.detach().double()
+    want = g.abs().reshape(n, -1).sum(1)
+    got = ws[:n * slots].double().reshape(n, slots).sum(1)
+    bad = ~((got - want).abs() <= 1e-4 * want.abs() + 1e-30)          # NaN-safe: a NaN sum must meet a NaN sum
+    bad &= ~(torch.isnan(got) & torch.isnan(want))
+    if bool(bad.any()):
+        i = int(bad.nonzero()[0])
+        raise HipExtensionError("TA_DEBUG_PARTIALS=verify: the |g| sums attached to this gradient are stale (image %d: attached "
+                                "%.9g, recomputed %.9g) -- the tensor was modified without torch noticing; call "
+                                "_hip.invalidate_partials(grad) after such a write" % (i, float(got[i]), float(want[i])))
 
 
 def _new_ws(like, count):
@@ -290,28 +314,53 @@ def timing_end():
     return [float(buf[i]) for i in range(count.value)]
 
 
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None):
+def u8_source_probe(data):
+    """(bytes, mismatch flag) of an image batch for ``mi_update(..., data_u8=...)``: ``bytes = round(data * 255)`` (uint8,
+    data's shape) and a device int that the kernel sets to 1 unless EVERY element of ``data`` is float(byte) / 255 bit for
+    bit -- true for PNG-decoded images (utils.py:136).  Asynchronous; nobody on the host reads the flag."""
+    if not data.is_contiguous():
+        raise ValueError("data must be contiguous")
+    u8 = torch.empty(data.shape, dtype=torch.uint8, device=data.device)
+    flag = torch.empty(1, dtype=torch.int32, device=data.device)
+    _call("ta_u8_source_probe", data, _ptr(data, name="data"), _ptr(u8, torch.uint8, name="data_u8"),
+          _ptr(flag, torch.int32, name="mismatch"), data.numel())
+    return u8, flag
+
+
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None):
     """Fused get_momentum + update_delta; ``delta`` is updated in place, momentum_out may alias momentum_in.
     ``momentum_in`` None = first iteration; ``momentum_out`` None = the momentum is not kept (decay == 0);
-    ``x_adv`` (optional) receives data + delta', the next iteration's input."""
+    ``x_adv`` (optional) receives data + delta', the next iteration's input; ``data_u8`` (optional) is
+    ``u8_source_probe(data)``: the kernel then reads one byte instead of four per element of ``data`` whenever the probe
+    found the batch byte-valued."""
     n, e = _batch(grad)
     if profile_sink is not None:
         dev = grad.device
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(dev))
-        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e)
+        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8)
         end.record(torch.cuda.current_stream(dev))
         bytes_per_elem = 4 * (3 + (variance is not None) + (momentum_in is not None) + 1 + (momentum_out is not None)
-                              + (x_adv is not None))       # r g,(v),(m),d,x  w (m),d,(x_adv)
-        profile_sink.append((start, end, n, e, bytes_per_elem))
+                              + (x_adv is not None))       # r g,(v),(m),d,x  w (m),d,(x_adv): the ALGORITHMIC bytes
+        profile_sink.append((start, end, n, e, bytes_per_elem, data_u8 is not None))
         return
-    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e)
+    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8)
 
 
-def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e):
+def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8=None):
     ready = _take_partials(grad, variance)
     stats["partials_reused" if ready is not None else "k1_passes"] += 1
     ws, slots = ready if ready is not None else (workspace.l1(grad, n, e), 0)
+    if data_u8 is not None:
+        u8, flag = data_u8
+        if u8.shape != data.shape or u8.device != data.device:
+            raise ValueError("data_u8 does not belong to data")
+        stats["u8_source_launches"] += 1
+        _call("ta_mi_update_u8", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"),
+              _ptr(momentum_in, name="momentum"), _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"),
+              _ptr(data, name="data"), _ptr(u8, torch.uint8, name="data_u8"), _ptr(flag, torch.int32, name="mismatch"),
+              _ptr(x_adv, name="x_adv"), _ptr(ws), slots, float(decay), float(alpha), float(epsilon), n, e)
+        return
     _call("ta_mi_update", grad, _ptr(grad, name="grad"), _ptr(variance, name="variance"),
           _ptr(momentum_in, name="momentum"), _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"),
           _ptr(data, name="data"), _ptr(x_adv, name="x_adv"), _ptr(ws), slots, float(decay), float(alpha),
@@ -345,6 +394,24 @@ def normalize_bwd(gy, gx, std, variance=None):
     _call("ta_normalize_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"),
           _ptr(variance, name="variance"), _ptr(ws), n, c, gy[0, 0].numel())
     _register_partials(gx, ws, slots, variance)
+
+
+def resize_normalize_fwd(x, y, mean, std):
+    """y[n, c, out, out] = (bilinear(x[n, c, in, in]) - mean[c]) / std[c] -- PreprocessingModel with a Resize (Inception-v3)"""
+    n, c, in_size, out_size = x.shape[0], x.shape[1], x.shape[-1], y.shape[-1]
+    _wrote(y)
+    _call("ta_resize_normalize_fwd", x, _ptr(x, name="x"), _ptr(y, name="y"), _ptr(mean, name="mean"), _ptr(std, name="std"),
+          n, c, in_size, out_size)
+
+
+def resize_normalize_bwd(gy, gx, std):
+    """gx[n, c, in, in] = upsample_bilinear2d_backward(gy[n, c, out, out] / std[c]); registers the |gx| tile sums"""
+    n, c, in_size, out_size = gx.shape[0], gx.shape[1], gx.shape[-1], gy.shape[-1]
+    tiles = load().ta_resize_tiles(in_size)
+    ws = _new_ws(gy, n * c * tiles)
+    _call("ta_resize_normalize_bwd", gy, _ptr(gy, name="gy"), _ptr(gx, name="gx"), _ptr(std, name="std"), _ptr(ws), n, c,
+          in_size, out_size)
+    _register_partials(gx, ws, c * tiles)
 
 
 def init_delta_uniform(delta, data, epsilon, seed=0, offset=0, noise=None):

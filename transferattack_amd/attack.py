@@ -66,6 +66,8 @@ class Attack(object):
         self.noise_source = None
         # test hook: callable(shape, mean, std) -> tensor replacing the normal draw of the L2 random start
         self.normal_source = None
+        # test hook of loops that never call get_grad (the folded VMI chain): callable(iteration, gradient)
+        self.grad_probe = None
 
     # ------------------------------------------------------------------------------------------ model
     def load_model(self, model_name):
@@ -79,9 +81,14 @@ class Attack(object):
             if os.environ.get("TA_FOLD_BN", "0") == "1":
                 backbones.fold_batchnorm(model)     # opt-in: eval-mode BN folded into the convolutions
             wrapped = wrap_model(model.eval().to(default_device()))
-            # NHWC is opt-in and skipped for Inception-v3: on ROCm 7.2 the NHWC fp32 backward-data kernels fault on
-            # its asymmetric 1x7 / 7x1 convolutions (profiles/r01/ens_diag/inc_nhwc.txt)
-            if os.environ.get("TA_CHANNELS_LAST", "0") == "1" and "Inc" not in model.__class__.__name__:
+            # NHWC is opt-in and skipped for Inception-v3 -- on ROCm 7.2 the NHWC fp32 backward-data kernels fault on its
+            # asymmetric 1x7 / 7x1 convolutions (profiles/r01/ens_diag/inc_nhwc.txt) -- and for the VGGs: +8 % throughput
+            # (profiles/r01/ens_diag/vgg_nhwc.txt) for an input gradient 2-4x further from the fp64 truth (4.4e-3 -> up to
+            # 1.75e-2 on the seeded VGG-16; GPUTEST_r03: 13 un-normalised conv + ReLU stages amplify the other
+            # accumulation order of MIOpen's NHWC kernels) is not a trade a parity-first engine makes by default
+            name = model.__class__.__name__
+            if os.environ.get("TA_CHANNELS_LAST", "0") == "1" and "Inc" not in name and not (
+                    "VGG" in name.upper() and os.environ.get("TA_VGG_CHANNELS_LAST", "0") != "1"):
                 wrapped = wrapped.to(memory_format=torch.channels_last)
             return wrapped
 
@@ -100,6 +107,7 @@ class Attack(object):
             label = label[1]
         data = data.clone().detach().to(self.device)
         label = label.clone().detach().to(self.device)
+        self._attach_byte_source(data)
 
         delta = self.init_delta(data)
         momentum = 0
@@ -140,8 +148,27 @@ class Attack(object):
         if variance is not None and not isinstance(variance, torch.Tensor):
             variance = None                                   # the Python 0 of the first VMI iteration
         _hip.mi_update(grad, m_in, m_out, delta.detach(), data, self.decay, self.alpha if alpha is None else alpha,
-                       self.epsilon, variance=variance, x_adv=x_adv)
+                       self.epsilon, variance=variance, x_adv=x_adv, data_u8=self._byte_source_of(data))
         return momentum if m_out is None else m_out
+
+    @staticmethod
+    def _byte_source_of(data):
+        """(bytes, mismatch flag) attached to ``data`` by ``_attach_byte_source``, if ``data`` still has the probed version"""
+        src = getattr(data, "_ta_u8", None)                 # (version of data when probed, bytes, mismatch flag)
+        return src[1:] if src is not None and src[0] == data._version else None
+
+    @staticmethod
+    def _attach_byte_source(data):
+        """The images of this path are PNG-decoded: ``float(byte) / 255`` (utils.py:136).  One asynchronous pass per batch
+        writes the bytes next to ``data`` and a device-side flag saying whether they reproduce it bit for bit; the fused
+        update then reads 1 B instead of 4 B per element of ``data`` in each of the K iterations -- or, if the flag says
+        otherwise (any other caller of the plug-in API), the fp32 operand: decided inside the kernel, identical results.
+        Travels as an attribute of the tensor (as the |g| sums do), valid while ``data`` keeps its version.
+        ``TA_U8_SOURCE=0`` turns it off."""
+        if (os.environ.get("TA_U8_SOURCE", "1") == "0" or data.dtype != torch.float32 or not data.is_contiguous()
+                or data.dim() < 2 or data[0].numel() % 4 or data.data_ptr() % 16):
+            return
+        data._ta_u8 = (data._version,) + tuple(_hip.u8_source_probe(data))
 
     # ------------------------------------------------------------------------------------------ hooks
     def get_logits(self, x, **kwargs):
@@ -225,7 +252,9 @@ class Attack(object):
         if self.targeted:
             assert len(label) == 2
             label = label[1]
-        return data.clone().detach().to(self.device), label.clone().detach().to(self.device)
+        data = data.clone().detach().to(self.device)
+        self._attach_byte_source(data)
+        return data, label.clone().detach().to(self.device)
 
     def l1_normalize(self, grad):
         """grad / mean_{CHW}|grad| -- the normalisation inside get_momentum, used on its own by several

@@ -589,6 +589,88 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// PreprocessingModel with a Resize (reference: transferattack/utils.py:50-53, 72-79 -- Inception-v3: 224 -> 299, mean = std =
+// 0.5):  y = (bilinear_{in->out}(x) - mean[c]) / std[c]  as ONE kernel each way, with the DIM kernels' taps and rounding
+// order (ATen's upsample_bilinear2d: width first, then height; backward fma(ly*lx, g, acc) over the outputs in row-major
+// order).  The backward is the LAST kernel of that member's input gradient, so it also emits the per-tile sums of |gx|.
+// A tile is 32 rows x 64 columns, one lane per column, waves stride over rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void resize_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                                 int channels, int in_size, int out_size, float scale,
+                                                                 int tiles_x, int tiles_y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = tiles_x * tiles_y;
+    const int tid = static_cast<int>(blockIdx.x);
+    const int plane = tid / tiles;
+    const int t = tid - plane * tiles;
+    const int tyi = t / tiles_x;
+    const int oy0 = tyi * kDimLaneRows, ox = (t - tyi * tiles_x) * 64 + lane;
+    const int ch = plane % channels;
+    const float mu = mean[ch], sd = stdv[ch];
+    if (ox >= out_size) return;
+    const Tap tx = make_tap_scaled(ox, in_size, scale);
+    const float* xp = x + static_cast<int64_t>(plane) * in_size * in_size;
+    float* yp = y + static_cast<int64_t>(plane) * out_size * out_size;
+    const int rows = min(kDimLaneRows, out_size - oy0);
+    for (int r = wave; r < rows; r += 4) {
+        const Tap ty = make_tap_scaled(oy0 + r, in_size, scale);
+        const float* r0 = xp + static_cast<int64_t>(ty.i0) * in_size;
+        const float* r1 = xp + static_cast<int64_t>(ty.i1) * in_size;
+        const float a = fmaf(tx.l0, r0[tx.i0], tx.l1 * r0[tx.i1]);
+        const float b = fmaf(tx.l0, r1[tx.i0], tx.l1 * r1[tx.i1]);
+        const float v = fmaf(ty.l0, a, ty.l1 * b);
+        yp[static_cast<int64_t>(oy0 + r) * out_size + ox] = (v - mu) / sd;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void resize_norm_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                 const float* __restrict__ stdv, float* __restrict__ ws,
+                                                                 int channels, int in_size, int out_size, float scale,
+                                                                 int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) Hit rowH[kDimLaneRows];
+    __shared__ float red[kBlock / kWave];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = tiles_x * tiles_y;
+    const int tid = static_cast<int>(blockIdx.x);
+    const int plane = tid / tiles;
+    const int t = tid - plane * tiles;
+    const int tyi = t / tiles_x;
+    const int iy0 = tyi * kDimLaneRows, ix = (t - tyi * tiles_x) * 64 + lane;
+    const int rows = min(kDimLaneRows, in_size - iy0);
+    const float sd = stdv[plane % channels];
+    if (static_cast<int>(threadIdx.x) < rows) rowH[threadIdx.x] = find_hits(iy0 + static_cast<int>(threadIdx.x), in_size, out_size, scale);
+    __syncthreads();
+    const float* gyp = gy + static_cast<int64_t>(plane) * out_size * out_size;
+    float* gxp = gx + static_cast<int64_t>(plane) * in_size * in_size;
+    float asum = 0.0f;
+    if (ix < in_size) {
+        const Hit hx = find_hits(ix, in_size, out_size, scale);
+        int col[kHitSlots];
+#pragma unroll
+        for (int k = 0; k < kHitSlots; ++k) col[k] = min(hx.first + k, out_size - 1);
+        for (int r = wave; r < rows; r += 4) {
+            const Hit* hy = &rowH[r];
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < kHitSlots; ++ky)
+                if (ky < hy->n) {
+                    const float* grow = gyp + static_cast<int64_t>(hy->first + ky) * out_size;
+#pragma unroll
+                    for (int kx = 0; kx < kHitSlots; ++kx)          // Normalize's backward first: gy / std, then the adjoint
+                        acc = hit_accumulate<false>(acc, grow[col[kx]] / sd, hy->w[ky], hy->w2[ky], (hy->both >> ky) & 1u, hx, kx);
+                }
+            gxp[static_cast<int64_t>(iy0 + r) * in_size + ix] = acc;
+            asum += fabsf(acc);
+        }
+    }
+    const float total = block_sum(asum, red);
+    if (ws != nullptr && threadIdx.x == 0) ws[tid] = total;
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -726,4 +808,37 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
     hipLaunchKernelGGL(dim_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), smem, st, gy, gx, ws, size, resize,
                        rnd, top, left, tps);
     return check_launch("dim_bwd");
+}
+
+extern "C" int64_t ta_resize_tiles(int side) { return side <= 0 ? 0 : ceil_div(side, 64) * ceil_div(side, kDimLaneRows); }
+
+static int check_resize(int64_t n, int c, int in_size, int out_size) {
+    TA_REQUIRE(n > 0 && c > 0 && in_size > 0 && out_size > 0 && in_size <= kDimMaxSide && out_size <= kDimMaxSide, "bad shape");
+    TA_REQUIRE(n * c * ta_resize_tiles(in_size > out_size ? in_size : out_size) < (1ll << 31), "too many tiles");
+    return 0;
+}
+
+extern "C" int ta_resize_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
+                                       int in_size, int out_size, void* stream) {
+    TA_REQUIRE(x && y && mean && stdv && x != y, "null or aliased pointers");
+    if (int rc = check_resize(n, c, in_size, out_size)) return rc;
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);      // ATen: area_pixel_compute_scale
+    const int tiles_x = static_cast<int>(ceil_div(out_size, 64)), tiles_y = static_cast<int>(ceil_div(out_size, kDimLaneRows));
+    hipLaunchKernelGGL(resize_norm_fwd_kernel, dim3(static_cast<unsigned>(n * c * tiles_x * tiles_y)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), x, y, mean, stdv, c, in_size, out_size, scale, tiles_x, tiles_y);
+    return check_launch("resize_normalize_fwd");
+}
+
+// ws (nullable): n * c * ta_resize_tiles(in_size) sums of |gx|, c * tiles consecutive per image
+extern "C" int ta_resize_normalize_bwd(const float* gy, float* gx, const float* stdv, float* ws, int64_t n, int c, int in_size,
+                                       int out_size, void* stream) {
+    TA_REQUIRE(gy && gx && stdv && gy != gx, "null or aliased pointers");
+    if (int rc = check_resize(n, c, in_size, out_size)) return rc;
+    TA_REQUIRE(max_hits(in_size, out_size) <= kHitSlots, "resize %d -> %d: more than %d outputs touch one input index", in_size,
+               out_size, kHitSlots);
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    const int tiles_x = static_cast<int>(ceil_div(in_size, 64)), tiles_y = static_cast<int>(ceil_div(in_size, kDimLaneRows));
+    hipLaunchKernelGGL(resize_norm_bwd_kernel, dim3(static_cast<unsigned>(n * c * tiles_x * tiles_y)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), gy, gx, stdv, ws, c, in_size, out_size, scale, tiles_x, tiles_y);
+    return check_launch("resize_normalize_bwd");
 }

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(kBlock) void stem7s2_prepare_kernel(const float* __
 
 __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float* __restrict__ dy, const float* __restrict__ w2,
                                                                     float* __restrict__ dx, int oh, int ow) {
+    // 66 640 B of LDS: more than the 64 KB of every pre-gfx950 part -- this library targets MI355X (gfx950, 160 KB per CU)
+    // only, as does philox.h's v_mad_u64_u32 path; the Makefile builds nothing else
+    static_assert(sizeof(float) * kStemWinRows * kStemWinCols * kStemLd <= 160 * 1024, "dy window exceeds gfx950's LDS");
     __shared__ __attribute__((aligned(16))) float win[kStemWinRows * kStemWinCols * kStemLd];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

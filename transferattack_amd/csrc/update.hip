@@ -305,17 +305,27 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_accumulate_kernel(const 
 // at N=125) but lose below it -- NT is therefore a launch-time choice.
 constexpr int kK2Block = 512;
 
-template <int VEC, int BLOCK, int SLOTS, bool NT, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV>
+//
+// X_U8: the images of this path are PNG-decoded (utils.py:136: `image.astype(np.float32) / 255`), i.e. every x is
+// float(k) / 255 for a byte k.  When the caller has verified that (ta_u8_source_probe: one pass per batch, a device-side
+// flag, no host round trip) the kernel reads the byte instead of the float -- 1 B instead of 4 B per element of the
+// 24 (+4) -- and rebuilds x with the bits of the IEEE division (u8_to_unit).  The flag is read by the kernel itself, so
+// a batch that is NOT byte-valued (any other caller of the plug-in API) silently takes the fp32 operand: same launch,
+// same result, no synchronisation.
+template <int VEC, int BLOCK, int SLOTS, bool NT, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV, bool X_U8 = false>
 __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
     const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out, float* delta,
     const float* __restrict__ x, float* __restrict__ x_adv, const float* __restrict__ ws, StepParams p, int64_t e,
-    int tiles_ws) {
+    int tiles_ws, const uint8_t* __restrict__ x_u8 = nullptr, const int* __restrict__ u8_mismatch = nullptr) {
     constexpr int TILE = BLOCK * VEC * SLOTS;
+    static_assert(!X_U8 || VEC == 4, "the byte source is read four at a time");
     const int64_t img = blockIdx.y;
     const int64_t base = img * e + static_cast<int64_t>(blockIdx.x) * TILE;
     const int64_t left = e - static_cast<int64_t>(blockIdx.x) * TILE;   // elements of this image from tile start
     Pack<VEC> pg[SLOTS], pv[SLOTS], pm[SLOTS], pd[SLOTS], px[SLOTS];
+    uint32_t pb[SLOTS];
     bool full[SLOTS];
+    const bool bytes = X_U8 && uniform_int(*u8_mismatch) == 0;           // one scalar load, a scalar branch
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int64_t off = (static_cast<int64_t>(u) * BLOCK + threadIdx.x) * VEC;
@@ -326,15 +336,24 @@ __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
                 if (HAS_V) pv[u].load_nt(v + base + off);
                 if (HAS_MIN) pm[u].load_nt(m_in + base + off);
                 pd[u].load_nt(delta + base + off);
-                px[u].load_nt(x + base + off);
+                if (X_U8 && bytes) pb[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(x_u8 + base + off));
+                else px[u].load_nt(x + base + off);
             } else {
                 pg[u].load(g + base + off);
                 if (HAS_V) pv[u].load(v + base + off);
                 if (HAS_MIN) pm[u].load(m_in + base + off);
                 pd[u].load(delta + base + off);
-                px[u].load(x + base + off);
+                if (X_U8 && bytes) pb[u] = *reinterpret_cast<const uint32_t*>(x_u8 + base + off);
+                else px[u].load(x + base + off);
             }
         }
+    }
+    if (X_U8 && bytes) {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+            if (full[u])
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) px[u][k] = u8_to_unit((pb[u] >> (8 * k)) & 0xffu);
     }
     const float mean = image_total(ws, img, tiles_ws) / static_cast<float>(e);   // sum then div_ (ATen mean)
 #pragma unroll
@@ -718,11 +737,12 @@ extern "C" int ta_normalize_bwd_accumulate(const float* gy, float* acc, const fl
     return check_launch("normalize_bwd_accumulate");
 }
 
-extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
-                            const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
-                            float eps, int64_t n, int64_t e, void* stream) {
+static int mi_update_impl(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                          const float* x, const uint8_t* x_u8, const int* u8_mismatch, float* x_adv, float* ws, int ws_slots,
+                          float decay, float alpha, float eps, int64_t n, int64_t e, void* stream) {
     if (int rc = check_batch(n, e)) return rc;
     TA_REQUIRE(g && delta && x && ws && ws_slots >= 0, "null pointer");
+    TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
     // ws_slots > 0 with a variance term: the producer summed |g + v| (ta_normalize_bwd with v) -- the caller's contract
     TA_REQUIRE(!(ws_slots && aten_sum_lanes() != 0),
                "TA_ATEN_SUM_LANES: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
@@ -737,10 +757,43 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
     // stream past the caches only when one launch moves more than the Infinity Cache can hold
     const bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
+    // the byte source: 16-byte aligned floats, 4-byte aligned bytes, whole images of a multiple of 4 elements
+    const bool u8 = x_u8 != nullptr && vec && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0;
+    if (u8) {
+#define TA_MI8(NT, HV, HMI, HMO, HXA)                                                                            \
+    TA_LAUNCH_TIMED((mi_update_kernel<4, kK2Block, 1, NT, HV, HMI, HMO, HXA, true>),                             \
+                    dim3(static_cast<unsigned>(ceil_div(e, kK2Block * 4)), static_cast<unsigned>(n)),             \
+                    dim3(kK2Block), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws, \
+                    x_u8, u8_mismatch)
+#define TA_MI8_CASES(NT)                                                  \
+    switch (key) {                                                        \
+        case 0: TA_MI8(NT, false, false, false, false); break;            \
+        case 1: TA_MI8(NT, false, false, false, true); break;             \
+        case 2: TA_MI8(NT, false, false, true, false); break;             \
+        case 3: TA_MI8(NT, false, false, true, true); break;              \
+        case 4: TA_MI8(NT, false, true, false, false); break;             \
+        case 5: TA_MI8(NT, false, true, false, true); break;              \
+        case 6: TA_MI8(NT, false, true, true, false); break;              \
+        case 7: TA_MI8(NT, false, true, true, true); break;               \
+        case 8: TA_MI8(NT, true, false, false, false); break;             \
+        case 9: TA_MI8(NT, true, false, false, true); break;              \
+        case 10: TA_MI8(NT, true, false, true, false); break;             \
+        case 11: TA_MI8(NT, true, false, true, true); break;              \
+        case 12: TA_MI8(NT, true, true, false, false); break;             \
+        case 13: TA_MI8(NT, true, true, false, true); break;              \
+        case 14: TA_MI8(NT, true, true, true, false); break;              \
+        default: TA_MI8(NT, true, true, true, true); break;               \
+    }
+        if (nt) { TA_MI8_CASES(true) } else { TA_MI8_CASES(false) }
+#undef TA_MI8_CASES
+#undef TA_MI8
+        return check_launch("mi_update (byte source)");
+    }
 #define TA_MI(VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA)                                                         \
     TA_LAUNCH_TIMED((mi_update_kernel<VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA>),                               \
                     dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),     \
-                    dim3(BLOCK), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws)
+                    dim3(BLOCK), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws,    \
+                    static_cast<const uint8_t*>(nullptr), static_cast<const int*>(nullptr))
 #define TA_MI_CASES(VEC, BLOCK, SLOTS, NT)                                   \
     switch (key) {                                                           \
         case 0: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, false, false); break; \
@@ -766,4 +819,57 @@ extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, f
 #undef TA_MI_CASES
 #undef TA_MI
     return check_launch("mi_update");
+}
+
+extern "C" int ta_mi_update(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                            const float* x, float* x_adv, float* ws, int ws_slots, float decay, float alpha,
+                            float eps, int64_t n, int64_t e, void* stream) {
+    return mi_update_impl(g, v, m_in, m_out, delta, x, nullptr, nullptr, x_adv, ws, ws_slots, decay, alpha, eps, n, e, stream);
+}
+
+extern "C" int ta_mi_update_u8(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
+                               const float* x, const uint8_t* x_u8, const int* u8_mismatch, float* x_adv, float* ws,
+                               int ws_slots, float decay, float alpha, float eps, int64_t n, int64_t e, void* stream) {
+    TA_REQUIRE(x_u8 && u8_mismatch, "null byte source (use ta_mi_update)");
+    return mi_update_impl(g, v, m_in, m_out, delta, x, x_u8, u8_mismatch, x_adv, ws, ws_slots, decay, alpha, eps, n, e, stream);
+}
+
+// x_u8[i] = round(x[i] * 255) and *mismatch |= (float(x_u8[i]) / 255 != x[i]) -- the caller zeroes *mismatch first
+// (ta_u8_source_probe does).  Grid-stride, 16 B in / 4 B out per lane.
+__global__ __launch_bounds__(256) void u8_probe_kernel(const float* __restrict__ x, uint8_t* __restrict__ x_u8,
+                                                       int* __restrict__ mismatch, int64_t numel) {
+    const int64_t quads = numel >> 2;
+    int bad = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < quads; i += static_cast<int64_t>(gridDim.x) * 256) {
+        Pack<4> px;
+        px.load(x + i * 4);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = px[k] * 255.0f;
+            const uint32_t b = (s >= 0.0f && s <= 255.0f) ? static_cast<uint32_t>(rintf(s)) : 0u;       // NaN -> 0 -> mismatch
+            bad |= !(u8_to_unit(b) == px[k]);
+            packed |= b << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(x_u8 + i * 4) = packed;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = quads * 4; i < numel; ++i) {
+            const float s = x[i] * 255.0f;
+            const uint32_t b = (s >= 0.0f && s <= 255.0f) ? static_cast<uint32_t>(rintf(s)) : 0u;
+            bad |= !(u8_to_unit(b) == x[i]);
+            x_u8[i] = static_cast<uint8_t>(b);
+        }
+    if (bad) atomicOr(mismatch, 1);
+}
+
+extern "C" int ta_u8_source_probe(const float* x, uint8_t* x_u8, int* mismatch, int64_t numel, void* stream) {
+    TA_REQUIRE(x && x_u8 && mismatch && numel > 0, "null pointer or empty batch");
+    TA_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0, "unaligned operand");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipError_t err = hipMemsetAsync(mismatch, 0, sizeof(int), st)) return static_cast<int>(err);
+    const int64_t quads = numel >> 2;
+    const unsigned blocks = static_cast<unsigned>(quads / 256 < 1 ? 1 : (quads / 256 > 8192 ? 8192 : quads / 256));
+    hipLaunchKernelGGL(u8_probe_kernel, dim3(blocks), dim3(256), 0, st, x, x_u8, mismatch, numel);
+    return check_launch("u8_source_probe");
 }

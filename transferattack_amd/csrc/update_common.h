@@ -46,6 +46,20 @@ __device__ __forceinline__ float image_total(const float* __restrict__ ws, int64
     return wave_sum(t);
 }
 
+// float(k) / 255.0f for a byte k with the bits of the IEEE division (what utils.py:136's `astype(np.float32) / 255` stores):
+// q = k * fl(1/255) is off by one ulp for 126 of the 256 bytes; one Newton step on the residual r = k - 255 q (exact in an
+// fma) lands on the correctly rounded quotient for every byte (tests/test_kernel_logic_host.py checks all 256).
+__device__ __forceinline__ float u8_to_unit(uint32_t k) {
+    const float kf = static_cast<float>(k);
+    const float r255 = 1.0f / 255.0f;                       // folded at compile time
+    const float q = kf * r255;
+    const float r = __builtin_fmaf(-q, 255.0f, kf);
+    return __builtin_fmaf(r, r255, q);
+}
+
+// a value every lane holds alike, moved to a scalar register so that a branch on it is a scalar branch
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 struct StepParams {
     float decay, alpha, neg_eps, eps;
 };

@@ -128,25 +128,48 @@ class _SumInputGrad(torch.autograd.Function):
         return total, None
 
 
-class ShardedEnsemble(nn.Module):
-    """Drop-in for ``EnsembleModel`` (utils.py:82-105, mode 'mean') when each rank of ``group`` holds ONE member:
-    forward = local member + all-reduce(mean) of the logits.  ``models`` / ``num_models`` / ``device`` keep the
-    attribute contract of the reference class."""
+class _AllGatherStack(torch.autograd.Function):
+    """out[m] = member m's logits (all-gather over the group, member order = rank order within the group); every rank
+    evaluates the same loss on the same stack, so d(loss)/d(own logits) is that rank's slice of the stack's gradient."""
 
-    def __init__(self, local_model, group, members):
+    @staticmethod
+    def forward(ctx, logits, group, members, index):
+        parts = [torch.empty_like(logits) for _ in range(members)]
+        dist.all_gather(parts, logits.detach().contiguous(), group=group)
+        ctx.index = index
+        return torch.stack(parts, dim=0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        return grad[ctx.index].contiguous(), None, None, None
+
+
+class ShardedEnsemble(nn.Module):
+    """Drop-in for ``EnsembleModel`` (utils.py:82-105) when each rank of ``group`` holds ONE member: forward = local member +
+    all-reduce(mean) of the logits for mode 'mean' (utils.py:100), all-gather into the [M, N, classes] stack for mode 'ind'
+    (utils.py:101-103); the input gradient is the members' sum either way.  ``models`` / ``num_models`` / ``device`` /
+    ``mode`` keep the attribute contract of the reference class."""
+
+    def __init__(self, local_model, group, members, mode='mean'):
         super().__init__()
         self.local = local_model
         self.models = [local_model]
         self.group = group
         self.num_models = members
-        self.mode = 'mean'
+        self.mode = mode
         self.type_name = 'ensemble'
         self.device = next(local_model.parameters()).device
+        self.index = dist.get_group_rank(group, dist.get_rank()) if group is not None else dist.get_rank()
 
     def forward(self, x):
         if x.requires_grad:
             x = _SumInputGrad.apply(x, self.group)
-        return _AllReduceMean.apply(self.local(x), self.group, self.num_models)
+        if self.mode == 'mean':
+            return _AllReduceMean.apply(self.local(x), self.group, self.num_models)
+        if self.mode == 'ind':
+            return _AllGatherStack.apply(self.local(x), self.group, self.num_models, self.index)
+        raise NotImplementedError
 
 
 class _OwnerCall(torch.autograd.Function):

@@ -87,6 +87,8 @@ class VMIFGSM(Attack):
             gy = self._backbone_grad(y, label)
             grad = torch.empty_like(data)
             _hip.normalize_bwd(gy, grad, std, variance=variance)          # leaves the tile sums of |grad + variance|
+            if self.grad_probe is not None:                               # test hook: sees what get_grad would return
+                self.grad_probe(it, grad)
             acc = torch.empty_like(data)
             for i in range(self.num_neighbor):
                 noise = None
@@ -101,7 +103,7 @@ class VMIFGSM(Attack):
             if x_adv is None and it + 1 < self.epoch:
                 x_adv = torch.empty_like(data)
             _hip.mi_update(grad, momentum, m_out, delta, data, self.decay, self.alpha, self.epsilon, variance=variance,
-                           x_adv=x_adv if it + 1 < self.epoch else None)
+                           x_adv=x_adv if it + 1 < self.epoch else None, data_u8=self._byte_source_of(data))
             momentum, variance = m_out, new_variance
         return delta.detach()
 
@@ -113,7 +115,10 @@ class VMIFGSM(Attack):
         label = label.clone().detach().to(self.device)
         folds = self._normalize_folds(data)
         if folds is not None:
-            return self._forward_folded(data.contiguous(), label, *folds)
+            data = data.contiguous()
+            self._attach_byte_source(data)
+            return self._forward_folded(data, label, *folds)
+        self._attach_byte_source(data)
         delta = self.init_delta(data)
         momentum, variance = 0, 0
         fused = self._can_fuse_update()

@@ -94,6 +94,30 @@ class _Normalize(nn.Module):
         return (x - self.mean) / self.std            # other dtypes / ranks: not the path this package accelerates
 
 
+class _ResizeNormalizeFn(torch.autograd.Function):
+    """Normalize(Resize(x)) of the 299-pixel members (utils.py:50-53, 75-76) as one HIP kernel each way: ATen's bilinear
+    arithmetic (``F.interpolate(mode='bilinear', align_corners=False)``) with the Normalize folded in; the backward -- the
+    last kernel of that member's input gradient -- leaves the |g| tile sums for the fused update."""
+
+    @staticmethod
+    def forward(ctx, x, mean, std, size):
+        x = x.contiguous()
+        y = torch.empty((x.shape[0], x.shape[1], size, size), dtype=x.dtype, device=x.device)
+        _hip.resize_normalize_fwd(x, y, mean, std)
+        ctx.save_for_backward(std)
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (std,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty(ctx.in_shape, dtype=gy.dtype, device=gy.device)
+        _hip.resize_normalize_bwd(gy, gx, std)
+        return gx, None, None, None
+
+
 class PreprocessingModel(nn.Module):
     """normalize(resize(x)) in front of the backbone -- utils.py:72-79."""
 
@@ -103,6 +127,13 @@ class PreprocessingModel(nn.Module):
         self.normalize = _Normalize(mean, std)
 
     def forward(self, x):
+        size = self.resize.size
+        if (x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2] < size and 2 * size <= 3 * x.shape[-1]
+                and max(size, x.shape[-1]) <= 1024 and os.environ.get("TA_RESIZE_KERNEL", "1") != "0"
+                and not (self.resize._forward_hooks or self.normalize._forward_hooks)):
+            # the attack path of a 299-pixel member: one fused kernel each way instead of F.interpolate + Normalize
+            return _ResizeNormalizeFn.apply(x, self.normalize.mean.reshape(-1).contiguous(),
+                                            self.normalize.std.reshape(-1).contiguous(), size)
         return self.normalize(self.resize(x))
 
 
@@ -199,7 +230,8 @@ class EnsembleModel(nn.Module):
         if x.requires_grad and x.dtype == torch.float32 and x.dim() == 4 and len(self.models) > 1:
             # the attack path (HIP kernels whatever device x claims to be on, like _Normalize: no torch fallback)
             views = _FanOut.apply(x, len(self.models))
-            outputs = torch.stack([model(v) for model, v in zip(self.models, views)], dim=0)
+            outputs = torch.stack(self._members_on_streams(views) if self._use_streams(x) else
+                                  [model(v) for model, v in zip(self.models, views)], dim=0)
         else:
             outputs = torch.stack([model(x) for model in self.models], dim=0)
         if self.mode == 'mean':
@@ -207,6 +239,30 @@ class EnsembleModel(nn.Module):
         if self.mode == 'ind':
             return outputs
         raise NotImplementedError
+
+    # ---- one HIP stream per member (MI355X: 256 CUs, and most kernels of a 32-image Inception-v3 / MobileNet / ViT
+    # evaluation are too small to fill them): the members of an ensemble are independent between the fan-out of x and the
+    # stack of their logits, so member k's forward runs on stream k -- and, because autograd runs every backward node on
+    # its forward's stream and orders streams itself, so does its backward.  Same kernels, same per-member order, same
+    # bits; the members' kernels overlap on the device.  ``TA_ENS_STREAMS=0`` runs them one after the other.
+    def _use_streams(self, x):
+        return x.is_cuda and os.environ.get("TA_ENS_STREAMS", "1") != "0"
+
+    def _members_on_streams(self, views):
+        dev = views[0].device
+        main = torch.cuda.current_stream(dev)
+        streams = getattr(self, "_member_streams", None)
+        if streams is None or len(streams) != len(self.models) or streams[0].device != dev:
+            streams = self._member_streams = [torch.cuda.Stream(device=dev) for _ in self.models]
+        outs = []
+        for model, v, s in zip(self.models, views, streams):
+            s.wait_stream(main)                       # x (and whatever produced it) is ready
+            with torch.cuda.stream(s):
+                outs.append(model(v))
+        for o, s in zip(outs, streams):
+            main.wait_stream(s)
+            o.record_stream(main)                     # allocated on s, consumed (stacked) on main
+        return outs
 
     def eval(self):
         for model in self.models:
