@@ -102,8 +102,8 @@ rocprof)
   find $OUT/prof -name "*kernel_trace.csv" -size +8M -delete; find $OUT/prof -name "*.db" -delete ;;
 newtests4)
   # round 4: byte source of the fused update, loop-level goldens (L2 / tensor / negative step, random starts), partials verify mode
-  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_loops_golden.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
-      -k "test_hip_kernels or loops_golden or registry_rules" 2>&1 | grep -v Warning | tee $OUT/newtests4_pytest.txt | tail -25 ;;
+  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_loops_golden.py tests/test_zz_hip_widened.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
+      -k "test_hip_kernels or loops_golden or registry_rules or shard_size or members_on_streams" 2>&1 | grep -v Warning | tee $OUT/newtests4_pytest.txt | tail -25 ;;
 asr4)
   timeout 1200 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "mifgsm_resnet50 or dts" 2>&1 | grep -v Warning | tee $OUT/asr4_pytest.txt | tail -60 ;;
 bench32)
@@ -114,6 +114,15 @@ ens4)
   for b in 32 125; do
   timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
   done ;;
+ensab)
+  # configs[4] at the reference's batch: members one after the other / on their own HIP streams, then what the iteration is made of
+  M="--attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --cpu-images 0 --kernel-sweep 0"
+  TA_ENS_STREAMS=0 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_one_stream.json
+  TA_ENS_STREAMS=1 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_member_streams.json
+  ( cd /tmp && TA_ENS_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ens_trace -o trace -- python $R/bench.py $M --steps 2 --warmup 1 > $R/$OUT/ens_trace.log 2>&1 )
+  python tools/steady_trace.py $OUT/ens_trace $OUT/ens4_b32_steady_state.json 40 | tee $OUT/ens4_b32_steady_state.txt | head -50
+  f=$(find $OUT/ens_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/ens4_b32_kernel_stats.csv
+  find $OUT/ens_trace -name "*kernel_trace.csv" -delete; find $OUT/ens_trace -name "*.db" -delete ;;
 members)
   # one member at a time (MI-FGSM, batch 32): where configs[4]'s time goes
   for m in vgg16 inception_v3 vit_base_patch16_224 mobilenet_v2; do

@@ -43,7 +43,9 @@ def main():
     # the byte source (ta_mi_update_u8): byte-valued images, 1 B instead of 4 B per element of x
     bsets = []
     for g, m, d, x, xa in sets:
-        xb = (torch.randint(0, 256, x.shape, device="cuda", dtype=torch.uint8).float() / 255).contiguous()
+        # the quotient on the HOST: torch's device division by a scalar multiplies by the reciprocal, which is not the IEEE
+        # quotient for 126 of the 256 bytes (the probe would -- rightly -- report "not byte-valued": r4b's first PMC pass)
+        xb = (torch.randint(0, 256, x.shape, dtype=torch.uint8).float() / 255).to("cuda").contiguous()
         bsets.append((g, m, d, xb, xa, _hip.u8_source_probe(xb)))
     for i in range(REPS):                               # steady state with the byte source (25 B/element executed)
         g, m, d, x, xa, src = bsets[i % 4]
@@ -58,6 +60,7 @@ def main():
         _hip.abs_sum_partials(g)
         _hip.mi_update(g, None, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa, data_u8=src)
     torch.cuda.synchronize()
+    print("byte source taken by the kernels: %s" % all(int(b[5][1].item()) == 0 for b in bsets))
     print("microbench done N=%d" % N)
 
 

@@ -589,6 +589,204 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 }
 
 
+// The three colour planes of an image at once (round 4).  PMC of the lanes kernel above (profiles/r04/dim_pmc_n160_r4b.txt):
+// 68 % of its cycles are VALU issue, 2147 VALU instructions per wave of a three-plane workgroup -- three times the same
+// index logic, weight products and predication, once per plane.  Where a pixel's hits are and what they weigh is the same
+// for R, G and B, so here a lane carries all three through both stages: one weight product per tap, the first two planes in
+// one v_pk_fma_f32 (an even-aligned register pair), the third in a v_fma_f32; the d(rescaled) window lives in LDS as one
+// 16-byte cell per pixel (R, G, B, 0) -- one ds_read_b128 per tap instead of three ds_read_b32.  Slots beyond a column's hit
+// count read an all-zero cell (column 64 of every window row) with weight 0: fma(0, 0, acc) == acc bit for bit, no select.
+// Every accumulator still sees its taps in ATen's order, so each plane's result -- and its |gx| tile sum -- carries the bits
+// of the one-plane kernel (tests: both kernels against oracle/ta_oracle.c and against each other at the shard size).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int RPW, int SB, int SA>
+__global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                             float* __restrict__ ws, int size, int resize, int rnd,
+                                                             int top, int left, float scale1, float scale2, int tw,
+                                                             int tiles_x, int tiles_y) {
+    constexpr int ROWS = 4 * RPW;
+    constexpr int MS = 65;                                              // cells per window row: 64 columns + the zero cell
+    __shared__ __attribute__((aligned(16))) Hit colB[64];
+    __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];
+    __shared__ __attribute__((aligned(16))) Hit colA[64];
+    __shared__ __attribute__((aligned(16))) Hit rowA[ROWS];
+    __shared__ __attribute__((aligned(16))) float4 mid[ROWS * MS];      // d(rescaled) window: (R, G, B, 0) per pixel
+    __shared__ float red[3][kBlock / kWave];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = tiles_x * tiles_y;
+    const int tid = static_cast<int>(blockIdx.x);
+    const int image = tid / tiles;
+    const int t = tid - image * tiles;
+    const int tyi = t / tiles_x;
+    const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
+    const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
+
+    if (wave == 0 && lane < twc) colB[lane] = find_hits(ix0 + lane, size, rnd, scale1);
+    if (wave == 1 && lane < th) rowB[lane] = find_hits(iy0 + lane, size, rnd, scale1);
+    for (int p = threadIdx.x; p < ROWS; p += kBlock) mid[p * MS + 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int rx_lo = colB[0].first, rx_hi = colB[twc - 1].first + colB[twc - 1].n - 1;
+    const int ry_lo = rowB[0].first, ry_hi = rowB[th - 1].first + rowB[th - 1].n - 1;
+    const int mw = rx_hi - rx_lo + 1, mh = ry_hi - ry_lo + 1;           // <= 64, <= ROWS (host-checked)
+    if (wave == 0 && lane < mw) colA[lane] = find_hits(rx_lo + lane + left, resize, size, scale2);
+    {
+        const int p = static_cast<int>(threadIdx.x) - 64;
+        if (p >= 0 && p < mh) rowA[p] = find_hits(ry_lo + p + top, resize, size, scale2);
+    }
+    __syncthreads();
+
+    const int64_t plane_elems = static_cast<int64_t>(size) * size;
+    const char* gyp[3];
+    char* gxp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gyp[c] = reinterpret_cast<const char*>(gy + (static_cast<int64_t>(image) * 3 + c) * plane_elems);
+        gxp[c] = reinterpret_cast<char*>(gx + (static_cast<int64_t>(image) * 3 + c) * plane_elems);
+    }
+    // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c] of the three planes
+    {
+        Hit hx = colA[lane < mw ? lane : 0];
+        if (lane >= mw) hx.n = 0;
+        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
+        unsigned col[SA];
+#pragma unroll
+        for (int k = 0; k < SA; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        auto fetch = [&](int p, float (&g)[3][SA][SA]) {
+            const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
+#pragma unroll
+            for (int ky = 0; ky < SA; ++ky) {
+                const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
+#pragma unroll
+                for (int kx = 0; kx < SA; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[c][ky][kx] = *reinterpret_cast<const float*>(gyp[c] + (row + col[kx]));
+            }
+        };
+        auto reduce = [&](int p, const float (&g)[3][SA][SA]) {
+            const Hit* hy = &rowA[p];
+            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
+            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+            float4 cell = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!any_both_x && both_y == 0u) {
+                v2f acc01 = v2f{0.0f, 0.0f};
+                float acc2 = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < SA; ++ky)
+                    if (ky < n_y)
+#pragma unroll
+                        for (int kx = 0; kx < SA; ++kx) {
+                            const bool on = kx < hx.n;                 // an off slot re-reads a neighbour: keep a non-finite one out
+                            const float w = hy->w[ky] * hx.w[kx];       // (0 beyond n)
+                            const v2f g01 = v2f{on ? g[0][ky][kx] : 0.0f, on ? g[1][ky][kx] : 0.0f};
+                            acc01 = __builtin_elementwise_fma(v2f{w, w}, g01, acc01);
+                            acc2 = fmaf(w, on ? g[2][ky][kx] : 0.0f, acc2);
+                        }
+                cell = make_float4(acc01.x, acc01.y, acc2, 0.f);
+            } else {
+                float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int ky = 0; ky < SA; ++ky)
+                        if (ky < n_y)
+#pragma unroll
+                            for (int kx = 0; kx < SA; ++kx)
+                                acc[c] = hit_accumulate<false>(acc[c], g[c][ky][kx], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+                cell = make_float4(acc[0], acc[1], acc[2], 0.f);
+            }
+            mid[p * MS + lane] = cell;
+        };
+        float ga[3][SA][SA], gb[3][SA][SA];
+        int p = wave;
+        if (p < mh) fetch(p, ga);
+#pragma unroll 1
+        while (p < mh) {
+            fetch(min(p + 4, mh - 1), gb);
+            reduce(p, ga);
+            p += 4;
+            if (p >= mh) break;
+            fetch(min(p + 4, mh - 1), ga);
+            reduce(p, gb);
+            p += 4;
+        }
+    }
+    __syncthreads();
+    // -- stage B: gx[iy][ix] of the three planes
+    float asum[3] = {0.0f, 0.0f, 0.0f};
+    Hit hx = colB[lane < twc ? lane : 0];
+    if (lane >= twc) hx.both = 0u;
+    const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
+    if (lane < twc) {
+        int col[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) col[k] = k < hx.n ? min(hx.first - rx_lo + k, 63) : 64;       // off slots: the zero cell
+        unsigned out = static_cast<unsigned>((iy0 + wave) * size + ix0 + lane) * 4u;
+        const unsigned bstep = 16u * static_cast<unsigned>(size);
+#pragma unroll 1
+        for (int r = wave; r < th; r += 4, out += bstep) {
+            const Hit* hy = &rowB[r];
+            const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
+            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
+            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+            float res[3];
+            if (!any_both_x && both_y == 0u) {
+                v2f acc01 = v2f{0.0f, 0.0f};
+                float acc2 = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < SB; ++ky)
+                    if (ky < n_y) {
+                        const float4* mrow = mid + (first_y + ky) * MS;
+#pragma unroll
+                        for (int kx = 0; kx < SB; ++kx) {
+                            const float4 g = mrow[col[kx]];
+                            const float w = hy->w[ky] * hx.w[kx];
+                            acc01 = __builtin_elementwise_fma(v2f{w, w}, v2f{g.x, g.y}, acc01);
+                            acc2 = fmaf(w, g.z, acc2);
+                        }
+                    }
+                res[0] = acc01.x; res[1] = acc01.y; res[2] = acc2;
+            } else {
+                res[0] = res[1] = res[2] = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < SB; ++ky)
+                    if (ky < n_y) {
+                        const float4* mrow = mid + (first_y + ky) * MS;
+#pragma unroll
+                        for (int kx = 0; kx < SB; ++kx) {
+                            const float4 g = mrow[col[kx]];
+                            res[0] = hit_accumulate<false>(res[0], g.x, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+                            res[1] = hit_accumulate<false>(res[1], g.y, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+                            res[2] = hit_accumulate<false>(res[2], g.z, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                *reinterpret_cast<float*>(gxp[c] + out) = res[c];
+                asum[c] += fabsf(res[c]);
+            }
+        }
+    }
+    // three workgroup sums in block_sum's order (wave butterflies, then the waves in index order)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = wave_sum(asum[c]);
+        if (lane == 0) red[c][wave] = v;
+    }
+    __syncthreads();
+    if (ws != nullptr && threadIdx.x < 3) {
+        const int c = static_cast<int>(threadIdx.x);
+        float total = red[c][0];
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) total += red[c][w];
+        ws[(static_cast<int64_t>(image) * 3 + c) * tiles + t] = total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PreprocessingModel with a Resize (reference: transferattack/utils.py:50-53, 72-79 -- Inception-v3: 224 -> 299, mean = std =
 // 0.5):  y = (bilinear_{in->out}(x) - mean[c]) / std[c]  as ONE kernel each way, with the DIM kernels' taps and rounding
@@ -774,6 +972,23 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             // the three planes of an RGB image share one workgroup's hit tables (a quarter of the backward's instructions)
             // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
             const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
+            // three planes per LANE (dim_bwd_rgb_kernel) wherever three planes per workgroup paid; TA_DIM_BWD_RGB = 1 forces
+            // it for any multiple of three planes (tests), 0 keeps the one-plane-at-a-time kernel
+            const char* rgb_env = getenv("TA_DIM_BWD_RGB");
+            const bool rgb = planes % 3 == 0 && (rgb_env == nullptr ? pp == 3 : atoi(rgb_env) != 0);
+            if (rgb) {
+                const dim3 rgb_grid(static_cast<unsigned>(planes / 3 * tiles_x * tiles_y));
+                const bool three_b = max_hits(size, rnd) <= 3, two_a = max_hits(resize, size) <= 2;
+#define TA_DIM_RGB(RPW, SB, SA)                                                                                          \
+    hipLaunchKernelGGL((dim_bwd_rgb_kernel<RPW, SB, SA>), rgb_grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
+                       left, scale1, scale2, tw, tiles_x, tiles_y)
+#define TA_DIM_RGB_A(RPW, SB) do { if (two_a) TA_DIM_RGB(RPW, SB, 2); else TA_DIM_RGB(RPW, SB, 3); } while (0)
+                if (rows <= 40) { if (three_b) TA_DIM_RGB_A(10, 3); else TA_DIM_RGB_A(10, 4); }
+                else { if (three_b) TA_DIM_RGB_A(17, 3); else TA_DIM_RGB_A(17, 4); }
+#undef TA_DIM_RGB_A
+#undef TA_DIM_RGB
+                return check_launch("dim_bwd_rgb");
+            }
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
