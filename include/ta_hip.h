@@ -221,11 +221,15 @@ int ta_axpy(const float* x, const float* m, float coeff, float* out, int64_t num
  * inner = 1 for NHWC, H*W for NCHW (fastest when channels % 4 == 0 resp. H*W % 4 == 0).  Same rounding points as the separate ATen passes.
  *   ta_bias_act        y = y + bias[c], then clamp_min(., 0) if relu                       (in place)
  *   ta_bias_add_relu   y = clamp_min((y + bias[c]) + (other [+ bias_other[c]]), 0)           (in place; bias_other nullable)
- *   ta_relu_mask       out = y <= 0 ? 0 : ga [+ gb]          (gb nullable; out may alias ga) = threshold_backward(ga + gb, y, 0) */
-int ta_bias_act(float* y, const float* bias, int relu, int64_t numel, int channels, int64_t inner, void* stream);
-int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, int64_t numel, int channels,
-                     int64_t inner, void* stream);
-int ta_relu_mask(const float* ga, const float* gb, const float* y, float* out, int64_t numel, void* stream);
+ *   ta_relu_mask       out = y <= 0 ? 0 : ga [+ gb]          (gb nullable; out may alias ga) = threshold_backward(ga + gb, y, 0)
+ * Pass bits (round 4): `mask` (nullable; numel / 8 bytes, numel % 8 == 0) of the two forward kernels receives one bit per
+ * element of the result -- bit i % 8 of byte i / 8, set where !(y <= 0), i.e. where threshold_backward lets the gradient
+ * pass -- and ta_relu_mask takes EITHER the activation y OR those bits: the backward of a frozen network reads an
+ * activation for nothing but that test, 4 bytes per element to learn one bit. */
+int ta_bias_act(float* y, const float* bias, int relu, uint8_t* mask, int64_t numel, int channels, int64_t inner, void* stream);
+int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, uint8_t* mask, int64_t numel,
+                     int channels, int64_t inner, void* stream);
+int ta_relu_mask(const float* ga, const float* gb, const float* y, const uint8_t* mask, float* out, int64_t numel, void* stream);
 /*   ta_maxpool_bwd_relu  out = threshold_backward(max_pool2d_with_indices_backward(ga [+ gb], idx), y, 0) in ONE gather pass (the
  *                        stem of the ResNets: conv -> ReLU -> max-pool; no zero fill, no atomics, deterministic).  channels_last
  *                        buffers: ga / gb / idx [n, ph, pw, c], y / out [n, h, w, c]; idx = ATen's argmax index h * w_ + w. */

@@ -217,6 +217,22 @@ def test_glue_kernels_against_aten(monkeypatch):
         ref = torch.ops.aten.threshold_backward(ga, res, 0)
         got = _hip.relu_mask(ga.clone(memory_format=torch.preserve_format), res, ga)
         assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+        # pass bits: the forward kernels leave one bit per element, the backward takes it instead of the activation
+        for fwd in ("bias_act", "bias_add_relu"):
+            yy = y.clone(memory_format=torch.preserve_format)
+            bits = _hip.pass_bits_like(yy)
+            bits.fill_(0xA5)
+            res = _hip.bias_act_(yy, b, mask=bits) if fwd == "bias_act" else _hip.bias_add_relu_(yy, b, o, bo, mask=bits)
+            flat = res.detach().as_strided((res.numel(),), (1,))                       # memory order
+            want = np.packbits((~(flat <= 0)).numpy().astype(np.uint8), bitorder="little")
+            assert np.array_equal(bits.numpy(), want), "pass bits differ from !(y <= 0)"
+            for second in (None, gb):
+                ref = torch.ops.aten.threshold_backward(ga if second is None else ga + second, res, 0)
+                got = _hip.relu_mask(ga, res, torch.empty_like(ga), gb=second, mask=bits)
+                assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+    with pytest.raises(_hip.HipExtensionError, match="numel"):                      # 4 * 3 * 3 * 1 = 36 elements: not a multiple of 8
+        odd = torch.randn(4, 3, 3, 1)
+        _hip.bias_act_(odd, torch.randn(3), mask=torch.empty(5, dtype=torch.uint8))
 
 
 def test_attack_loops_through_the_fused_surrogate(monkeypatch):

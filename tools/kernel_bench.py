@@ -84,7 +84,13 @@ def main():
         rec("glue_relu_mask_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3])), 12 * ea)
         rec("glue_relu_mask_add_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3],
                                                                       gb=acts[3 + (i + 1) % 3])), 16 * ea)
-        del acts
+        # the same passes with pass bits: the forward writes 1 bit per element extra, the backward reads 1 bit instead of 4 B
+        bits = _hip.pass_bits_like(acts[0])
+        rec("glue_bias_relu_bits_nhwc", timed(lambda i: _hip.bias_act_(acts[i % 3], bias, mask=bits)), 8 * ea)
+        rec("glue_relu_mask_bits_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3], mask=bits)), 12 * ea)
+        rec("glue_relu_mask_add_bits_nhwc", timed(lambda i: _hip.relu_mask(acts[i % 3], acts[3 + i % 3], acts[i % 3],
+                                                                           gb=acts[3 + (i + 1) % 3], mask=bits)), 16 * ea)
+        del acts, bits
         # the stem convolution's input gradient (7x7 / stride 2 / 3 -> 64): csrc/stem.hip against MIOpen's backward-data
         wst = (torch.randn(64, 3, 7, 7, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)
         dys = [torch.randn(n, 64, 112, 112, device=DEV).contiguous(memory_format=torch.channels_last) for _ in range(2)]

@@ -40,7 +40,10 @@ def main():
             print("%-92s launches %-4d mean %.1f KiB = %.3f B/elem" % (short, len(vals), mean_kib, b_per_elem))
     copy = [k for k in per if "elementwise" in k or "copy" in k.lower()]
     factor = None
-    if copy:
+    if "--factor" in sys.argv:                      # a calibration taken elsewhere (say where): this run's copy launches are not
+        factor = float(sys.argv[sys.argv.index("--factor") + 1])       # all of one size (e.g. host-to-device staging copies)
+        print("fetch correction x%.4f given on the command line" % factor)
+    elif copy:
         c = per[copy[0]]
         if c.get("FETCH_SIZE"):
             factor = 4.0 / c["FETCH_SIZE"]                # the copy reads 4 B/elem
@@ -50,7 +53,9 @@ def main():
         dst = sys.argv[sys.argv.index("--json") + 1]
         doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/update_microbench.py, "
                          "N = %d; summary by tools/pmc_summary.py" % n,
-               "fetch_correction": round(factor, 4), "kernels": {}}
+               "fetch_correction": round(factor, 4),
+               "fetch_correction_source": "command line (--factor)" if "--factor" in sys.argv else "the known-size device copy of the same run",
+               "kernels": {}}
         for name, c in per.items():
             if "ta::" not in name and "ta2" not in name:
                 continue

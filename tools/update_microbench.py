@@ -43,9 +43,11 @@ def main():
     # the byte source (ta_mi_update_u8): byte-valued images, 1 B instead of 4 B per element of x
     bsets = []
     for g, m, d, x, xa in sets:
-        # the quotient on the HOST: torch's device division by a scalar multiplies by the reciprocal, which is not the IEEE
-        # quotient for 126 of the 256 bytes (the probe would -- rightly -- report "not byte-valued": r4b's first PMC pass)
-        xb = (torch.randint(0, 256, x.shape, dtype=torch.uint8).float() / 255).to("cuda").contiguous()
+        # byte-valued images built on the device WITHOUT torch's fp32 division (by a scalar it multiplies by the reciprocal,
+        # not the IEEE quotient for 126 of the 256 bytes: the probe would -- rightly -- say "not byte-valued", r4b's first PMC
+        # pass) and without host-to-device copies (they would join the calibration copy's kernel name, r4c's second): the
+        # double-precision product rounds to the correctly rounded fp32 quotient for every byte
+        xb = (torch.randint(0, 256, x.shape, device="cuda", dtype=torch.uint8).double() / 255).float().contiguous()
         bsets.append((g, m, d, xb, xa, _hip.u8_source_probe(xb)))
     for i in range(REPS):                               # steady state with the byte source (25 B/element executed)
         g, m, d, x, xa, src = bsets[i % 4]

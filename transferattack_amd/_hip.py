@@ -53,9 +53,9 @@ SIGNATURES = {
     "ta_dim_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_stem7s2_prepare": (_int, [_vp, _vp, _vp]),
     "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
-    "ta_bias_act": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
-    "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
-    "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "ta_bias_act": (_int, [_vp, _vp, _int, _vp, _i64, _int, _i64, _vp]),
+    "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ta_maxpool_bwd_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_scale_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
@@ -609,35 +609,47 @@ def _glue_layout(t):
     raise ValueError("activation must be dense NCHW or channels_last, got strides %s" % (t.stride(),))
 
 
-def bias_act_(y, bias, relu=True):
-    """y <- clamp_min(y + bias[c], 0) (or just the bias add) in place: one pass where ATen makes two"""
+def pass_bits_like(y):
+    """an (uninitialised) buffer for the pass bits of activation ``y``: one bit per element, or None if y.numel() % 8"""
+    if y.numel() % 8:
+        return None
+    return torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device)
+
+
+def bias_act_(y, bias, relu=True, mask=None):
+    """y <- clamp_min(y + bias[c], 0) (or just the bias add) in place: one pass where ATen makes two.  ``mask`` (optional,
+    ``pass_bits_like(y)``) receives one bit per element: does threshold_backward let the gradient pass there"""
     c, inner = _glue_layout(y)
     _wrote(y)
-    _call("ta_bias_act", y, _ptr_any(y, "y"), _ptr(bias, name="bias"), 1 if relu else 0, y.numel(), c, inner)
+    _call("ta_bias_act", y, _ptr_any(y, "y"), _ptr(bias, name="bias"), 1 if relu else 0, _ptr(mask, torch.uint8, "mask"),
+          y.numel(), c, inner)
     return y
 
 
-def bias_add_relu_(y, bias, other, bias_other=None):
+def bias_add_relu_(y, bias, other, bias_other=None, mask=None):
     """y <- clamp_min((y + bias[c]) + (other [+ bias_other[c]]), 0) in place: a bottleneck's third convolution, its shortcut
-    and the ReLU in one pass"""
+    and the ReLU in one pass; ``mask`` as in ``bias_act_``"""
     c, inner = _glue_layout(y)
     if _glue_layout(other) != (c, inner) or other.shape != y.shape:
         raise ValueError("shortcut and main branch differ in shape or memory format")
     _wrote(y)
     _call("ta_bias_add_relu", y, _ptr_any(y, "y"), _ptr(bias, name="bias"), _ptr_any(other, "other"),
-          _ptr(bias_other, name="bias_other"), y.numel(), c, inner)
+          _ptr(bias_other, name="bias_other"), _ptr(mask, torch.uint8, "mask"), y.numel(), c, inner)
     return y
 
 
-def relu_mask(ga, y, out, gb=None):
-    """out <- threshold_backward(ga [+ gb], y, 0); ``out`` may be ``ga``.  All operands share one dense layout."""
+def relu_mask(ga, y, out, gb=None, mask=None):
+    """out <- threshold_backward(ga [+ gb], y, 0); ``out`` may be ``ga``.  All operands share one dense layout.  With ``mask``
+    (the pass bits the forward kernel left for y) the activation itself is not read: 1 bit instead of 4 bytes per element"""
     layout = _glue_layout(y)
     for t in (ga, gb, out):
         if t is not None and (t.shape != y.shape or _glue_layout(t) != layout):
             raise ValueError("operands differ in shape or memory format")
+    if mask is not None and (mask.numel() * 8 != y.numel() or mask.device != y.device):
+        raise ValueError("pass bits do not belong to this activation")
     _wrote(out)
-    _call("ta_relu_mask", y, _ptr_any(ga, "ga"), None if gb is None else _ptr_any(gb, "gb"), _ptr_any(y, "y"),
-          _ptr_any(out, "out"), y.numel())
+    _call("ta_relu_mask", y, _ptr_any(ga, "ga"), None if gb is None else _ptr_any(gb, "gb"),
+          None if mask is not None else _ptr_any(y, "y"), _ptr(mask, torch.uint8, "mask"), _ptr_any(out, "out"), y.numel())
     return out
 
 

@@ -116,23 +116,33 @@ class _ResNetFn(torch.autograd.Function):
         bottleneck = hasattr(net.layer1[0], "conv3")
         if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
             x = x.contiguous()
+        # pass bits (round 4): the backward reads an activation only for threshold_backward's sign test -- the forward glue
+        # leaves that bit, the backward glue reads 1 bit instead of 4 bytes per element (TA_RELU_BITS=0: the activations)
+        bits = os.environ.get("TA_RELU_BITS", "1") != "0"
+        new_bits = (lambda t: _hip.pass_bits_like(t)) if bits else (lambda t: None)
         stem = _hip.bias_act_(_conv(x, net.conv1), net.conv1.bias)
         pooled, idx = F.max_pool2d(stem, net.maxpool.kernel_size, net.maxpool.stride, net.maxpool.padding, return_indices=True)
-        saved, cur = [], pooled
+        saved, masks, cur = [], [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
-                a = _hip.bias_act_(_conv(cur, blk.conv1), blk.conv1.bias)
+                a = _conv(cur, blk.conv1)
+                ma = new_bits(a)
+                _hip.bias_act_(a, blk.conv1.bias, mask=ma)
                 if bottleneck:
-                    b = _hip.bias_act_(_conv(a, blk.conv2), blk.conv2.bias)
+                    b = _conv(a, blk.conv2)
+                    mb = new_bits(b)
+                    _hip.bias_act_(b, blk.conv2.bias, mask=mb)
                     last_in, last = b, blk.conv3
                 else:
-                    b, last_in, last = None, a, blk.conv2
+                    b, mb, last_in, last = None, None, a, blk.conv2
                 y = _conv(last_in, last)
+                my = new_bits(y)
                 if blk.downsample is None:
-                    _hip.bias_add_relu_(y, last.bias, cur)
+                    _hip.bias_add_relu_(y, last.bias, cur, mask=my)
                 else:
-                    _hip.bias_add_relu_(y, last.bias, _conv(cur, blk.downsample[0]), blk.downsample[0].bias)
+                    _hip.bias_add_relu_(y, last.bias, _conv(cur, blk.downsample[0]), blk.downsample[0].bias, mask=my)
                 saved.append((a, b, y))
+                masks.append((ma, mb, my))
                 cur = y
         feat = cur.mean(dim=(2, 3))                                            # AdaptiveAvgPool2d(1) + flatten
         logits = F.linear(feat, net.fc.weight, net.fc.bias)
@@ -143,6 +153,10 @@ class _ResNetFn(torch.autograd.Function):
         flat = [x, stem, pooled, idx]
         for a, b, y in saved:
             flat += [a, b, y] if bottleneck else [a, y]
+        ctx.have_bits = bits and all(m is not None for trio in masks for m in (trio if bottleneck else (trio[0], trio[2])))
+        if ctx.have_bits:
+            for ma, mb, my in masks:
+                flat += [ma, mb, my] if bottleneck else [ma, my]
         ctx.save_for_backward(*flat)
         return logits
 
@@ -153,8 +167,13 @@ class _ResNetFn(torch.autograd.Function):
         flat = ctx.saved_tensors
         x, stem, pooled, idx = flat[:4]
         per = 3 if bottleneck else 2
-        saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(4, len(flat), per)]
         blocks = [blk for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for blk in layer]
+        end = 4 + per * len(blocks)
+        saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(4, end, per)]
+        if ctx.have_bits:
+            masks = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(end, end + per * len(blocks), per)]
+        else:
+            masks = [(None, None, None)] * len(blocks)
         last_y = saved[-1][2]
         n, c, h, w = last_y.shape
         g_feat = g_logits.mm(net.fc.weight)                                    # [N, C]
@@ -166,17 +185,18 @@ class _ResNetFn(torch.autograd.Function):
         for i in range(len(blocks) - 1, -1, -1):
             blk = blocks[i]
             a, b, y = saved[i]
+            ma, mb, my = masks[i]
             x_in = saved[i - 1][2] if i > 0 else pooled
             # threshold of the block's output ReLU on the sum of the junction's two branches, in place on ``g`` (a fresh
             # convolution output nobody else holds; ``pending`` -- possibly the previous ``gm`` -- is only read)
-            gm = _hip.relu_mask(g, y, g, gb=pending)
+            gm = _hip.relu_mask(g, y, g, gb=pending, mask=my)
             if bottleneck:
                 gb_ = _like(_conv_input_grad(gm, b, blk.conv3), b)
-                _hip.relu_mask(gb_, b, gb_)
+                _hip.relu_mask(gb_, b, gb_, mask=mb)
                 ga_ = _like(_conv_input_grad(gb_, a, blk.conv2), a)
             else:
                 ga_ = _like(_conv_input_grad(gm, a, blk.conv2), a)
-            _hip.relu_mask(ga_, a, ga_)
+            _hip.relu_mask(ga_, a, ga_, mask=ma)
             g_main = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in)
             g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
             g, pending = g_main, g_skip                                        # summed inside the next threshold pass

@@ -125,7 +125,11 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
-template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
+// 8 / 12 bytes at a 4-byte aligned address: global_load_dwordx2 / x3 (gfx950 takes dword-aligned wide loads)
+struct __attribute__((packed, aligned(4))) Pair2 { float x, y; };
+struct __attribute__((packed, aligned(4))) Trio3 { float x, y, z; };
+
+template <int RPW, bool PAIRS = true>   // rows per wave of the LDS rectangles: ROWS = 4 * RPW; PAIRS: size >= 2
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
@@ -181,15 +185,26 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         const char* base = reinterpret_cast<const char*>(xp);
         const int w0 = min(wave, max(sh - 1, 0));                      // this wave's first row, inside the rectangle
         const unsigned row0 = static_cast<unsigned>((sr_lo + w0) * size), bstep = 16u * static_cast<unsigned>(size);
-        const unsigned b0 = (row0 + static_cast<unsigned>(tx1.i0)) * 4u, b1 = (row0 + static_cast<unsigned>(tx1.i1)) * 4u;
+        // the two horizontal taps of a lane are neighbours in memory (i1 = i0 + 1, or both the last column): ONE 8-byte load
+        // at a 4-byte aligned address instead of two 4-byte gathers -- vector-memory instructions are what bounds this kernel
+        // (a wave's 64 addresses take the texture addresser 16 cycles whatever the access width: PMC, profiles/r04)
+        const unsigned pair_col = static_cast<unsigned>(min(tx1.i0, max(size - 2, 0)));
+        const bool a_hi = static_cast<unsigned>(tx1.i0) != pair_col, b_hi = static_cast<unsigned>(tx1.i1) != pair_col;
+        const unsigned b0 = (row0 + pair_col) * 4u;
         // rows past the rectangle are clamped to its last row (scalar min) and lanes outside the image read column 0:
         // every load is in bounds and unpredicated; what they produce is never read by V1
         const int last = max(sh - 1 - w0, 0);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const unsigned off = static_cast<unsigned>(min(4 * i, last & ~3)) * (bstep / 4u);
-            a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
-            b[i] = *reinterpret_cast<const float*>(base + (b1 + off));
+            if (PAIRS) {
+                const Pair2 pr = *reinterpret_cast<const Pair2*>(base + (b0 + off));
+                a[i] = a_hi ? pr.y : pr.x;
+                b[i] = b_hi ? pr.y : pr.x;
+            } else {                                                   // a one-column plane: nothing to pair
+                a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
+                b[i] = a[i];
+            }
         }
         float* out = T + wave * 64 + lane;
 #pragma unroll
@@ -367,13 +382,31 @@ struct Hit {
     int first, n;
     unsigned both;                 // bit k: output first+k hits the index with BOTH taps (clamped border): w then w2
     float w[kHitSlots], w2[kHitSlots];
-    int pad;
-};
+    int lo;                        // slots below lo are not hits either (shift_hit: a run moved up so that it starts at an
+};                                 // address a wide load can take); 0 from find_hits
+
+// the same hits with the run starting `shift` outputs earlier: slots 0 .. shift-1 are dead (weight 0, masked), the live ones
+// keep their order.  Needs n + shift <= kHitSlots.
+__device__ __forceinline__ Hit shift_hit(const Hit& h, int shift) {      // shift in 0 .. 2; selects only (no register-array
+    Hit o;                                                                 // indexing by a run-time value: that would go to scratch)
+    o.first = h.first - shift;
+    o.n = h.n == 0 ? 0 : h.n + shift;
+    o.lo = h.n == 0 ? 0 : shift;
+    o.both = h.both << shift;
+#pragma unroll
+    for (int k = 0; k < kHitSlots; ++k) {
+        const float w1 = k >= 1 ? h.w[k >= 1 ? k - 1 : 0] : 0.0f, w2 = k >= 2 ? h.w[k >= 2 ? k - 2 : 0] : 0.0f;
+        const float v1 = k >= 1 ? h.w2[k >= 1 ? k - 1 : 0] : 0.0f, v2 = k >= 2 ? h.w2[k >= 2 ? k - 2 : 0] : 0.0f;
+        o.w[k] = shift == 0 ? h.w[k] : (shift == 1 ? w1 : w2);
+        o.w2[k] = shift == 0 ? h.w2[k] : (shift == 1 ? v1 : v2);
+    }
+    return o;
+}
 
 // outputs o of a 1-D resample (in_size -> out_size, scale = in/out) whose taps touch source index t
 __device__ __forceinline__ Hit find_hits(int t, int in_size, int out_size, float scale) {
     Hit h;
-    h.first = 0; h.n = 0; h.both = 0u; h.pad = 0;
+    h.first = 0; h.n = 0; h.both = 0u; h.lo = 0;
 #pragma unroll
     for (int k = 0; k < kHitSlots; ++k) { h.w[k] = 0.0f; h.w2[k] = 0.0f; }
     // src(o) >= t-1  <=>  o >= (t-0.5)/scale - 0.5 ; start two below the estimate, the taps themselves decide
@@ -420,7 +453,7 @@ __device__ __forceinline__ Hit find_hits(int t, int in_size, int out_size, float
 // except the clamped last row / column): one multiply and one fma per slot.
 template <bool FAST>
 __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, float wy2, bool both_y, const Hit& hx, int k) {
-    const bool on = k < hx.n;
+    const bool on = k < hx.n && k >= hx.lo;
     const float gm = on ? g : 0.0f;
     const float wx = hx.w[k];                                  // 0 beyond n (find_hits)
     acc = fmaf(wy * wx, gm, acc);
@@ -436,6 +469,22 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     }
     return acc;
 }
+
+// SA consecutive floats of one row starting at a dword-aligned byte offset: ONE global_load_dword / dwordx2 / dwordx3
+template <int SA> struct RowRun;
+template <> struct RowRun<1> { static __device__ __forceinline__ void load(const char* p, float (&g)[1]) { g[0] = *reinterpret_cast<const float*>(p); } };
+template <> struct RowRun<2> {
+    static __device__ __forceinline__ void load(const char* p, float (&g)[2]) {
+        const Pair2 v = *reinterpret_cast<const Pair2*>(p);
+        g[0] = v.x; g[1] = v.y;
+    }
+};
+template <> struct RowRun<3> {
+    static __device__ __forceinline__ void load(const char* p, float (&g)[3]) {
+        const Trio3 v = *reinterpret_cast<const Trio3*>(p);
+        g[0] = v.x; g[1] = v.y; g[2] = v.z;
+    }
+};
 
 template <int RPW, int SB, int PP, int SA>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
                                         // SA: hit slots of stage A (2 when no padded index is touched by 3 outputs: always so when the
@@ -488,19 +537,22 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     {
         Hit hx = colA[lane < mw ? lane : 0];
         if (lane >= mw) hx.n = 0;
+        // the lane's SA output columns are neighbours: one wide load per row (vector-memory instructions bound this kernel,
+        // see dim_fwd_lanes_kernel).  At the right border the run is moved left until it fits the row (shift_hit).
+        {
+            const int start = max(min(hx.first, size - SA), 0);
+            hx = shift_hit(hx, hx.first - start);
+        }
         const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        unsigned col[SA];                                    // byte offsets of the lane's output columns
-#pragma unroll
-        for (int k = 0; k < SA; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
+        const unsigned col0 = static_cast<unsigned>(hx.first) * 4u;       // byte offset of the run
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-        // software pipeline over the wave's rows: the 9 loads of row p + 4 are in flight while row p is accumulated
+        // software pipeline over the wave's rows: the loads of row p + 4 are in flight while row p is accumulated
         auto fetch = [&](int p, float (&g)[SA][SA]) {
             const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
 #pragma unroll
             for (int ky = 0; ky < SA; ++ky) {
                 const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
-#pragma unroll
-                for (int kx = 0; kx < SA; ++kx) g[ky][kx] = *reinterpret_cast<const float*>(gyp + (row + col[kx]));
+                RowRun<SA>::load(gyp + (row + col0), g[ky]);
             }
         };
         auto reduce = [&](int p, const float (&g)[SA][SA]) {
@@ -650,10 +702,12 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
     {
         Hit hx = colA[lane < mw ? lane : 0];
         if (lane >= mw) hx.n = 0;
+        {                                                                 // one wide load per (plane, row): see the lanes kernel
+            const int start = max(min(hx.first, size - SA), 0);
+            hx = shift_hit(hx, hx.first - start);
+        }
         const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        unsigned col[SA];
-#pragma unroll
-        for (int k = 0; k < SA; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
+        const unsigned col0 = static_cast<unsigned>(hx.first) * 4u;
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
         auto fetch = [&](int p, float (&g)[3][SA][SA]) {
             const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
@@ -661,9 +715,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
             for (int ky = 0; ky < SA; ++ky) {
                 const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
 #pragma unroll
-                for (int kx = 0; kx < SA; ++kx)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) g[c][ky][kx] = *reinterpret_cast<const float*>(gyp[c] + (row + col[kx]));
+                for (int c = 0; c < 3; ++c) RowRun<SA>::load(gyp[c] + (row + col0), g[c][ky]);
             }
         };
         auto reduce = [&](int p, const float (&g)[3][SA][SA]) {
@@ -679,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
                     if (ky < n_y)
 #pragma unroll
                         for (int kx = 0; kx < SA; ++kx) {
-                            const bool on = kx < hx.n;                 // an off slot re-reads a neighbour: keep a non-finite one out
+                            const bool on = kx < hx.n && kx >= hx.lo;  // a dead slot reads a neighbour: keep a non-finite one out
                             const float w = hy->w[ky] * hx.w[kx];       // (0 beyond n)
                             const v2f g01 = v2f{on ? g[0][ky][kx] : 0.0f, on ? g[1][ky][kx] : 0.0f};
                             acc01 = __builtin_elementwise_fma(v2f{w, w}, g01, acc01);
@@ -901,7 +953,7 @@ static int max_hits(int in_size, int out_size) {
 
 static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
     if (size <= 0 || resize <= 0) return 0;
-    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+    if (size >= 4 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const double up = static_cast<double>(resize) / size;
         const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
@@ -932,12 +984,11 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-            if (rows <= 40)
-                hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y);
-            else
-                hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y);
+#define TA_DIM_FWD(RPW, PAIRS) hipLaunchKernelGGL((dim_fwd_lanes_kernel<RPW, PAIRS>), grid, dim3(kBlock), 0, st, x, y, size, resize, \
+                                                  rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y)
+            if (rows <= 40) { if (size >= 2) TA_DIM_FWD(10, true); else TA_DIM_FWD(10, false); }
+            else { if (size >= 2) TA_DIM_FWD(17, true); else TA_DIM_FWD(17, false); }
+#undef TA_DIM_FWD
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -960,8 +1011,9 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // lane-per-column gather: resize > size, resize <= 1.5 * size and < 2^28 elements per plane (the choice depends on
-    // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives)
-    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+    // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives); size >= 4: a
+    // lane's run of up to 3 output columns is one wide load that must fit a row
+    if (size >= 4 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double up = static_cast<double>(resize) / size;                          // bound for rnd / size

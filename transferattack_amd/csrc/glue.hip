@@ -17,6 +17,24 @@ namespace ta {
 
 __device__ __forceinline__ float relu_like_aten(float v) { return v < 0.0f ? 0.0f : v; }   // clamp_min(v, 0): NaN stays NaN
 
+// ---- ReLU masks as bits (round 4).  The input-gradient backward of a frozen network needs the saved activations for ONE
+// thing: the sign test of threshold_backward (y <= 0 ? 0 : g) -- 4 bytes read per element to learn one bit.  The forward
+// kernels below can leave that bit behind (bit i % 8 of byte i / 8 for element i of the dense buffer; set where the
+// gradient passes: !(y <= 0), so a NaN activation lets it pass as ATen does), and relu_mask_kernel can take it instead of
+// y: 12.1 instead of 16 B/element at a junction, 8.1 instead of 12 after a convolution.  Two neighbouring lanes hold the
+// two halves of a byte (16-byte groups of four elements); the even lane fetches its neighbour's half with one DPP move.
+__device__ __forceinline__ unsigned pass_bits(const float4& v) {
+    return (v.x <= 0.0f ? 0u : 1u) | (v.y <= 0.0f ? 0u : 2u) | (v.z <= 0.0f ? 0u : 4u) | (v.w <= 0.0f ? 0u : 8u);
+}
+// the caller guarantees numel % 8 == 0, so the lanes (2k, 2k + 1) of a pair are both inside or both outside the buffer
+__device__ __forceinline__ void store_pass_bits(uint8_t* __restrict__ mask, unsigned i, unsigned nibble) {
+    const unsigned other = __float_as_uint(__shfl_xor(__uint_as_float(nibble), 1, kWave));
+    if ((threadIdx.x & 1u) == 0u) mask[i >> 3] = static_cast<uint8_t>(nibble | (other << 4));
+}
+__device__ __forceinline__ unsigned load_pass_bits(const uint8_t* __restrict__ mask, unsigned i) {
+    return (static_cast<unsigned>(mask[i >> 3]) >> (i & 4u)) & 15u;
+}
+
 struct ChannelOf {
     unsigned inner, channels, mask;      // mask = channels - 1 when channels is a power of two, else 0
     __device__ __forceinline__ unsigned operator()(unsigned i) const {
@@ -36,9 +54,9 @@ __device__ __forceinline__ float4 bias4(const float* __restrict__ bias, const Ch
     return make_float4(bias[ch(i)], bias[ch(i + 1)], bias[ch(i + 2)], bias[ch(i + 3)]);
 }
 
-template <bool RELU>
+template <bool RELU, bool BITS = false>
 __global__ __launch_bounds__(kBlock) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, ChannelOf ch,
-                                                          unsigned numel, int mode) {
+                                                          unsigned numel, int mode, uint8_t* __restrict__ mask = nullptr) {
     const unsigned base = blockIdx.x * kTile;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -49,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_kernel(float* __restrict__ y,
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             if (RELU) { a.x = relu_like_aten(a.x); a.y = relu_like_aten(a.y); a.z = relu_like_aten(a.z); a.w = relu_like_aten(a.w); }
             *reinterpret_cast<float4*>(y + i) = a;
+            if (BITS) store_pass_bits(mask, i, pass_bits(a));
         } else {
             for (unsigned j = i; j < numel; ++j) {
                 const float v = y[j] + bias[ch(j)];
@@ -58,11 +77,11 @@ __global__ __launch_bounds__(kBlock) void bias_act_kernel(float* __restrict__ y,
     }
 }
 
-template <bool HAS_BO>
+template <bool HAS_BO, bool BITS = false>
 __global__ __launch_bounds__(kBlock) void bias_add_relu_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                const float* __restrict__ other,
                                                                const float* __restrict__ bias_other, ChannelOf ch,
-                                                               unsigned numel, int mode) {
+                                                               unsigned numel, int mode, uint8_t* __restrict__ mask = nullptr) {
     const unsigned base = blockIdx.x * kTile;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -80,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void bias_add_relu_kernel(float* __restrict
             a.z = relu_like_aten((a.z + b.z) + o.z);
             a.w = relu_like_aten((a.w + b.w) + o.w);
             *reinterpret_cast<float4*>(y + i) = a;
+            if (BITS) store_pass_bits(mask, i, pass_bits(a));
         } else {
             for (unsigned j = i; j < numel; ++j) {
                 const unsigned c = ch(j);
@@ -90,9 +110,9 @@ __global__ __launch_bounds__(kBlock) void bias_add_relu_kernel(float* __restrict
     }
 }
 
-template <bool HAS_B>      // out = y <= 0 ? 0 : ga (+ gb)      threshold_backward(grad, result, 0): NaN in y lets the gradient pass
+template <bool HAS_B, bool BITS = false>   // out = y <= 0 ? 0 : ga (+ gb)   threshold_backward(grad, result, 0): NaN in y lets the gradient pass
 __global__ __launch_bounds__(kBlock) void relu_mask_kernel(const float* ga, const float* gb, const float* __restrict__ y,
-                                                           float* out, unsigned numel) {
+                                                           float* out, unsigned numel, const uint8_t* __restrict__ mask = nullptr) {
     const unsigned base = blockIdx.x * kTile;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -103,11 +123,19 @@ __global__ __launch_bounds__(kBlock) void relu_mask_kernel(const float* ga, cons
                 const float4 h = *reinterpret_cast<const float4*>(gb + i);
                 g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
             }
-            const float4 r = *reinterpret_cast<const float4*>(y + i);
-            g.x = r.x <= 0.0f ? 0.0f : g.x;
-            g.y = r.y <= 0.0f ? 0.0f : g.y;
-            g.z = r.z <= 0.0f ? 0.0f : g.z;
-            g.w = r.w <= 0.0f ? 0.0f : g.w;
+            if (BITS) {
+                const unsigned pass = load_pass_bits(mask, i);
+                g.x = (pass & 1u) ? g.x : 0.0f;
+                g.y = (pass & 2u) ? g.y : 0.0f;
+                g.z = (pass & 4u) ? g.z : 0.0f;
+                g.w = (pass & 8u) ? g.w : 0.0f;
+            } else {
+                const float4 r = *reinterpret_cast<const float4*>(y + i);
+                g.x = r.x <= 0.0f ? 0.0f : g.x;
+                g.y = r.y <= 0.0f ? 0.0f : g.y;
+                g.z = r.z <= 0.0f ? 0.0f : g.z;
+                g.w = r.w <= 0.0f ? 0.0f : g.w;
+            }
             *reinterpret_cast<float4*>(out + i) = g;
         } else {
             for (unsigned j = i; j < numel; ++j) {
@@ -135,45 +163,54 @@ static int glue_shape(int64_t numel, int channels, int64_t inner, ChannelOf* ch,
 
 #define TA_GLUE_GRID(numel) dim3(static_cast<unsigned>(ceil_div((numel), kTile)))
 
-extern "C" int ta_bias_act(float* y, const float* bias, int relu, int64_t numel, int channels, int64_t inner, void* stream) {
+extern "C" int ta_bias_act(float* y, const float* bias, int relu, uint8_t* mask, int64_t numel, int channels, int64_t inner,
+                           void* stream) {
     TA_REQUIRE(y && bias && aligned16(y) && aligned16(bias), "null or unaligned pointer");
+    TA_REQUIRE(mask == nullptr || (relu && numel % 8 == 0), "pass bits need the ReLU and numel %% 8 == 0");
     ChannelOf ch;
     int vc;
     if (int rc = glue_shape(numel, channels, inner, &ch, &vc)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (relu)
-        hipLaunchKernelGGL(bias_act_kernel<true>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, ch, static_cast<unsigned>(numel), vc);
+    const unsigned n = static_cast<unsigned>(numel);
+    if (mask)
+        hipLaunchKernelGGL((bias_act_kernel<true, true>), TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, ch, n, vc, mask);
+    else if (relu)
+        hipLaunchKernelGGL((bias_act_kernel<true, false>), TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, ch, n, vc, mask);
     else
-        hipLaunchKernelGGL(bias_act_kernel<false>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, ch, static_cast<unsigned>(numel), vc);
+        hipLaunchKernelGGL((bias_act_kernel<false, false>), TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, ch, n, vc, mask);
     return check_launch("bias_act");
 }
 
-extern "C" int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, int64_t numel,
-                                int channels, int64_t inner, void* stream) {
+extern "C" int ta_bias_add_relu(float* y, const float* bias, const float* other, const float* bias_other, uint8_t* mask,
+                                int64_t numel, int channels, int64_t inner, void* stream) {
     TA_REQUIRE(y && bias && other && y != other && aligned16(y) && aligned16(bias) && aligned16(other) &&
                (bias_other == nullptr || aligned16(bias_other)), "null, aliased or unaligned pointer");
+    TA_REQUIRE(mask == nullptr || numel % 8 == 0, "pass bits need numel %% 8 == 0");
     ChannelOf ch;
     int vc;
     if (int rc = glue_shape(numel, channels, inner, &ch, &vc)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bias_other)
-        hipLaunchKernelGGL(bias_add_relu_kernel<true>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, other, bias_other, ch,
-                           static_cast<unsigned>(numel), vc);
-    else
-        hipLaunchKernelGGL(bias_add_relu_kernel<false>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, other, bias_other, ch,
-                           static_cast<unsigned>(numel), vc);
+    const unsigned n = static_cast<unsigned>(numel);
+#define TA_BAR(BO, BITS) hipLaunchKernelGGL((bias_add_relu_kernel<BO, BITS>), TA_GLUE_GRID(numel), dim3(kBlock), 0, st, y, bias, other, bias_other, ch, n, vc, mask)
+    if (bias_other) { if (mask) TA_BAR(true, true); else TA_BAR(true, false); }
+    else { if (mask) TA_BAR(false, true); else TA_BAR(false, false); }
+#undef TA_BAR
     return check_launch("bias_add_relu");
 }
 
-extern "C" int ta_relu_mask(const float* ga, const float* gb, const float* y, float* out, int64_t numel, void* stream) {
-    TA_REQUIRE(ga && y && out && aligned16(ga) && aligned16(y) && aligned16(out) && (gb == nullptr || aligned16(gb)),
-               "null or unaligned pointer");
+// exactly one of y (the activation itself) and mask (its pass bits, from ta_bias_act / ta_bias_add_relu) is given
+extern "C" int ta_relu_mask(const float* ga, const float* gb, const float* y, const uint8_t* mask, float* out, int64_t numel,
+                            void* stream) {
+    TA_REQUIRE(ga && out && (y != nullptr) != (mask != nullptr) && aligned16(ga) && aligned16(out) &&
+               (y == nullptr || aligned16(y)) && (gb == nullptr || aligned16(gb)), "null or unaligned pointer");
     TA_REQUIRE(numel > 0 && numel % 4 == 0 && numel < (1ll << 32) - kTile, "numel=%lld", (long long)numel);
+    TA_REQUIRE(mask == nullptr || numel % 8 == 0, "pass bits need numel %% 8 == 0");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (gb)
-        hipLaunchKernelGGL(relu_mask_kernel<true>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, ga, gb, y, out, static_cast<unsigned>(numel));
-    else
-        hipLaunchKernelGGL(relu_mask_kernel<false>, TA_GLUE_GRID(numel), dim3(kBlock), 0, st, ga, gb, y, out, static_cast<unsigned>(numel));
+    const unsigned n = static_cast<unsigned>(numel);
+#define TA_RM(B, BITS) hipLaunchKernelGGL((relu_mask_kernel<B, BITS>), TA_GLUE_GRID(numel), dim3(kBlock), 0, st, ga, gb, y, out, n, mask)
+    if (gb) { if (mask) TA_RM(true, true); else TA_RM(true, false); }
+    else { if (mask) TA_RM(false, true); else TA_RM(false, false); }
+#undef TA_RM
     return check_launch("relu_mask");
 }
 
