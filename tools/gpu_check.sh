@@ -114,6 +114,10 @@ ens4)
   for b in 32 125; do
   timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
   done ;;
+benchq)
+  # the default line without the CPU leg and the stand-alone sweep; then with the ReLU pass bits off (activations read instead)
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick.json
+  TA_RELU_BITS=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick_no_relu_bits.json ;;
 ensab)
   # configs[4] at the reference's batch: members one after the other / on their own HIP streams, then what the iteration is made of
   M="--attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --cpu-images 0 --kernel-sweep 0"

@@ -129,7 +129,8 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
 struct __attribute__((packed, aligned(4))) Pair2 { float x, y; };
 struct __attribute__((packed, aligned(4))) Trio3 { float x, y, z; };
 
-template <int RPW, bool PAIRS = true>   // rows per wave of the LDS rectangles: ROWS = 4 * RPW; PAIRS: size >= 2
+// RPW: rows per wave of the LDS rectangles, ROWS = 4 * RPW; PAIRS: size >= 2; QUADS: 16-byte stores through LDS
+template <int RPW, bool PAIRS = true, bool QUADS = false>
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
@@ -239,7 +240,29 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     }
     __syncthreads();
     // -- V2: y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
-    if (lane < twc) {
+    if (QUADS) {
+        // the tile leaves through LDS (`mid` is free: every lane is past H2) so that it reaches memory in 16-byte stores:
+        // 8 store instructions per workgroup instead of 32 (size % 4 == 0, tw % 4 == 0, y 16-byte aligned: host-checked)
+        if (lane < twc) {
+            const float* uc = u + lane - py_lo * 64;
+#pragma unroll
+            for (int i = 0; i < kDimLaneRows / 4; ++i) {
+                const int r = wave + 4 * i;
+                if (r < th) {
+                    const Tap ty = ty2[r];
+                    mid[r * 64 + lane] = fmaf(ty.l0, uc[ty.i0 * 64], ty.l1 * uc[ty.i1 * 64]);
+                }
+            }
+        }
+        __syncthreads();
+        const int c4 = static_cast<int>(threadIdx.x & 15u) * 4;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = static_cast<int>(threadIdx.x >> 4) + 16 * half;
+            if (r < th && c4 < twc)
+                *reinterpret_cast<float4*>(yp + static_cast<int64_t>(oy0 + r) * size + ox0 + c4) = *reinterpret_cast<const float4*>(mid + r * 64 + c4);
+        }
+    } else if (lane < twc) {
         const float* uc = u + lane - py_lo * 64;
         char* base = reinterpret_cast<char*>(yp);
         const unsigned first = static_cast<unsigned>((oy0 + wave) * size + ox0 + lane) * 4u, bstep = 16u * static_cast<unsigned>(size);
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 // of the one-plane kernel (tests: both kernels against oracle/ta_oracle.c and against each other at the shard size).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int RPW, int SB, int SA>
+template <int RPW, int SB, int SA, bool QUADS>      // QUADS: the tile leaves through LDS in 16-byte stores (size % 4 == 0, tw % 4 == 0)
 __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                              float* __restrict__ ws, int size, int resize, int rnd,
                                                              int top, int left, float scale1, float scale2, int tw,
@@ -769,6 +792,11 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
     __syncthreads();
     // -- stage B: gx[iy][ix] of the three planes
     float asum[3] = {0.0f, 0.0f, 0.0f};
+    float keep[3][kDimLaneRows / 4];                                     // QUADS: the lane's results until the tile is staged
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < kDimLaneRows / 4; ++i) keep[c][i] = 0.0f;
     Hit hx = colB[lane < twc ? lane : 0];
     if (lane >= twc) hx.both = 0u;
     const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
@@ -778,8 +806,12 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
         for (int k = 0; k < SB; ++k) col[k] = k < hx.n ? min(hx.first - rx_lo + k, 63) : 64;       // off slots: the zero cell
         unsigned out = static_cast<unsigned>((iy0 + wave) * size + ix0 + lane) * 4u;
         const unsigned bstep = 16u * static_cast<unsigned>(size);
-#pragma unroll 1
-        for (int r = wave; r < th; r += 4, out += bstep) {
+        // (fully unrolled when the results are kept in registers for the staged store: `keep` is then indexed statically)
+        constexpr int kUnrollRows = QUADS ? kDimLaneRows / 4 : 1;
+#pragma unroll kUnrollRows
+        for (int slot = 0; slot < kDimLaneRows / 4; ++slot, out += bstep) {
+            const int r = wave + 4 * slot;
+            if (r >= th) break;
             const Hit* hy = &rowB[r];
             const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
             const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
@@ -818,10 +850,34 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __rest
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                *reinterpret_cast<float*>(gxp[c] + out) = res[c];
+                if (QUADS) keep[c][slot] = res[c];
+                else *reinterpret_cast<float*>(gxp[c] + out) = res[c];
                 asum[c] += fabsf(res[c]);
             }
         }
+    }
+    if (QUADS) {
+        // 16-byte stores: the tile goes through LDS (the window `mid` is dead once every wave is past stage B), planar
+        __syncthreads();
+        float* stage = reinterpret_cast<float*>(mid);                    // [3][kDimLaneRows][64]
+        if (lane < twc) {
+#pragma unroll
+            for (int i = 0; i < kDimLaneRows / 4; ++i)
+                if (wave + 4 * i < th)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) stage[(c * kDimLaneRows + wave + 4 * i) * 64 + lane] = keep[c][i];
+        }
+        __syncthreads();
+        const int c4 = static_cast<int>(threadIdx.x & 15u) * 4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = static_cast<int>(threadIdx.x >> 4) + 16 * half;
+                if (r < th && c4 < twc)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(gxp[c]) + static_cast<int64_t>(iy0 + r) * size + ix0 + c4) =
+                        *reinterpret_cast<const float4*>(stage + (c * kDimLaneRows + r) * 64 + c4);
+            }
     }
     // three workgroup sums in block_sum's order (wave butterflies, then the waves in index order)
 #pragma unroll
@@ -955,7 +1011,8 @@ static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
     if (size <= 0 || resize <= 0) return 0;
     if (size >= 4 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const double up = static_cast<double>(resize) / size;
-        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
+        int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
+        if (size % 4 == 0 && tw >= 12) tw &= ~3;             // as ta_dim_bwd: tiles that start on 16-byte boundaries
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
         if (tw >= 8 && rows <= 68) return ceil_div(size, tw) * ceil_div(size, kDimLaneRows);
     }
@@ -975,7 +1032,9 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double ratio = static_cast<double>(resize) / size;
-        const int tw = static_cast<int>(fmin(64.0, floor(61.0 / ratio) + 1.0));        // window <= (tw-1)*ratio + 3 <= 64
+        int tw = static_cast<int>(fmin(64.0, floor(61.0 / ratio) + 1.0));              // window <= (tw-1)*ratio + 3 <= 64
+        const bool quads = size % 4 == 0 && tw >= 12 && aligned16(y);                  // tiles start and end on 16-byte boundaries
+        if (quads) tw &= ~3;
         const int rows = static_cast<int>(ceil((kDimLaneRows - 1) * ratio)) + 4;       // window rows + 1 row of x
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
@@ -984,10 +1043,10 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-#define TA_DIM_FWD(RPW, PAIRS) hipLaunchKernelGGL((dim_fwd_lanes_kernel<RPW, PAIRS>), grid, dim3(kBlock), 0, st, x, y, size, resize, \
-                                                  rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y)
-            if (rows <= 40) { if (size >= 2) TA_DIM_FWD(10, true); else TA_DIM_FWD(10, false); }
-            else { if (size >= 2) TA_DIM_FWD(17, true); else TA_DIM_FWD(17, false); }
+#define TA_DIM_FWD(RPW, PAIRS, QUADS) hipLaunchKernelGGL((dim_fwd_lanes_kernel<RPW, PAIRS, QUADS>), grid, dim3(kBlock), 0, st, x, y, \
+                                                         size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y)
+            if (rows <= 40) { if (quads) TA_DIM_FWD(10, true, true); else if (size >= 2) TA_DIM_FWD(10, true, false); else TA_DIM_FWD(10, false, false); }
+            else { if (quads) TA_DIM_FWD(17, true, true); else if (size >= 2) TA_DIM_FWD(17, true, false); else TA_DIM_FWD(17, false, false); }
 #undef TA_DIM_FWD
             return check_launch("dim_fwd_lanes");
         }
@@ -1017,7 +1076,9 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double up = static_cast<double>(resize) / size;                          // bound for rnd / size
-        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));           // window <= (tw + 1) * up + 1 <= 64
+        int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));                 // window <= (tw + 1) * up + 1 <= 64
+        if (size % 4 == 0 && tw >= 12) tw &= ~3;                                       // (the same rule in ta_dim_bwd_tiles)
+        const bool quads = size % 4 == 0 && tw % 4 == 0 && aligned16(gx);
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
@@ -1031,14 +1092,16 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             if (rgb) {
                 const dim3 rgb_grid(static_cast<unsigned>(planes / 3 * tiles_x * tiles_y));
                 const bool three_b = max_hits(size, rnd) <= 3, two_a = max_hits(resize, size) <= 2;
-#define TA_DIM_RGB(RPW, SB, SA)                                                                                          \
-    hipLaunchKernelGGL((dim_bwd_rgb_kernel<RPW, SB, SA>), rgb_grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
+#define TA_DIM_RGB_Q(RPW, SB, SA, Q)                                                                                     \
+    hipLaunchKernelGGL((dim_bwd_rgb_kernel<RPW, SB, SA, Q>), rgb_grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
                        left, scale1, scale2, tw, tiles_x, tiles_y)
+#define TA_DIM_RGB(RPW, SB, SA) do { if (quads) TA_DIM_RGB_Q(RPW, SB, SA, true); else TA_DIM_RGB_Q(RPW, SB, SA, false); } while (0)
 #define TA_DIM_RGB_A(RPW, SB) do { if (two_a) TA_DIM_RGB(RPW, SB, 2); else TA_DIM_RGB(RPW, SB, 3); } while (0)
                 if (rows <= 40) { if (three_b) TA_DIM_RGB_A(10, 3); else TA_DIM_RGB_A(10, 4); }
                 else { if (three_b) TA_DIM_RGB_A(17, 3); else TA_DIM_RGB_A(17, 4); }
 #undef TA_DIM_RGB_A
 #undef TA_DIM_RGB
+#undef TA_DIM_RGB_Q
                 return check_launch("dim_bwd_rgb");
             }
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
