@@ -481,40 +481,21 @@ def test_dim_golden(golden):
     (33, 2.0, [(40, 5, 20), (65, 0, 1)]),
 ])
 def test_dim_random(size, rate, geoms):
-    """forward and backward against oracle/ta_oracle.c (bit-exact) and the torch ops the reference runs; the backward once
-    with one plane at a time (dim_bwd_lanes_kernel, TA_DIM_BWD_RGB=0) and once with the three colour planes of an image in
-    one lane (dim_bwd_rgb_kernel, packed arithmetic, TA_DIM_BWD_RGB=1) -- the same bits from both, and the same |gx| sums"""
-    import os
     gen = torch.Generator().manual_seed(size)
     resize = int(size * rate)
     x = torch.rand(3, 3, size, size, generator=gen)
     gy = torch.randn(3, 3, size, size, generator=gen)
-    saved = os.environ.get("TA_DIM_BWD_RGB")
-    try:
-        for rnd, top, left in geoms:
-            geom = (True, rnd, top, left)
-            y = torch.empty(x.shape, device=DEV)
-            _hip.dim_fwd(x.to(DEV), y, resize, rnd, top, left)
-            assert np.array_equal(host(y), C.dim_fwd(x.numpy(), geom, resize)), geom
-            got = {}
-            for rgb in ("0", "1"):
-                os.environ["TA_DIM_BWD_RGB"] = rgb
-                gx = torch.full(x.shape, float("nan"), device=DEV)
-                _hip.dim_bwd(gy.to(DEV), gx, resize, rnd, top, left)
-                sums, slots = _hip.partials_of(gx)
-                got[rgb] = (gx, sums[:3 * slots].clone())
-                assert np.array_equal(host(gx), C.dim_bwd(gy.numpy(), geom, resize)), (geom, rgb)
-            assert torch.equal(got["0"][1], got["1"][1]), "the |gx| tile sums differ between the two backward kernels"
-            gx = got["1"][0]
-            xin = x.clone().requires_grad_(True)
-            yt = O.dim_apply(xin, geom, rate)
-            assert ulp_diff(host(y), yt.detach().numpy()) <= (2 if size >= 128 else 4)   # ATen's own small-tensor variant
-            np.testing.assert_allclose(host(gx), torch.autograd.grad(yt, xin, gy)[0].numpy(), rtol=0, atol=1e-6)
-    finally:
-        if saved is None:
-            os.environ.pop("TA_DIM_BWD_RGB", None)
-        else:
-            os.environ["TA_DIM_BWD_RGB"] = saved
+    for rnd, top, left in geoms:
+        geom = (True, rnd, top, left)
+        y, gx = torch.empty(x.shape, device=DEV), torch.empty(x.shape, device=DEV)
+        _hip.dim_fwd(x.to(DEV), y, resize, rnd, top, left)
+        _hip.dim_bwd(gy.to(DEV), gx, resize, rnd, top, left)
+        assert np.array_equal(host(y), C.dim_fwd(x.numpy(), geom, resize)), geom
+        assert np.array_equal(host(gx), C.dim_bwd(gy.numpy(), geom, resize)), geom
+        xin = x.clone().requires_grad_(True)
+        yt = O.dim_apply(xin, geom, rate)
+        assert ulp_diff(host(y), yt.detach().numpy()) <= (2 if size >= 128 else 4)   # ATen's own small-tensor variant
+        np.testing.assert_allclose(host(gx), torch.autograd.grad(yt, xin, gy)[0].numpy(), rtol=0, atol=1e-6)
 
 
 # -------------------------------------------------------------------------------------------- SIM / Admix

@@ -52,10 +52,6 @@ def main():
         rec("tim_conv15", timed(lambda i: _hip.depthwise_conv2d_same(sets[i % 3][0], sets[i % 3][1], w)), 8, 450)
         rec("dim_fwd", timed(lambda i: _hip.dim_fwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
         rec("dim_bwd", timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
-        for tag, flag in (("dim_bwd_one_plane_per_lane", "0"), ("dim_bwd_three_planes_per_lane", "1")):
-            os.environ["TA_DIM_BWD_RGB"] = flag
-            rec(tag, timed(lambda i: _hip.dim_bwd(sets[i % 3][0], sets[i % 3][1], 246, 237, 3, 5)), 8)
-        os.environ.pop("TA_DIM_BWD_RGB", None)
         rec("vmi_neighbor_philox", timed(lambda i: _hip.vmi_neighbor(sets[i % 3][0], sets[i % 3][1], sets[i % 3][2],
                                                                       0.09, seed=1, offset=i)), 12)
         rec("vmi_neighbor_normalized_philox", timed(lambda i: _hip.vmi_neighbor_normalized(

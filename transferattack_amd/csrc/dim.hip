@@ -125,12 +125,7 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
-// 8 / 12 bytes at a 4-byte aligned address: global_load_dwordx2 / x3 (gfx950 takes dword-aligned wide loads)
-struct __attribute__((packed, aligned(4))) Pair2 { float x, y; };
-struct __attribute__((packed, aligned(4))) Trio3 { float x, y, z; };
-
-// RPW: rows per wave of the LDS rectangles, ROWS = 4 * RPW; PAIRS: size >= 2; QUADS: 16-byte stores through LDS
-template <int RPW, bool PAIRS = true, bool QUADS = false>
+template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
@@ -186,26 +181,15 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         const char* base = reinterpret_cast<const char*>(xp);
         const int w0 = min(wave, max(sh - 1, 0));                      // this wave's first row, inside the rectangle
         const unsigned row0 = static_cast<unsigned>((sr_lo + w0) * size), bstep = 16u * static_cast<unsigned>(size);
-        // the two horizontal taps of a lane are neighbours in memory (i1 = i0 + 1, or both the last column): ONE 8-byte load
-        // at a 4-byte aligned address instead of two 4-byte gathers -- vector-memory instructions are what bounds this kernel
-        // (a wave's 64 addresses take the texture addresser 16 cycles whatever the access width: PMC, profiles/r04)
-        const unsigned pair_col = static_cast<unsigned>(min(tx1.i0, max(size - 2, 0)));
-        const bool a_hi = static_cast<unsigned>(tx1.i0) != pair_col, b_hi = static_cast<unsigned>(tx1.i1) != pair_col;
-        const unsigned b0 = (row0 + pair_col) * 4u;
+        const unsigned b0 = (row0 + static_cast<unsigned>(tx1.i0)) * 4u, b1 = (row0 + static_cast<unsigned>(tx1.i1)) * 4u;
         // rows past the rectangle are clamped to its last row (scalar min) and lanes outside the image read column 0:
         // every load is in bounds and unpredicated; what they produce is never read by V1
         const int last = max(sh - 1 - w0, 0);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const unsigned off = static_cast<unsigned>(min(4 * i, last & ~3)) * (bstep / 4u);
-            if (PAIRS) {
-                const Pair2 pr = *reinterpret_cast<const Pair2*>(base + (b0 + off));
-                a[i] = a_hi ? pr.y : pr.x;
-                b[i] = b_hi ? pr.y : pr.x;
-            } else {                                                   // a one-column plane: nothing to pair
-                a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
-                b[i] = a[i];
-            }
+            a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
+            b[i] = *reinterpret_cast<const float*>(base + (b1 + off));
         }
         float* out = T + wave * 64 + lane;
 #pragma unroll
@@ -240,29 +224,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     }
     __syncthreads();
     // -- V2: y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
-    if (QUADS) {
-        // the tile leaves through LDS (`mid` is free: every lane is past H2) so that it reaches memory in 16-byte stores:
-        // 8 store instructions per workgroup instead of 32 (size % 4 == 0, tw % 4 == 0, y 16-byte aligned: host-checked)
-        if (lane < twc) {
-            const float* uc = u + lane - py_lo * 64;
-#pragma unroll
-            for (int i = 0; i < kDimLaneRows / 4; ++i) {
-                const int r = wave + 4 * i;
-                if (r < th) {
-                    const Tap ty = ty2[r];
-                    mid[r * 64 + lane] = fmaf(ty.l0, uc[ty.i0 * 64], ty.l1 * uc[ty.i1 * 64]);
-                }
-            }
-        }
-        __syncthreads();
-        const int c4 = static_cast<int>(threadIdx.x & 15u) * 4;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int r = static_cast<int>(threadIdx.x >> 4) + 16 * half;
-            if (r < th && c4 < twc)
-                *reinterpret_cast<float4*>(yp + static_cast<int64_t>(oy0 + r) * size + ox0 + c4) = *reinterpret_cast<const float4*>(mid + r * 64 + c4);
-        }
-    } else if (lane < twc) {
+    if (lane < twc) {
         const float* uc = u + lane - py_lo * 64;
         char* base = reinterpret_cast<char*>(yp);
         const unsigned first = static_cast<unsigned>((oy0 + wave) * size + ox0 + lane) * 4u, bstep = 16u * static_cast<unsigned>(size);
@@ -405,31 +367,13 @@ struct Hit {
     int first, n;
     unsigned both;                 // bit k: output first+k hits the index with BOTH taps (clamped border): w then w2
     float w[kHitSlots], w2[kHitSlots];
-    int lo;                        // slots below lo are not hits either (shift_hit: a run moved up so that it starts at an
-};                                 // address a wide load can take); 0 from find_hits
-
-// the same hits with the run starting `shift` outputs earlier: slots 0 .. shift-1 are dead (weight 0, masked), the live ones
-// keep their order.  Needs n + shift <= kHitSlots.
-__device__ __forceinline__ Hit shift_hit(const Hit& h, int shift) {      // shift in 0 .. 2; selects only (no register-array
-    Hit o;                                                                 // indexing by a run-time value: that would go to scratch)
-    o.first = h.first - shift;
-    o.n = h.n == 0 ? 0 : h.n + shift;
-    o.lo = h.n == 0 ? 0 : shift;
-    o.both = h.both << shift;
-#pragma unroll
-    for (int k = 0; k < kHitSlots; ++k) {
-        const float w1 = k >= 1 ? h.w[k >= 1 ? k - 1 : 0] : 0.0f, w2 = k >= 2 ? h.w[k >= 2 ? k - 2 : 0] : 0.0f;
-        const float v1 = k >= 1 ? h.w2[k >= 1 ? k - 1 : 0] : 0.0f, v2 = k >= 2 ? h.w2[k >= 2 ? k - 2 : 0] : 0.0f;
-        o.w[k] = shift == 0 ? h.w[k] : (shift == 1 ? w1 : w2);
-        o.w2[k] = shift == 0 ? h.w2[k] : (shift == 1 ? v1 : v2);
-    }
-    return o;
-}
+    int pad;
+};
 
 // outputs o of a 1-D resample (in_size -> out_size, scale = in/out) whose taps touch source index t
 __device__ __forceinline__ Hit find_hits(int t, int in_size, int out_size, float scale) {
     Hit h;
-    h.first = 0; h.n = 0; h.both = 0u; h.lo = 0;
+    h.first = 0; h.n = 0; h.both = 0u; h.pad = 0;
 #pragma unroll
     for (int k = 0; k < kHitSlots; ++k) { h.w[k] = 0.0f; h.w2[k] = 0.0f; }
     // src(o) >= t-1  <=>  o >= (t-0.5)/scale - 0.5 ; start two below the estimate, the taps themselves decide
@@ -476,7 +420,7 @@ __device__ __forceinline__ Hit find_hits(int t, int in_size, int out_size, float
 // except the clamped last row / column): one multiply and one fma per slot.
 template <bool FAST>
 __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, float wy2, bool both_y, const Hit& hx, int k) {
-    const bool on = k < hx.n && k >= hx.lo;
+    const bool on = k < hx.n;
     const float gm = on ? g : 0.0f;
     const float wx = hx.w[k];                                  // 0 beyond n (find_hits)
     acc = fmaf(wy * wx, gm, acc);
@@ -492,22 +436,6 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     }
     return acc;
 }
-
-// SA consecutive floats of one row starting at a dword-aligned byte offset: ONE global_load_dword / dwordx2 / dwordx3
-template <int SA> struct RowRun;
-template <> struct RowRun<1> { static __device__ __forceinline__ void load(const char* p, float (&g)[1]) { g[0] = *reinterpret_cast<const float*>(p); } };
-template <> struct RowRun<2> {
-    static __device__ __forceinline__ void load(const char* p, float (&g)[2]) {
-        const Pair2 v = *reinterpret_cast<const Pair2*>(p);
-        g[0] = v.x; g[1] = v.y;
-    }
-};
-template <> struct RowRun<3> {
-    static __device__ __forceinline__ void load(const char* p, float (&g)[3]) {
-        const Trio3 v = *reinterpret_cast<const Trio3*>(p);
-        g[0] = v.x; g[1] = v.y; g[2] = v.z;
-    }
-};
 
 template <int RPW, int SB, int PP, int SA>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
                                         // SA: hit slots of stage A (2 when no padded index is touched by 3 outputs: always so when the
@@ -560,22 +488,19 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     {
         Hit hx = colA[lane < mw ? lane : 0];
         if (lane >= mw) hx.n = 0;
-        // the lane's SA output columns are neighbours: one wide load per row (vector-memory instructions bound this kernel,
-        // see dim_fwd_lanes_kernel).  At the right border the run is moved left until it fits the row (shift_hit).
-        {
-            const int start = max(min(hx.first, size - SA), 0);
-            hx = shift_hit(hx, hx.first - start);
-        }
         const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        const unsigned col0 = static_cast<unsigned>(hx.first) * 4u;       // byte offset of the run
+        unsigned col[SA];                                    // byte offsets of the lane's output columns
+#pragma unroll
+        for (int k = 0; k < SA; ++k) col[k] = static_cast<unsigned>(min(hx.first + k, size - 1)) * 4u;
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-        // software pipeline over the wave's rows: the loads of row p + 4 are in flight while row p is accumulated
+        // software pipeline over the wave's rows: the 9 loads of row p + 4 are in flight while row p is accumulated
         auto fetch = [&](int p, float (&g)[SA][SA]) {
             const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
 #pragma unroll
             for (int ky = 0; ky < SA; ++ky) {
                 const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
-                RowRun<SA>::load(gyp + (row + col0), g[ky]);
+#pragma unroll
+                for (int kx = 0; kx < SA; ++kx) g[ky][kx] = *reinterpret_cast<const float*>(gyp + (row + col[kx]));
             }
         };
         auto reduce = [&](int p, const float (&g)[SA][SA]) {
@@ -663,237 +588,6 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     }   // planes of the group
 }
 
-
-// The three colour planes of an image at once (round 4).  PMC of the lanes kernel above (profiles/r04/dim_pmc_n160_r4b.txt):
-// 68 % of its cycles are VALU issue, 2147 VALU instructions per wave of a three-plane workgroup -- three times the same
-// index logic, weight products and predication, once per plane.  Where a pixel's hits are and what they weigh is the same
-// for R, G and B, so here a lane carries all three through both stages: one weight product per tap, the first two planes in
-// one v_pk_fma_f32 (an even-aligned register pair), the third in a v_fma_f32; the d(rescaled) window lives in LDS as one
-// 16-byte cell per pixel (R, G, B, 0) -- one ds_read_b128 per tap instead of three ds_read_b32.  Slots beyond a column's hit
-// count read an all-zero cell (column 64 of every window row) with weight 0: fma(0, 0, acc) == acc bit for bit, no select.
-// Every accumulator still sees its taps in ATen's order, so each plane's result -- and its |gx| tile sum -- carries the bits
-// of the one-plane kernel (tests: both kernels against oracle/ta_oracle.c and against each other at the shard size).
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int RPW, int SB, int SA, bool QUADS>      // QUADS: the tile leaves through LDS in 16-byte stores (size % 4 == 0, tw % 4 == 0)
-__global__ __launch_bounds__(kBlock) void dim_bwd_rgb_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                             float* __restrict__ ws, int size, int resize, int rnd,
-                                                             int top, int left, float scale1, float scale2, int tw,
-                                                             int tiles_x, int tiles_y) {
-    constexpr int ROWS = 4 * RPW;
-    constexpr int MS = 65;                                              // cells per window row: 64 columns + the zero cell
-    __shared__ __attribute__((aligned(16))) Hit colB[64];
-    __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];
-    __shared__ __attribute__((aligned(16))) Hit colA[64];
-    __shared__ __attribute__((aligned(16))) Hit rowA[ROWS];
-    __shared__ __attribute__((aligned(16))) float4 mid[ROWS * MS];      // d(rescaled) window: (R, G, B, 0) per pixel
-    __shared__ float red[3][kBlock / kWave];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(blockIdx.x);
-    const int image = tid / tiles;
-    const int t = tid - image * tiles;
-    const int tyi = t / tiles_x;
-    const int iy0 = tyi * kDimLaneRows, ix0 = (t - tyi * tiles_x) * tw;
-    const int th = min(kDimLaneRows, size - iy0), twc = min(tw, size - ix0);
-
-    if (wave == 0 && lane < twc) colB[lane] = find_hits(ix0 + lane, size, rnd, scale1);
-    if (wave == 1 && lane < th) rowB[lane] = find_hits(iy0 + lane, size, rnd, scale1);
-    for (int p = threadIdx.x; p < ROWS; p += kBlock) mid[p * MS + 64] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    const int rx_lo = colB[0].first, rx_hi = colB[twc - 1].first + colB[twc - 1].n - 1;
-    const int ry_lo = rowB[0].first, ry_hi = rowB[th - 1].first + rowB[th - 1].n - 1;
-    const int mw = rx_hi - rx_lo + 1, mh = ry_hi - ry_lo + 1;           // <= 64, <= ROWS (host-checked)
-    if (wave == 0 && lane < mw) colA[lane] = find_hits(rx_lo + lane + left, resize, size, scale2);
-    {
-        const int p = static_cast<int>(threadIdx.x) - 64;
-        if (p >= 0 && p < mh) rowA[p] = find_hits(ry_lo + p + top, resize, size, scale2);
-    }
-    __syncthreads();
-
-    const int64_t plane_elems = static_cast<int64_t>(size) * size;
-    const char* gyp[3];
-    char* gxp[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        gyp[c] = reinterpret_cast<const char*>(gy + (static_cast<int64_t>(image) * 3 + c) * plane_elems);
-        gxp[c] = reinterpret_cast<char*>(gx + (static_cast<int64_t>(image) * 3 + c) * plane_elems);
-    }
-    // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c] of the three planes
-    {
-        Hit hx = colA[lane < mw ? lane : 0];
-        if (lane >= mw) hx.n = 0;
-        {                                                                 // one wide load per (plane, row): see the lanes kernel
-            const int start = max(min(hx.first, size - SA), 0);
-            hx = shift_hit(hx, hx.first - start);
-        }
-        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        const unsigned col0 = static_cast<unsigned>(hx.first) * 4u;
-        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-        auto fetch = [&](int p, float (&g)[3][SA][SA]) {
-            const int first_y = __builtin_amdgcn_readfirstlane(rowA[p].first);
-#pragma unroll
-            for (int ky = 0; ky < SA; ++ky) {
-                const unsigned row = static_cast<unsigned>(min(first_y + ky, size - 1)) * row_bytes;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) RowRun<SA>::load(gyp[c] + (row + col0), g[c][ky]);
-            }
-        };
-        auto reduce = [&](int p, const float (&g)[3][SA][SA]) {
-            const Hit* hy = &rowA[p];
-            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
-            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
-            float4 cell = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!any_both_x && both_y == 0u) {
-                v2f acc01 = v2f{0.0f, 0.0f};
-                float acc2 = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < SA; ++ky)
-                    if (ky < n_y)
-#pragma unroll
-                        for (int kx = 0; kx < SA; ++kx) {
-                            const bool on = kx < hx.n && kx >= hx.lo;  // a dead slot reads a neighbour: keep a non-finite one out
-                            const float w = hy->w[ky] * hx.w[kx];       // (0 beyond n)
-                            const v2f g01 = v2f{on ? g[0][ky][kx] : 0.0f, on ? g[1][ky][kx] : 0.0f};
-                            acc01 = __builtin_elementwise_fma(v2f{w, w}, g01, acc01);
-                            acc2 = fmaf(w, on ? g[2][ky][kx] : 0.0f, acc2);
-                        }
-                cell = make_float4(acc01.x, acc01.y, acc2, 0.f);
-            } else {
-                float acc[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int ky = 0; ky < SA; ++ky)
-                        if (ky < n_y)
-#pragma unroll
-                            for (int kx = 0; kx < SA; ++kx)
-                                acc[c] = hit_accumulate<false>(acc[c], g[c][ky][kx], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
-                cell = make_float4(acc[0], acc[1], acc[2], 0.f);
-            }
-            mid[p * MS + lane] = cell;
-        };
-        float ga[3][SA][SA], gb[3][SA][SA];
-        int p = wave;
-        if (p < mh) fetch(p, ga);
-#pragma unroll 1
-        while (p < mh) {
-            fetch(min(p + 4, mh - 1), gb);
-            reduce(p, ga);
-            p += 4;
-            if (p >= mh) break;
-            fetch(min(p + 4, mh - 1), ga);
-            reduce(p, gb);
-            p += 4;
-        }
-    }
-    __syncthreads();
-    // -- stage B: gx[iy][ix] of the three planes
-    float asum[3] = {0.0f, 0.0f, 0.0f};
-    float keep[3][kDimLaneRows / 4];                                     // QUADS: the lane's results until the tile is staged
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < kDimLaneRows / 4; ++i) keep[c][i] = 0.0f;
-    Hit hx = colB[lane < twc ? lane : 0];
-    if (lane >= twc) hx.both = 0u;
-    const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-    if (lane < twc) {
-        int col[SB];
-#pragma unroll
-        for (int k = 0; k < SB; ++k) col[k] = k < hx.n ? min(hx.first - rx_lo + k, 63) : 64;       // off slots: the zero cell
-        unsigned out = static_cast<unsigned>((iy0 + wave) * size + ix0 + lane) * 4u;
-        const unsigned bstep = 16u * static_cast<unsigned>(size);
-        // (fully unrolled when the results are kept in registers for the staged store: `keep` is then indexed statically)
-        constexpr int kUnrollRows = QUADS ? kDimLaneRows / 4 : 1;
-#pragma unroll kUnrollRows
-        for (int slot = 0; slot < kDimLaneRows / 4; ++slot, out += bstep) {
-            const int r = wave + 4 * slot;
-            if (r >= th) break;
-            const Hit* hy = &rowB[r];
-            const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
-            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);
-            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
-            float res[3];
-            if (!any_both_x && both_y == 0u) {
-                v2f acc01 = v2f{0.0f, 0.0f};
-                float acc2 = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < SB; ++ky)
-                    if (ky < n_y) {
-                        const float4* mrow = mid + (first_y + ky) * MS;
-#pragma unroll
-                        for (int kx = 0; kx < SB; ++kx) {
-                            const float4 g = mrow[col[kx]];
-                            const float w = hy->w[ky] * hx.w[kx];
-                            acc01 = __builtin_elementwise_fma(v2f{w, w}, v2f{g.x, g.y}, acc01);
-                            acc2 = fmaf(w, g.z, acc2);
-                        }
-                    }
-                res[0] = acc01.x; res[1] = acc01.y; res[2] = acc2;
-            } else {
-                res[0] = res[1] = res[2] = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < SB; ++ky)
-                    if (ky < n_y) {
-                        const float4* mrow = mid + (first_y + ky) * MS;
-#pragma unroll
-                        for (int kx = 0; kx < SB; ++kx) {
-                            const float4 g = mrow[col[kx]];
-                            res[0] = hit_accumulate<false>(res[0], g.x, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
-                            res[1] = hit_accumulate<false>(res[1], g.y, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
-                            res[2] = hit_accumulate<false>(res[2], g.z, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
-                        }
-                    }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (QUADS) keep[c][slot] = res[c];
-                else *reinterpret_cast<float*>(gxp[c] + out) = res[c];
-                asum[c] += fabsf(res[c]);
-            }
-        }
-    }
-    if (QUADS) {
-        // 16-byte stores: the tile goes through LDS (the window `mid` is dead once every wave is past stage B), planar
-        __syncthreads();
-        float* stage = reinterpret_cast<float*>(mid);                    // [3][kDimLaneRows][64]
-        if (lane < twc) {
-#pragma unroll
-            for (int i = 0; i < kDimLaneRows / 4; ++i)
-                if (wave + 4 * i < th)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) stage[(c * kDimLaneRows + wave + 4 * i) * 64 + lane] = keep[c][i];
-        }
-        __syncthreads();
-        const int c4 = static_cast<int>(threadIdx.x & 15u) * 4;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int r = static_cast<int>(threadIdx.x >> 4) + 16 * half;
-                if (r < th && c4 < twc)
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(gxp[c]) + static_cast<int64_t>(iy0 + r) * size + ix0 + c4) =
-                        *reinterpret_cast<const float4*>(stage + (c * kDimLaneRows + r) * 64 + c4);
-            }
-    }
-    // three workgroup sums in block_sum's order (wave butterflies, then the waves in index order)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = wave_sum(asum[c]);
-        if (lane == 0) red[c][wave] = v;
-    }
-    __syncthreads();
-    if (ws != nullptr && threadIdx.x < 3) {
-        const int c = static_cast<int>(threadIdx.x);
-        float total = red[c][0];
-#pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) total += red[c][w];
-        ws[(static_cast<int64_t>(image) * 3 + c) * tiles + t] = total;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // PreprocessingModel with a Resize (reference: transferattack/utils.py:50-53, 72-79 -- Inception-v3: 224 -> 299, mean = std =
@@ -1009,10 +703,9 @@ static int max_hits(int in_size, int out_size) {
 
 static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
     if (size <= 0 || resize <= 0) return 0;
-    if (size >= 4 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const double up = static_cast<double>(resize) / size;
-        int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
-        if (size % 4 == 0 && tw >= 12) tw &= ~3;             // as ta_dim_bwd: tiles that start on 16-byte boundaries
+        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
         if (tw >= 8 && rows <= 68) return ceil_div(size, tw) * ceil_div(size, kDimLaneRows);
     }
@@ -1032,9 +725,7 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double ratio = static_cast<double>(resize) / size;
-        int tw = static_cast<int>(fmin(64.0, floor(61.0 / ratio) + 1.0));              // window <= (tw-1)*ratio + 3 <= 64
-        const bool quads = size % 4 == 0 && tw >= 12 && aligned16(y);                  // tiles start and end on 16-byte boundaries
-        if (quads) tw &= ~3;
+        const int tw = static_cast<int>(fmin(64.0, floor(61.0 / ratio) + 1.0));        // window <= (tw-1)*ratio + 3 <= 64
         const int rows = static_cast<int>(ceil((kDimLaneRows - 1) * ratio)) + 4;       // window rows + 1 row of x
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
@@ -1043,11 +734,12 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-#define TA_DIM_FWD(RPW, PAIRS, QUADS) hipLaunchKernelGGL((dim_fwd_lanes_kernel<RPW, PAIRS, QUADS>), grid, dim3(kBlock), 0, st, x, y, \
-                                                         size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y)
-            if (rows <= 40) { if (quads) TA_DIM_FWD(10, true, true); else if (size >= 2) TA_DIM_FWD(10, true, false); else TA_DIM_FWD(10, false, false); }
-            else { if (quads) TA_DIM_FWD(17, true, true); else if (size >= 2) TA_DIM_FWD(17, true, false); else TA_DIM_FWD(17, false, false); }
-#undef TA_DIM_FWD
+            if (rows <= 40)
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, tw, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -1070,40 +762,18 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // lane-per-column gather: resize > size, resize <= 1.5 * size and < 2^28 elements per plane (the choice depends on
-    // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives); size >= 4: a
-    // lane's run of up to 3 output columns is one wide load that must fit a row
-    if (size >= 4 && resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
+    // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives)
+    if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
         const double up = static_cast<double>(resize) / size;                          // bound for rnd / size
-        int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));                 // window <= (tw + 1) * up + 1 <= 64
-        if (size % 4 == 0 && tw >= 12) tw &= ~3;                                       // (the same rule in ta_dim_bwd_tiles)
-        const bool quads = size % 4 == 0 && tw % 4 == 0 && aligned16(gx);
+        const int tw = static_cast<int>(fmin(64.0, floor(63.0 / up) - 1.0));           // window <= (tw + 1) * up + 1 <= 64
         const int rows = static_cast<int>(ceil((kDimLaneRows + 1) * up)) + 1;
         if (tw >= 8 && rows <= 68) {
             const int tiles_x = static_cast<int>(ceil_div(size, tw)), tiles_y = static_cast<int>(ceil_div(size, kDimLaneRows));
             // the three planes of an RGB image share one workgroup's hit tables (a quarter of the backward's instructions)
             // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
             const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
-            // three planes per LANE (dim_bwd_rgb_kernel) wherever three planes per workgroup paid; TA_DIM_BWD_RGB = 1 forces
-            // it for any multiple of three planes (tests), 0 keeps the one-plane-at-a-time kernel
-            const char* rgb_env = getenv("TA_DIM_BWD_RGB");
-            const bool rgb = planes % 3 == 0 && (rgb_env == nullptr ? pp == 3 : atoi(rgb_env) != 0);
-            if (rgb) {
-                const dim3 rgb_grid(static_cast<unsigned>(planes / 3 * tiles_x * tiles_y));
-                const bool three_b = max_hits(size, rnd) <= 3, two_a = max_hits(resize, size) <= 2;
-#define TA_DIM_RGB_Q(RPW, SB, SA, Q)                                                                                     \
-    hipLaunchKernelGGL((dim_bwd_rgb_kernel<RPW, SB, SA, Q>), rgb_grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, \
-                       left, scale1, scale2, tw, tiles_x, tiles_y)
-#define TA_DIM_RGB(RPW, SB, SA) do { if (quads) TA_DIM_RGB_Q(RPW, SB, SA, true); else TA_DIM_RGB_Q(RPW, SB, SA, false); } while (0)
-#define TA_DIM_RGB_A(RPW, SB) do { if (two_a) TA_DIM_RGB(RPW, SB, 2); else TA_DIM_RGB(RPW, SB, 3); } while (0)
-                if (rows <= 40) { if (three_b) TA_DIM_RGB_A(10, 3); else TA_DIM_RGB_A(10, 4); }
-                else { if (three_b) TA_DIM_RGB_A(17, 3); else TA_DIM_RGB_A(17, 4); }
-#undef TA_DIM_RGB_A
-#undef TA_DIM_RGB
-#undef TA_DIM_RGB_Q
-                return check_launch("dim_bwd_rgb");
-            }
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
