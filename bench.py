@@ -30,9 +30,15 @@ One JSON line on rank 0, with
                 launch durations, measured with HIP events on the launch stream inside the timed region -- events bound
                 to the kernels' own dispatch packets (ta_timing_begin / ta_timing_end; ``roofline.clock``), with the
                 hipEventRecord-marker clock of the same launches beside it (``roofline.marker_clock``); peak 8 TB/s
-                (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).
-  cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores,
-                same surrogate / workload, bounded sample.
+                (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).  The same launches are priced two more
+                ways: ``frac_at_24B_contract`` (SURVEY 8(d)'s 24 B/element and nothing else, steady-state launches) and
+                ``executed`` (the bytes the kernel requests: with the byte source -- images are PNG-decoded bytes, the
+                update reads 1 B instead of 4 B per element of x -- 25 instead of 28 B/element; ``traffic`` prices them
+                with the committed PMC passes, profiles/pmc_update_kernel.json).
+  cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores: 32 images (the
+                reference's batch), all K=10 iterations, at the best of a thread sweep from 8 to every hardware thread
+                (``cores`` = physical cores, ``threads_used``, ``thread_sweep_images_per_s``); kind "reference" where
+                /root/reference exists (the build container), "port" on the GPU box.
 """
 import argparse
 import json

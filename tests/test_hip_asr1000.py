@@ -70,7 +70,8 @@ def product_attack(name, nets, fold_bn=False, channels_last=False):
             if fold_bn:
                 backbones.fold_batchnorm(backbone)
             w = wrap_model(backbone.eval().to(DEV))
-            wrapped.append(w.to(memory_format=torch.channels_last) if channels_last else w)
+            from transferattack_amd.attack import takes_channels_last          # Attack.load_model's own rule (not Inception, not VGG)
+            wrapped.append(w.to(memory_format=torch.channels_last) if channels_last and takes_channels_last(backbone) else w)
         return wrapped[0] if len(wrapped) == 1 else EnsembleModel(wrapped)
 
     return type("Gpu" + base.__name__, (base,), {"load_model": load_model})(model_name="injected")
@@ -206,13 +207,16 @@ def test_asr1000_dts_resnet50(tag, arrangement):
 
 def test_asr_ens_four_members():
     """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
-    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here)."""
+    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here), in the arrangement
+    ``bench.py --attack ens`` runs: BatchNorm folded, ResNet-50 through the fused glue with ReLU pass bits, NHWC for ResNet /
+    ViT only (attack.takes_channels_last), the 299-pixel member behind the resize + Normalize kernel, every member on its own
+    HIP stream.  (The reference-literal arrangement of these members is what test_config5_ensemble_replay pins.)"""
     g = fixture("ens")
-    x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(), g)
+    x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(fold_bn=True, channels_last=True), g)
     print("\nconfigs[4]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the reference "
           "%.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
     assert agree >= 0.99
-    check_rates("configs[4] ensemble MI-FGSM / RN50 + VGG-16 + Inc-v3 + ViT-B/16", "reference-literal surrogates", g, x, label, adv)
+    check_rates("configs[4] ensemble MI-FGSM / RN50 + VGG-16 + Inc-v3 + ViT-B/16", "the bench arrangement", g, x, label, adv)
 
 
 def test_asr_vmifgsm_vit():

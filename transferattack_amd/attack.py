@@ -42,6 +42,16 @@ class _AdvInput(torch.autograd.Function):
         return g, None
 
 
+def takes_channels_last(backbone):
+    """Which surrogates the opt-in NHWC arrangement (``TA_CHANNELS_LAST=1``) applies to: not Inception-v3 (ROCm 7.2's NHWC
+    fp32 backward-data kernels fault on its 1x7 / 7x1 convolutions) and, unless ``TA_VGG_CHANNELS_LAST=1``, not the VGGs
+    (input gradient 2-4x further from the fp64 truth for +8 % throughput)."""
+    name = backbone.__class__.__name__
+    if "Inc" in name:
+        return False
+    return not ("VGG" in name.upper() and os.environ.get("TA_VGG_CHANNELS_LAST", "0") != "1")
+
+
 class Attack(object):
     """Base class for all attacks (same constructor as transferattack/attack.py:12-38)."""
 
@@ -86,9 +96,7 @@ class Attack(object):
             # (profiles/r01/ens_diag/vgg_nhwc.txt) for an input gradient 2-4x further from the fp64 truth (4.4e-3 -> up to
             # 1.75e-2 on the seeded VGG-16; GPUTEST_r03: 13 un-normalised conv + ReLU stages amplify the other
             # accumulation order of MIOpen's NHWC kernels) is not a trade a parity-first engine makes by default
-            name = model.__class__.__name__
-            if os.environ.get("TA_CHANNELS_LAST", "0") == "1" and "Inc" not in name and not (
-                    "VGG" in name.upper() and os.environ.get("TA_VGG_CHANNELS_LAST", "0") != "1"):
+            if os.environ.get("TA_CHANNELS_LAST", "0") == "1" and takes_channels_last(model):
                 wrapped = wrapped.to(memory_format=torch.channels_last)
             return wrapped
 
