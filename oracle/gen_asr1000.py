@@ -5,8 +5,8 @@ Run in the build container only (needs /root/reference):
     python oracle/gen_asr1000.py mifgsm          # configs[1]: MI-FGSM on ResNet-50, ~30 min on 8 cores
     python oracle/gen_asr1000.py dts             # configs[2]: DIM + TIM + SIM on ResNet-50, 5 copies, ~2.5 h
     python oracle/gen_asr1000.py ens             # configs[4]: ensemble MI-FGSM (RN50 + VGG-16 + Inc-v3 + ViT-B/16), ~1 h
-    python oracle/gen_asr1000.py vmifgsm         # configs[3]: VMI-FGSM on ViT-B/16, 20 neighbours, first 640 images (210 surrogate
-                                                 # evaluations per batch, ~11 min each: the full set takes 6 h of CPU time)
+    python oracle/gen_asr1000.py vmifgsm         # configs[3]: VMI-FGSM on ViT-B/16, 20 neighbours (210 surrogate evaluations per
+                                                 # batch, ~12 min each on 8 cores: ~6.5 h for the set; resumable)
 
 What it does, following /root/reference/main.py line by line with synthetic data in place of the ImageNet subset:
 

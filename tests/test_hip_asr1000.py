@@ -220,8 +220,8 @@ def test_asr_ens_four_members():
 
 
 def test_asr_vmifgsm_vit():
-    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 640 images of the set (20 reference
-    batches = 4200 surrogate evaluations of 32 images: ~4 h of reference CPU time).  The neighbours come from different
+    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the 1000-image set (32 reference batches =
+    6720 surrogate evaluations of 32 images: ~6.5 h of reference CPU time for the fixture).  The neighbours come from different
     generators on the two paths (torch's CPU generator in the reference run, the in-kernel Philox stream here) -- as they would
     between any two runs of the reference itself, which seeds nothing."""
     g = fixture("vmifgsm")
