@@ -114,6 +114,9 @@ ens4)
   for b in 32 125; do
   timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
   done ;;
+dimclock)
+  # where a DIM tile's cycles go: per-phase shader-clock cycles of the two lane-per-column kernels (a tuning build of dim.hip)
+  timeout 300 python tools/dim_phase_clock.py 2>&1 | tee $OUT/dim_phase_clock.txt ;;
 benchq)
   # the default line without the CPU leg and the stand-alone sweep; then with the ReLU pass bits off (activations read instead)
   timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick.json

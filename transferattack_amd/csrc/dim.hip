@@ -22,6 +22,27 @@
 
 namespace ta {
 
+// Phase clock (a tuning aid, compiled in only by tools/dim_phase_clock.py with -DTA_DIM_PHASE_CLOCK; libta_hip.so is built
+// without it and these macros vanish): thread 0 of every workgroup of the two lane-per-column kernels adds the shader-clock
+// cycles between consecutive phase boundaries (the barriers) to a device-side table -- where a tile's ~12 000 cycles go.
+#ifdef TA_DIM_PHASE_CLOCK
+__device__ unsigned long long ta_dim_phase_cycles[2][8];
+__device__ unsigned long long ta_dim_phase_groups[2];
+#define TA_PHASE_BEGIN() unsigned long long ta_phase_t = clock64()
+#define TA_PHASE(kernel, phase)                                                       \
+    do {                                                                              \
+        if (threadIdx.x == 0) {                                                       \
+            const unsigned long long ta_phase_now = clock64();                        \
+            atomicAdd(&ta_dim_phase_cycles[kernel][phase], ta_phase_now - ta_phase_t); \
+            if ((phase) == 0) atomicAdd(&ta_dim_phase_groups[kernel], 1ull);           \
+            ta_phase_t = ta_phase_now;                                                \
+        }                                                                             \
+    } while (0)
+#else
+#define TA_PHASE_BEGIN() do { } while (0)
+#define TA_PHASE(kernel, phase) do { } while (0)
+#endif
+
 struct Tap {
     int i0, i1;
     float l0, l1;
@@ -131,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
                                                                float scale1, float scale2, int tw, int tiles_x,
                                                                int tiles_y) {
     constexpr int ROWS = 4 * RPW;
+    TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
     __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
     __shared__ int corner[2];                                          // px_lo, px_hi
@@ -156,6 +178,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     if (threadIdx.x == 64) corner[0] = tx2.i0;                         // lane 0 of wave 1
     if (threadIdx.x == 64 + twc - 1) corner[1] = tx2.i1;
     __syncthreads();
+    TA_PHASE(0, 0);
     const int py_lo = ty2[0].i0, py_hi = ty2[th - 1].i1, px_lo = corner[0], px_hi = corner[1];
     const int mh = py_hi - py_lo + 1, mw = px_hi - px_lo + 1;          // <= ROWS - 1, <= 64 (host-checked)
     const int p_a = max(top - py_lo, 0), p_b = min(top + rnd - 1 - py_lo, mh - 1);   // window rows inside the image
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         if (p >= p_a && p <= p_b) ty1[p] = make_tap_scaled(py_lo + p - top, size, scale1);
     }
     __syncthreads();
+    TA_PHASE(0, 1);
     const bool any_rows = p_a <= p_b;
     const int sr_lo = any_rows ? ty1[p_a].i0 : 0;
     const int sh = any_rows ? ty1[p_b].i1 - sr_lo + 1 : 0;             // <= ROWS
@@ -196,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         for (int i = 0; i < RPW; ++i) out[i * 256] = fmaf(tx1.l0, a[i], tx1.l1 * b[i]);
     }
     __syncthreads();
+    TA_PHASE(0, 2);
     // -- V1: mid[p][c] = fma(ly0, T[i0][c], ly1 * T[i1][c]) inside the rescaled image, 0 in the padding (dim.py:65)
     {
         const float* Tc = T + lane - sr_lo * 64;
@@ -212,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         }
     }
     __syncthreads();
+    TA_PHASE(0, 3);
     // -- H2: u[p][ox] = fma(lx0, mid[p][i0], lx1 * mid[p][i1])      (u overwrites T: every lane is past V1)
     float* u = T;
     if (lane < twc) {
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
             if (wave + 4 * i < mh) out[i * 256] = fmaf(tx2.l0, m0[i * 256], tx2.l1 * m1[i * 256]);
     }
     __syncthreads();
+    TA_PHASE(0, 4);
     // -- V2: y[oy][ox] = fma(ly0, u[i0][ox], ly1 * u[i1][ox])
     if (lane < twc) {
         const float* uc = u + lane - py_lo * 64;
@@ -237,6 +264,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
             }
         }
     }
+    TA_PHASE(0, 5);
 }
 
 // --------------------------------------------------------------------------------------- backward
@@ -447,6 +475,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
                                                                float scale1, float scale2, int tw, int tiles_x,
                                                                int tiles_y) {
     constexpr int ROWS = 4 * RPW;
+    TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
     __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
     __shared__ __attribute__((aligned(16))) Hit colA[64];               // window column px -> output columns
@@ -468,6 +497,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     if (wave == 0 && lane < twc) colB[lane] = find_hits(ix0 + lane, size, rnd, scale1);
     if (wave == 1 && lane < th) rowB[lane] = find_hits(iy0 + lane, size, rnd, scale1);
     __syncthreads();
+    TA_PHASE(1, 0);
     const int rx_lo = colB[0].first, rx_hi = colB[twc - 1].first + colB[twc - 1].n - 1;
     const int ry_lo = rowB[0].first, ry_hi = rowB[th - 1].first + rowB[th - 1].n - 1;
     const int mw = rx_hi - rx_lo + 1, mh = ry_hi - ry_lo + 1;           // <= 64, <= ROWS (host-checked)
@@ -478,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
         if (p >= 0 && p < mh) rowA[p] = find_hits(ry_lo + p + top, resize, size, scale2);
     }
     __syncthreads();
+    TA_PHASE(1, 1);
 
 #pragma unroll 1
     for (int q = 0; q < PP; ++q) {
@@ -542,6 +573,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
         }
     }
     __syncthreads();
+    TA_PHASE(1, 2);
     // -- stage B: gx[iy][ix]
     float asum = 0.0f;
     Hit hx = colB[lane < twc ? lane : 0];
@@ -583,8 +615,10 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
             asum += fabsf(acc);
         }
     }
+    TA_PHASE(1, 3);
     const float total = block_sum(asum, red);             // (its barriers also fence `mid` for the next plane)
     if (ws != nullptr && threadIdx.x == 0) ws[plane * tiles + t] = total;
+    TA_PHASE(1, 4);
     }   // planes of the group
 }
 
@@ -842,3 +876,16 @@ extern "C" int ta_resize_normalize_bwd(const float* gy, float* gx, const float* 
                        static_cast<hipStream_t>(stream), gy, gx, stdv, ws, c, in_size, out_size, scale, tiles_x, tiles_y);
     return check_launch("resize_normalize_bwd");
 }
+
+#ifdef TA_DIM_PHASE_CLOCK
+// cycles[kernel][phase] (kernel 0 = dim_fwd_lanes, 1 = dim_bwd_lanes) summed over the workgroups since the last call, and the
+// number of workgroups; resets the table.  tools/dim_phase_clock.py only.
+extern "C" int ta_dim_phase_clock_read(unsigned long long* cycles16, unsigned long long* groups2) {
+    if (hipError_t err = hipDeviceSynchronize()) return static_cast<int>(err);
+    if (hipError_t err = hipMemcpyFromSymbol(cycles16, HIP_SYMBOL(ta::ta_dim_phase_cycles), sizeof(unsigned long long) * 16)) return static_cast<int>(err);
+    if (hipError_t err = hipMemcpyFromSymbol(groups2, HIP_SYMBOL(ta::ta_dim_phase_groups), sizeof(unsigned long long) * 2)) return static_cast<int>(err);
+    unsigned long long zeros[16] = {0};
+    if (hipError_t err = hipMemcpyToSymbol(HIP_SYMBOL(ta::ta_dim_phase_cycles), zeros, sizeof(unsigned long long) * 16)) return static_cast<int>(err);
+    return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(ta::ta_dim_phase_groups), zeros, sizeof(unsigned long long) * 2));
+}
+#endif
