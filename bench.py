@@ -112,6 +112,37 @@ def kernel_sweep(sizes=(32, 125, 250), reps=30):
         torch.cuda.synchronize()
         us = start.elapsed_time(end) * 1e3 / reps
         out["n%d_k1_k2" % n] = {"us": round(us, 2), "GBps": round(BYTES_PER_ELEM * e * n / us / 1e3, 1)}
+        # the steady-state launch of the loop (|g| sums handed over, x + delta written: 28 B/element algorithmic) by the
+        # dispatch clock, with the fp32 image operand and with the byte source, same cold operands
+        try:
+            xa = torch.empty_like(sets[0][0])
+            for tag, byte_valued in (("fp32_source", False), ("byte_source", True)):
+                srcs = []
+                for k in range(4):
+                    if byte_valued:             # float(byte) / 255 with the IEEE quotient's bits, built on the device
+                        xb = (torch.randint(0, 256, sets[k][3].shape, device="cuda", dtype=torch.uint8).double() / 255).float()
+                        sets[k] = sets[k][:3] + (xb.contiguous(),)
+                        srcs.append(_hip.u8_source_probe(sets[k][3]))
+                    else:
+                        srcs.append(None)
+                _hip.timing_begin(reps + 8)
+                for i in range(reps):
+                    g, m, d, x = sets[i % 4]
+                    _hip.abs_sum_partials(g)
+                    _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa, data_u8=srcs[i % 4])
+                torch.cuda.synchronize()
+                ms = _hip.timing_end()[5:]                                  # the first launches warm the instruction cache
+                us = 1e3 * sum(ms) / len(ms)
+                taken = (not byte_valued) or all(int(s_[1].item()) == 0 for s_ in srcs)
+                out["n%d_k2_steady_%s" % (n, tag)] = {"us": round(us, 2), "GBps_at_28B": round(28 * e * n / us / 1e3, 1),
+                                                      "frac_of_8TBps": round(28 * e * n / us / 1e3 / HBM_PEAK_GBS, 4),
+                                                      "bytes_read_by_the_kernel": bool(taken and byte_valued)}
+        except Exception as exc:  # noqa: BLE001  -- a diagnostic: never at the expense of the line
+            out["n%d_k2_steady_error" % n] = repr(exc)[:160]
+            try:
+                _hip.timing_end()                                           # leave no timing session armed behind
+            except Exception:  # noqa: BLE001
+                pass
         del sets
     return out
 
