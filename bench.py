@@ -229,8 +229,10 @@ def physical_cores():
 def cpu_baseline(args):
     """The reference's CPU path on this host's cores: ``cpu_images`` images (default 32, the reference's batch,
     main.py:15) through ALL K=10 iterations (one surrogate forward/backward + the 13-kernel update stack each), at the
-    best of a thread sweep from 8 up to every hardware thread of the host (one iteration per count).  A slow host (one
-    iteration > 6 s) gets a proportionally shorter timed run, scaled to K=10 and said so in ``sample``.
+    best of a thread sweep from 8 towards every hardware thread of the host (one iteration per count; the sweep stops at the
+    first count whose warm-up iteration takes over 3x the best count's -- beyond the optimum ATen's intra-op parallelism only
+    loses on a 32-image batch: the complete sweep to 256 threads is on record in profiles/r04/bench_default_b125_r4e.json).
+    A slow host (one iteration > 6 s) gets a proportionally shorter timed run, scaled to K=10 and said so in ``sample``.
     kind "reference": the reference's OWN ``Attack.forward`` (imported from /root/reference through oracle/ref_shim.py --
     only where that tree exists, i.e. the build container); kind "port": the oracle (oracle/fgsm_oracle.py, the same ATen
     ops in the same order) -- what runs on the GPU box."""
@@ -264,7 +266,13 @@ def cpu_baseline(args):
         if time.time() - t_sweep > budget_s:
             break
         torch.set_num_threads(th)
+        t0 = time.time()
         run(1)                                                         # warm-up at this count
+        if best[0] < float("inf") and time.time() - t0 > 3 * best[0]:
+            # more threads only make it slower from here (r4b / r4e on 2 x EPYC 9575F: 16 threads 2.6 images/s, 64: 1.2, 128:
+            # 0.5, 256: 0.04 -- the last probe alone took three minutes); the full sweep is on record in profiles/r04
+            sweep[th] = "skipped: warm-up %.1f s, over 3x the best count's iteration" % (time.time() - t0)
+            break
         t0 = time.time()
         run(1)
         dt1 = time.time() - t0
