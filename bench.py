@@ -24,17 +24,18 @@ on N = k*4 GPUs puts one surrogate per rank of a 4-rank model group (configs[4])
 path (logits forward, input gradient backward) run over RCCL, images shard over the k groups.
 
 One JSON line on rank 0, with
-  roofline      the fused momentum-sign-project update (ta_mi_update): algorithmic bytes of every launch -- 4 B/element
-                per operand it actually moves: read g, m, delta, x, write m, delta = 24; first iteration (no momentum
-                yet) 20; +4 when it also writes x + delta for the next iteration -- summed over the launches / summed
-                launch durations, measured with HIP events on the launch stream inside the timed region -- events bound
-                to the kernels' own dispatch packets (ta_timing_begin / ta_timing_end; ``roofline.clock``), with the
-                hipEventRecord-marker clock of the same launches beside it (``roofline.marker_clock``); peak 8 TB/s
-                (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).  The same launches are priced two more
-                ways: ``frac_at_24B_contract`` (SURVEY 8(d)'s 24 B/element and nothing else, steady-state launches) and
-                ``executed`` (the bytes the kernel requests: with the byte source -- images are PNG-decoded bytes, the
-                update reads 1 B instead of 4 B per element of x -- 25 instead of 28 B/element; ``traffic`` prices them
-                with the committed PMC passes, profiles/pmc_update_kernel.json).
+  roofline      the fused momentum-sign-project update (ta_mi_update_std / ta_mi_update).  ``achieved`` / ``frac``: the bytes
+                every launch's kernel instantiation REQUESTS -- 4 B per fp32 operand read or written, 1 B per element of the
+                image when it comes from the byte source (images are PNG-decoded bytes): 21 B/element in the steady state of
+                the default loop (read gy, m, delta, the image byte; write m, delta), 17 on the first iteration (no momentum
+                yet) -- summed over the launches / summed launch durations, measured with HIP events on the launch stream
+                inside the timed region: events bound to the kernels' own dispatch packets (ta_timing_begin /
+                ta_timing_end; ``roofline.clock``), the hipEventRecord-marker clock of the same launches beside it
+                (``roofline.marker_clock``); peak 8 TB/s (MI355X_MICROARCH.md; 6.29 TB/s is what a float4 copy reaches).
+                ``frac_at_24B_contract``: the steady-state launches at SURVEY 8(d)'s algorithmic 24 B/element (read g, m,
+                delta, x; write m, delta -- what the launch does, since round 5 it stores no x + delta);
+                ``frac_algorithmic``: every operand priced as fp32; ``traffic``: the committed PMC passes
+                (profiles/pmc_update_kernel.json) priced per launch.
   cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores: 32 images (the
                 reference's batch), all K=10 iterations, at the best of a thread sweep from 8 to every hardware thread
                 (``cores`` = physical cores, ``threads_used``, ``thread_sweep_images_per_s``); kind "reference" where
@@ -137,6 +138,19 @@ def kernel_sweep(sizes=(32, 125, 250), reps=30):
                 out["n%d_k2_steady_%s" % (n, tag)] = {"us": round(us, 2), "GBps_at_28B": round(28 * e * n / us / 1e3, 1),
                                                       "frac_of_8TBps": round(28 * e * n / us / 1e3 / HBM_PEAK_GBS, 4),
                                                       "bytes_read_by_the_kernel": bool(taken and byte_valued)}
+            # round 5: the std form (gy / std[c] inline, no x_adv store), sums handed over as the stem kernel hands them
+            std = torch.tensor([0.229, 0.224, 0.225], device="cuda")
+            _hip.timing_begin(reps + 8)
+            for i in range(reps):
+                g, m, d, x = sets[i % 4]
+                _hip.abs_sum_partials_std(g, std)
+                _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, data_u8=srcs[i % 4], std=std)
+            torch.cuda.synchronize()
+            ms = _hip.timing_end()[5:]
+            us = 1e3 * sum(ms) / len(ms)
+            out["n%d_k2_std_steady_byte_source" % n] = {"us": round(us, 2), "executed_GBps_at_21B": round(21 * e * n / us / 1e3, 1),
+                                                        "frac_executed": round(21 * e * n / us / 1e3 / HBM_PEAK_GBS, 4),
+                                                        "frac_at_24B_contract": round(24 * e * n / us / 1e3 / HBM_PEAK_GBS, 4)}
         except Exception as exc:  # noqa: BLE001  -- a diagnostic: never at the expense of the line
             out["n%d_k2_steady_error" % n] = repr(exc)[:160]
             try:
@@ -408,7 +422,13 @@ def over_ranks(dt, rate, world, dev):
 
 
 def roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken=False):
-    """The fused update's launches of the timed region -> the ``roofline`` object (module docstring)."""
+    """The fused update's launches of the timed region -> the ``roofline`` object (module docstring).
+
+    ``achieved`` / ``frac`` price every launch with the bytes its kernel instantiation REQUESTS (round 5; the PMC passes
+    agree to 0.1 %): 4 B per fp32 operand it reads or writes, 1 B per element of the image when the byte source is taken.
+    ``frac_at_24B_contract`` prices the steady-state launches with SURVEY 8(d)'s algorithmic figure for the update -- 24 B
+    per element: read g, m, delta, x, write m, delta -- which is exactly what a steady-state launch does now that it stores
+    no x + delta (executed: 21, the image operand being a byte)."""
     # two clocks over the same launches: hipEventRecord markers before / after each call (they include the ~3 us the
     # command processor spends between a marker and a dependent kernel) and events bound to the kernels' own dispatch
     # packets (begin of the call's first kernel -> end of the update kernel: what rocprofv3 --kernel-trace reports).
@@ -417,48 +437,51 @@ def roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken=False
     durs_us, clock = marker_us, "hipEventRecord markers around each call"
     if len(dispatch_ms) == len(sink) and all(0.0 < 1e3 * d <= m + 1.0 for d, m in zip(dispatch_ms, marker_us)):
         durs_us, clock = [1e3 * d for d in dispatch_ms], "HIP events bound to the kernels' dispatch packets"
-    launch_bytes = [rec[2] * rec[3] * rec[4] for rec in sink]
-    mean_us = sum(durs_us) / len(durs_us)
-    mean_bytes = sum(launch_bytes) / len(launch_bytes)
-    achieved = sum(launch_bytes) / sum(durs_us) / 1e3            # GB/s over the launches of the timed region
-    full = [(d, b) for d, b in zip(durs_us, launch_bytes) if b == max(launch_bytes)]
+    algorithmic = [rec[2] * rec[3] * rec[4] for rec in sink]                    # 4 B per operand moved, the image as fp32
+    u8 = [bool(rec[5]) and byte_source_taken for rec in sink]
+    executed = [b - 3 * rec[2] * rec[3] * int(t) for b, rec, t in zip(algorithmic, sink, u8)]
+    contract = [rec[2] * rec[3] * BYTES_PER_ELEM for rec in sink]                 # 24 B/element, nothing else
+    steady = [i for i, b in enumerate(algorithmic) if b == max(algorithmic)]
+    k1 = _hip.stats["k1_passes"]
+    if k1:                                       # a K1 pass inside a call re-reads g: 4 B/element more are requested by it
+        executed = [b + 4.0 * rec[2] * rec[3] * min(1.0, k1 / len(sink)) for b, rec in zip(executed, sink)]
+    total_us = sum(durs_us)
+    achieved = sum(executed) / total_us / 1e3                                   # GB/s over the launches of the timed region
+    std_form = sum(1 for rec in sink if len(rec) > 6 and rec[6])
     pmc = committed_pmc_traffic(sink, _hip)
-    # bytes the launches EXECUTE: with the byte source (ta_mi_update_u8; the probe's device flag said "byte-valued", checked
-    # by the caller after the run) the image operand costs 1 B instead of 4 B per element
-    u8 = [len(rec) > 5 and rec[5] and byte_source_taken for rec in sink]
-    executed = [b - 3 * rec[2] * rec[3] * int(t) for b, rec, t in zip(launch_bytes, sink, u8)]
-    contract = [rec[2] * rec[3] * BYTES_PER_ELEM for rec in sink]       # 24 B/element, nothing else counted
-    steady = [i for i, b in enumerate(launch_bytes) if b == max(launch_bytes)]
-    return {"bound": "hbm", "kernel": ("ta_mi_update (mi_update_kernel; |g| tile sums left by the kernel "
-                                       "that produced g)" if _hip.stats["k1_passes"] == 0 else
-                                       "ta_mi_update (abs_sum_partials_kernel + mi_update_kernel)"),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+    st_us = sum(durs_us[i] for i in steady)
+    return {"bound": "hbm",
+            "kernel": ("ta_mi_update_std" if std_form == len(sink) else "ta_mi_update") + (
+                " (mi_update_kernel; |g| tile sums left by the kernel that produced g)" if k1 == 0 else
+                " (abs_sum_partials_kernel + mi_update_kernel)"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "bytes": "executed: what the kernel instantiation of each launch requests (4 B per fp32 operand, 1 B per element "
+                     "of the image from the byte source)",
             # NOT measured by this run (rocprofv3 cannot count from inside bench.py): the committed PMC passes over this
             # kernel (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction), priced per launch; the source is named
             "traffic": pmc["bytes_per_launch"] if pmc else None,
             "traffic_source": pmc["source"] if pmc else None,
             "clock": clock if timing_note is None else clock + " (dispatch clock unavailable: %s)" % timing_note,
             "marker_clock": {"mean_us": round(sum(marker_us) / len(marker_us), 2),
-                             "frac": round(sum(launch_bytes) / sum(marker_us) / 1e3 / HBM_PEAK_GBS, 4)},
-            "launches": len(durs_us), "mean_us": round(mean_us, 2), "min_us": round(min(durs_us), 2),
-            "algorithmic_bytes_per_launch": int(mean_bytes),
-            "steady_state_launch": {"bytes": int(max(launch_bytes)),
-                                    "mean_us": round(sum(d for d, _ in full) / len(full), 2),
-                                    "GBps": round(sum(b for _, b in full) / sum(d for d, _ in full) / 1e3, 1)},
-            "k1_pass_skipped_launches": _hip.stats["partials_reused"],
-            "k1_passes": _hip.stats["k1_passes"],
+                             "frac": round(sum(executed) / sum(marker_us) / 1e3 / HBM_PEAK_GBS, 4)},
+            "launches": len(durs_us), "std_form_launches": std_form, "byte_source_launches": sum(u8),
+            "mean_us": round(total_us / len(durs_us), 2), "min_us": round(min(durs_us), 2),
+            "executed_bytes_per_launch": int(sum(executed) / len(executed)),
+            "algorithmic_bytes_per_launch": int(sum(algorithmic) / len(algorithmic)),
+            "steady_state_launch": {"executed_bytes": int(sum(executed[i] for i in steady) / len(steady)),
+                                    "algorithmic_bytes": int(max(algorithmic)),
+                                    "mean_us": round(st_us / len(steady), 2),
+                                    "executed_GBps": round(sum(executed[i] for i in steady) / st_us / 1e3, 1)},
+            "k1_pass_skipped_launches": _hip.stats["partials_reused"], "k1_passes": k1,
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4),
-            # the same launches priced three ways.  ``frac`` above: the algorithmic bytes of what each launch does (24 B
-            # per element for the update of SURVEY 8(d), -4 without a momentum to read, +4 when it also writes x + delta:
-            # the add of attack.py:88 that the reference runs as a 12-B pass).  ``frac_at_24B_contract``: 24 B per element
-            # and nothing else, steady-state launches only (the x + delta write is then unpaid work).  ``executed``: the
-            # bytes the kernel really requests -- with the byte source 1 B instead of 4 B for the image operand.
-            "frac_at_24B_contract": round(sum(contract[i] for i in steady) / sum(durs_us[i] for i in steady) / 1e3 / HBM_PEAK_GBS, 4),
+            # SURVEY 8(d)'s contract: 24 B per element and nothing else over the steady-state launches
+            "frac_at_24B_contract": round(sum(contract[i] for i in steady) / st_us / 1e3 / HBM_PEAK_GBS, 4),
+            # every operand as fp32 (what the same launches would move without the byte source)
+            "frac_algorithmic": round(sum(algorithmic) / total_us / 1e3 / HBM_PEAK_GBS, 4),
+            # kept for readers of earlier rounds' lines: identical to achieved / frac since round 5
             "executed": {"byte_source_launches": sum(u8), "bytes_per_launch": int(sum(executed) / len(executed)),
-                         "GBps": round(sum(executed) / sum(durs_us) / 1e3, 1),
-                         "frac": round(sum(executed) / sum(durs_us) / 1e3 / HBM_PEAK_GBS, 4),
-                         "frac_of_measured_copy_peak_6290": round(sum(executed) / sum(durs_us) / 1e3 / 6290.0, 4)}}
+                         "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}}
 
 
 def byte_source_taken(batches):
@@ -486,15 +509,16 @@ def committed_pmc_traffic(sink, _hip):
         if "mi_update_kernel<" not in name:
             continue
         flags = [f.strip() for f in name[name.index("<") + 1:name.rindex(">")].split(",")]
-        # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV[, X_U8]>
-        key = tuple(f == "true" for f in flags[4:8]) + (len(flags) > 8 and flags[8] == "true",)
+        # <VEC, BLOCK, SLOTS, NT, HAS_V, HAS_MIN, HAS_MOUT, HAS_XADV[, X_U8[, G_STD]]>
+        key = tuple(f == "true" for f in flags[4:8]) + (len(flags) > 8 and flags[8] == "true", len(flags) > 9 and flags[9] == "true")
         per_shape[key] = c["fetch_B_per_elem_corrected"] + c["write_B_per_elem"]
     k1 = next((c["fetch_B_per_elem_corrected"] for name, c in kernels.items() if "abs_sum_partials" in name), 4.0)
     total, priced = 0.0, 0
     for rec in sink:
         n_l, e_l, b_l = rec[2], rec[3], rec[4]
         # bytes/element -> which operands moved: 12 (g, d, x read; d written... ) + 4 each for m_in, m_out, x_adv
-        shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k[:4])) == b_l and not k[0] and k[4] == (len(rec) > 5 and bool(rec[5]))]
+        shapes = [k for k, v in per_shape.items() if 4 * (4 + sum(k[:4])) == b_l and not k[0]
+                  and k[4] == (len(rec) > 5 and bool(rec[5])) and k[5] == (len(rec) > 6 and bool(rec[6]))]
         if shapes:
             total += per_shape[shapes[0]] * n_l * e_l
             priced += 1
@@ -588,6 +612,9 @@ def main(argv=None):
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
                                       args.image_size, args.image_size, args.batch, layout),
                        "byte_source": os.environ.get("TA_U8_SOURCE", "1") != "0",
+                       # the surrogate's Normalize folded into the two HIP kernels either side of the backbone
+                       # (attack.py::_forward_normalize_folded): no x + delta store, no gx = gy / std store
+                       "normalize_folded": os.environ.get("TA_FOLD_NORMALIZE", "1") != "0",
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "parallelism": layout, "gpus_requested": args.gpus, "ranks_observed": observed_world,
                        "collective_backend": backend, "images_per_s_per_rank": per_rank},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 8
+#define TA_ABI_VERSION 9
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -102,6 +102,24 @@ int ta_u8_source_probe(const float* x, uint8_t* x_u8, int* mismatch, int64_t num
 int ta_mi_update_u8(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
                     const float* x, const uint8_t* x_u8, const int* u8_mismatch, float* x_adv, float* ws,
                     int ws_slots, float decay, float alpha, float eps, int64_t n, int64_t e, void* stream);
+/* The surrogate's Normalize folded into both ends of an iteration (round 5) -- for the loops in which nothing but
+ * PreprocessingModel's Normalize (transferattack/utils.py:72-79) sits between `data + delta` (attack.py:88) and the backbone:
+ *   ta_normalize_adv_fwd     y = ((x + d) - mean[c]) / std[c]: the add of attack.py:88 and the Normalize in one pass, x taken
+ *                            from the byte source when (x_u8, u8_mismatch) are given and the flag is 0 (both nullable together);
+ *                            the fused update then has no x + d' to store: 24 B/element algorithmic, 21 executed.
+ *   ta_mi_update_std         ta_mi_update[_u8] whose gradient operand is gy = d(loss)/d(normalised input), the backbone's own
+ *                            output; the kernel forms attack.py:118-122's gradient gy / std[c] inline (the division of
+ *                            Normalize's backward), so no pass stores it.  ws_slots > 0: ws holds ws_slots sums of
+ *                            |gy / std[c]| per image (ta_stem7s2_input_grad leaves them); ws_slots == 0: a sum-only pass
+ *                            over gy runs first (ta_abs_sum_partials_std; ws = scratch as for ta_mi_update).  e = c * hw.
+ *                            Same rounding points as ta_normalize_bwd + ta_mi_update: same bits.
+ *   ta_abs_sum_partials_std  K1 over gy / std[c]: ta_normalize_bwd's sums (bit for bit) without its store. */
+int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
+                         const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream);
+int ta_mi_update_std(const float* gy, const float* stdv, const float* m_in, float* m_out, float* delta, const float* x,
+                     const uint8_t* x_u8, const int* u8_mismatch, float* ws, int ws_slots, float decay, float alpha,
+                     float eps, int64_t n, int c, int64_t hw, void* stream);
+int ta_abs_sum_partials_std(const float* gy, const float* stdv, float* ws, int64_t n, int c, int64_t hw, void* stream);
 /* PreprocessingModel's Normalize (transferattack/utils.py:72-79, torchvision Normalize): y = (x - mean[c]) / std[c]
  * over [n, c, hw]; mean/std: device fp32 [c].  Backward gx = gy / std[c] (the last kernel of the surrogate's
  * backward, i.e. the producer of the gradient) also writes the |gx| tile sums to ws in K1's layout. */
@@ -242,7 +260,11 @@ int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64_t* idx, co
  *   ta_stem7s2_prepare      w [64,3,7,7] (dense NCHW) -> w2 (16384 floats, device): once per model
  *   ta_stem7s2_input_grad   dy channels_last [n, oh, ow, 64] -> dx NCHW [n, 3, 2*oh, 2*ow] */
 int ta_stem7s2_prepare(const float* w, float* w2, void* stream);
-int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, int64_t n, int oh, int ow, void* stream);
+/* stdv / ws (nullable together): the kernel also writes n * ta_stem_tiles(oh, ow) sums of |dx / stdv[c]| to ws -- one per
+ * workgroup, ta_stem_tiles consecutive per image, fixed order -- the layout ta_mi_update_std takes through `ws_slots` */
+int64_t ta_stem_tiles(int oh, int ow);
+int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh, int ow,
+                          void* stream);
 
 /* ---- output: save_images  transferattack/utils.py:63-66 (+ main.py:53 add) ---------------------------
  * u8[n,h,w,c] = trunc((x + d) * 255)   NCHW fp32 -> NHWC uint8 */

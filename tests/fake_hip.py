@@ -45,10 +45,14 @@ def u8_source_probe(data):
     return u8, torch.tensor([0 if exact else 1], dtype=torch.int32)
 
 
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None):
-    calls.append("mi_update")
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None,
+              std=None):
+    calls.append("mi_update" if std is None else "mi_update_std")
     if data_u8 is not None and int(data_u8[1]) == 0:            # the byte source stands for exactly these floats
         assert torch.equal(data_u8[0].float() / 255, data)
+    if std is not None:                                         # Normalize's backward folded into the update
+        assert variance is None and x_adv is None
+        grad = grad / std.view(1, -1, 1, 1)
     g = grad if variance is None else grad + variance
     m = O.momentum_step(g, 0 if momentum_in is None else momentum_in, decay)
     d = O.delta_step(delta, data, m, alpha, epsilon)
@@ -158,6 +162,13 @@ def axpy(x, m, coeff, out):
     out.copy_(x + coeff * m)
 
 
+def normalize_adv_fwd(data, delta, y, mean, std, data_u8=None):
+    calls.append("normalize_adv_fwd")
+    if data_u8 is not None and int(data_u8[1]) == 0:
+        assert torch.equal(data_u8[0].float() / 255, data)
+    y.copy_(((data + delta) - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
+
+
 def normalize_fwd(x, y, mean, std):
     calls.append("normalize_fwd")
     y.copy_((x - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1))
@@ -246,7 +257,7 @@ def sia_bwd(gy, plan, x, gx, copies, num_block, noise_radius, seed=0, offset=0, 
 _NAMES = ["sia_fwd", "sia_bwd", "bsr_fwd", "bsr_bwd", "sum_members", "momentum", "update_delta_linf", "update_delta_l2", "mi_update", "u8_source_probe", "init_delta_uniform",
           "depthwise_conv2d_same", "dim_fwd", "dim_bwd", "scale_copies_fwd", "scale_copies_bwd", "sum_copies_bwd", "admix_fwd",
           "admix_bwd", "vmi_neighbor", "grad_accumulate", "variance_finalize", "axpy", "quantize_u8_nhwc", "normalize_fwd",
-          "normalize_bwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate", "resize_normalize_fwd", "resize_normalize_bwd"]
+          "normalize_bwd", "normalize_adv_fwd", "vmi_neighbor_normalized", "normalize_bwd_accumulate", "resize_normalize_fwd", "resize_normalize_bwd"]
 
 
 def _fft_spectrum_view(x, noise, mask):

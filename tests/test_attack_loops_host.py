@@ -34,6 +34,15 @@ def _subset(cases, keep):
 
 
 test_config1_trajectory_replay = A.test_config1_trajectory_replay
+
+
+@pytest.mark.parametrize("name,backbone,kw", [("mifgsm", "toy_cnn", dict(epoch=4)), ("ifgsm", "toy_cnn", dict(epoch=3)),
+                                               ("mifgsm", "toy_cnn", dict(epoch=3, random_start=True))])
+def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw):
+    A.test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
+
+
+test_normalize_folded_loop_fused_resnet = A.test_normalize_folded_loop_fused_resnet
 test_variants_run = A.test_variants_run_on_gpu
 
 

@@ -96,9 +96,13 @@ def run_config(config, name, arrangement, g):
     atk = product_attack(name, nets, **arrangement)
     first = []
     k = int(g["sign_images"])
-    if name == "vmifgsm":
+    folded_plain = (name != "vmifgsm" and atk._can_fuse_update()
+                    and atk._normalize_chain(x[:1].to(DEV).contiguous()) is not None)
+    if name == "vmifgsm" or folded_plain:
         # the folded VMI loop never calls get_grad (gradient/vmifgsm.py): its own first-iteration gradient -- normalize_fwd,
-        # the surrogate, normalize_bwd inside _forward_folded -- is taken through the loop's probe hook
+        # the surrogate, normalize_bwd inside _forward_folded -- is taken through the loop's probe hook; so is the gradient of
+        # the plain loop with the surrogate's Normalize folded into its two ends (attack.py::_forward_normalize_folded), which
+        # patching get_grad would switch off
         def probe(it, grad):
             if it == 0 and not first:
                 first.append(grad.detach().clone())

@@ -196,6 +196,59 @@ def test_variants_run_on_gpu(golden):
     assert float(d.flatten(1).norm(dim=1).max()) <= 3.0 * (1 + 1e-5)
 
 
+def _loop(monkeypatch, fold, name, backbone=None, model_name=None, n=3, **kw):
+    """one attack loop on seeded 224-pixel images with the surrogate's Normalize folded into the loop's two ends or not"""
+    monkeypatch.setenv("TA_FOLD_NORMALIZE", "1" if fold else "0")
+    x = u8_images(n, 224, 77).float() / 255
+    label = torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(78))
+    if model_name is not None:                                   # through Attack.load_model (the bench's arrangement)
+        atk = ta.load_attack_class(name)(model_name=model_name, **kw)
+    else:
+        atk = make(name, [backbones.create(backbone, seed=5, verbose=False)], **kw)
+    torch.manual_seed(99)                                        # the random start's CPU draws (noise_source)
+    stats = dict(_hip.stats)
+    delta = atk(x, label).cpu()
+    return delta, {k: _hip.stats[k] - stats[k] for k in stats}
+
+
+@pytest.mark.parametrize("name,backbone,kw", [("mifgsm", "toy_cnn", dict(epoch=4)), ("ifgsm", "toy_cnn", dict(epoch=3)),
+                                               ("fgsm", "toy_cnn", {}), ("mifgsm", "toy_cnn", dict(epoch=3, random_start=True)),
+                                               ("mifgsm", "vit_tiny_patch16_224", dict(epoch=3))])
+def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw):
+    """attack.py::_forward_normalize_folded (ta_normalize_adv_fwd -> backbone -> ta_mi_update_std) against the hook-by-hook
+    loop (add, Normalize, backbone, Normalize backward with its |g| sums, ta_mi_update with x_adv): the same rounding points,
+    and with the sums taken by K1 in ta_normalize_bwd's order the same bits -- the final delta is EQUAL wherever the surrogate
+    itself is run-to-run deterministic (measured by running the hook loop twice; else the folded loop may differ from it no
+    more than it differs from itself)."""
+    plain, st0 = _loop(monkeypatch, False, name, backbone, **kw)
+    again, _ = _loop(monkeypatch, False, name, backbone, **kw)
+    folded, st1 = _loop(monkeypatch, True, name, backbone, **kw)
+    k = kw.get("epoch", 1 if name == "fgsm" else 10)
+    assert st0["std_form_launches"] == 0 and st1["std_form_launches"] == k
+    assert float(folded.abs().max()) > 0 and float(folded.abs().max()) <= EPS + 1e-7
+    noise = float((plain != again).float().mean())
+    diff = float((plain != folded).float().mean())
+    print("%s / %s: folded vs hook loop differ in %.5f%% of the elements (hook loop vs itself: %.5f%%)" % (name, backbone, 100 * diff, 100 * noise))
+    assert diff <= 3 * noise + (0.0 if noise == 0.0 else 1e-4)
+
+
+def test_normalize_folded_loop_fused_resnet(monkeypatch):
+    """the same with the bench's arrangement (folded BatchNorm, NHWC, fused glue): the stem kernel is the producer of the
+    update's operand and leaves the sums of |gy / std| -- no K1 pass, no Normalize backward pass.  Its sums add in another
+    order than ta_normalize_bwd's, so a momentum within rounding of zero may take the other sign: bounded like the kernel tests."""
+    for k_, v in (("TA_FOLD_BN", "1"), ("TA_CHANNELS_LAST", "1"), ("TA_FUSED_GLUE", "1"), ("TA_STEM_KERNEL", "1"), ("TA_ALLOW_RANDOM_INIT", "1")):
+        monkeypatch.setenv(k_, v)
+    plain, st0 = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=3)
+    again, _ = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=3)
+    folded, st1 = _loop(monkeypatch, True, "mifgsm", model_name="resnet18", n=2, epoch=3)
+    assert st1["std_form_launches"] == 3 and st1["partials_reused"] == 3 and st1["k1_passes"] == 0
+    assert st0["std_form_launches"] == 0 and st0["k1_passes"] == 0
+    noise = float((plain != again).float().mean())
+    diff = float((plain != folded).float().mean())
+    print("fused ResNet-18: folded vs hook loop differ in %.5f%% of the elements (hook loop vs itself: %.5f%%)" % (100 * diff, 100 * noise))
+    assert diff <= 3 * noise + 2e-4
+
+
 @pytest.mark.parametrize("name,n", [("toy_cnn", 4), ("resnet18", 4), ("resnet50", 4)])
 def test_gradient_accuracy_vs_fp64(name, n):
     """How far is the MI355X fp32 input-gradient (MIOpen / rocBLAS) from the exact gradient, compared with how far

@@ -175,6 +175,96 @@ def test_byte_source_of_the_fused_update():
         assert int(_hip.u8_source_probe(z)[1].item()) == 1
 
 
+@pytest.mark.parametrize("shape", [(4, 3, 224, 224), (125, 3, 224, 224), (3, 3, 37, 41), (2, 1, 5, 7), (2, 4, 6, 6)])
+def test_normalize_folded_update(shape):
+    """The surrogate's Normalize (utils.py:72-79) folded into both ends of an iteration (round 5):
+      ta_normalize_adv_fwd == the add of attack.py:88 (as the fused update's x_adv) followed by ta_normalize_fwd,
+      ta_abs_sum_partials_std + ta_mi_update_std == ta_normalize_bwd + ta_mi_update[_u8],
+    BIT FOR BIT -- y, the |g| sums, momentum and delta -- for the first iteration, the steady state and decay 0, with the fp32
+    and the byte source, at sizes that take the vector / streaming / scalar forms (hw % 4 != 0: scalar)."""
+    if DEV == "cpu" and shape[0] > 8:
+        pytest.skip("batch-size case: device only")
+    gen = torch.Generator().manual_seed(sum(shape))
+    n, c = shape[0], shape[1]
+    xb = torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8)
+    x = (xb.float() / 255).to(DEV)
+    mean = torch.tensor([0.485, 0.456, 0.406, 0.5][:c]).to(DEV)
+    std = torch.tensor([0.229, 0.224, 0.225, 0.25][:c]).to(DEV)
+    gy = (torch.randn(shape, generator=gen) * 1e-4).to(DEV)
+    gy.view(-1)[::97] = 0.0                                                 # exact zeros: sign(0) = 0
+    mom = torch.randn(shape, generator=gen).to(DEV)
+    delta = O.box_clamp((torch.randint(-10, 11, shape, generator=gen).float() * ALPHA).clamp(-EPS, EPS), 0 - x.cpu(), 1 - x.cpu()).to(DEV)
+    src = _hip.u8_source_probe(x) if x[0].numel() % 4 == 0 else None
+    # forward end
+    for source in (None, src):
+        xa = torch.empty_like(x)
+        _hip.update_delta_linf(delta, x, torch.zeros_like(x), 0.0, EPS, torch.empty_like(x), x_adv=xa)   # xa = x + delta
+        assert torch.equal(xa, x + delta)
+        y_ref, y = torch.empty_like(x), torch.full_like(x, float("nan"))
+        _hip.normalize_fwd(xa, y_ref, mean, std)
+        _hip.normalize_adv_fwd(x, delta, y, mean, std, data_u8=source)
+        assert torch.equal(y, y_ref)
+    # backward end
+    launches = _hip.stats["std_form_launches"]
+    for m_in, keep in ((mom, True), (None, True), (None, False)):
+        decay = 1.0 if keep else 0.0
+        gx = torch.empty_like(gy)
+        _hip.normalize_bwd(gy, gx, std)
+        ws_ref, slots = _hip.partials_of(gx)
+        d_ref, m_ref = delta.clone(), (torch.empty_like(x) if keep else None)
+        _hip.mi_update(gx, None if m_in is None else m_in.clone(), m_ref, d_ref, x, decay, ALPHA, EPS)
+        for source in (None, src):
+            for handed_over in (True, False):                               # sums left by a producer / K1 inside the call
+                g_in = gy.clone()
+                if handed_over:
+                    ws, s2 = _hip.abs_sum_partials_std(g_in, std)
+                    assert s2 == slots and torch.equal(ws[:n * slots], ws_ref[:n * slots]), "sums of |gy / std| differ from ta_normalize_bwd's"
+                d, m_out = delta.clone(), (torch.empty_like(x) if keep else None)
+                before = _hip.stats["partials_reused"]
+                _hip.mi_update(g_in, None if m_in is None else m_in.clone(), m_out, d, x, decay, ALPHA, EPS, data_u8=source, std=std)
+                assert _hip.stats["partials_reused"] == before + (1 if handed_over else 0)
+                assert torch.equal(d, d_ref) and (m_out is None or torch.equal(m_out, m_ref))
+    assert _hip.stats["std_form_launches"] == launches + 3 * 2 * 2
+    # sums attached for ONE std vector are not taken for another (or for the plain form)
+    g_in = gy.clone()
+    _hip.abs_sum_partials_std(g_in, std)
+    before = _hip.stats["k1_passes"]
+    _hip.mi_update(g_in, mom.clone(), torch.empty_like(x), delta.clone(), x, 1.0, ALPHA, EPS)
+    assert _hip.stats["k1_passes"] == before + 1
+    with pytest.raises(ValueError):
+        _hip.mi_update(gy, None, None, delta.clone(), x, 0.0, ALPHA, EPS, std=std, x_adv=torch.empty_like(x))
+
+
+@pytest.mark.parametrize("n,oh,ow", [(2, 112, 112), (1, 9, 37), (3, 16, 16)])
+def test_stem_kernel_leaves_the_sums(n, oh, ow):
+    """ta_stem7s2_input_grad with (std, ws): the same dx, plus per-workgroup sums of |dx / std[c]| that add up to the image's
+    (fp64 evaluation, summation-order tolerance) -- and ta_mi_update_std with them moves delta as it does with K1's sums"""
+    gen = torch.Generator().manual_seed(n * 100 + ow)
+    w = (torch.randn(64, 3, 7, 7, generator=gen) * 0.05).to(DEV)
+    dy = torch.randn(n, 64, oh, ow, generator=gen).to(DEV).contiguous(memory_format=torch.channels_last)
+    std = torch.tensor([0.229, 0.224, 0.225]).to(DEV)
+    w2 = _hip.stem7s2_prepare(w)
+    plain = _hip.stem7s2_input_grad(dy, w2, torch.full((n, 3, 2 * oh, 2 * ow), float("nan"), device=DEV))
+    assert _hip.partials_of(plain) is None
+    dx = _hip.stem7s2_input_grad(dy, w2, torch.full((n, 3, 2 * oh, 2 * ow), float("nan"), device=DEV), std=std)
+    assert torch.equal(dx, plain)
+    ws, slots = _hip.partials_of(dx)
+    assert slots == -(-ow // 32) * -(-oh // 4)
+    got = ws[:n * slots].double().reshape(n, slots).sum(1).cpu()
+    want = (dx.double() / std.double().view(1, 3, 1, 1)).abs().reshape(n, -1).sum(1).cpu()
+    assert float(((got - want).abs() / want).max()) <= 1e-6
+    x = (torch.randint(0, 256, dx.shape, generator=gen, dtype=torch.uint8).float() / 255).to(DEV)
+    d1, d2 = torch.zeros_like(x), torch.zeros_like(x)
+    m1, m2 = torch.empty_like(x), torch.empty_like(x)
+    before = _hip.stats["partials_reused"]
+    _hip.mi_update(dx, None, m1, d1, x, 1.0, ALPHA, EPS, std=std)            # the stem kernel's sums
+    assert _hip.stats["partials_reused"] == before + 1
+    _hip.mi_update(plain, None, m2, d2, x, 1.0, ALPHA, EPS, std=std)         # K1 inside the call
+    q = (plain / std.view(1, 3, 1, 1)).abs()
+    assert_momentum_close(host(m1), host(m2), host(plain / std.view(1, 3, 1, 1)), None, 1.0)
+    assert_delta_equal(host(d1), host(d2), host(m2))
+
+
 @pytest.mark.parametrize("n,in_size,out_size", [(2, 224, 299), (3, 37, 50), (1, 8, 11), (2, 64, 96), (1, 100, 101)])
 def test_resize_normalize_kernels(n, in_size, out_size):
     """PreprocessingModel with a Resize (utils.py:50-53, 72-79: Inception-v3, 224 -> 299, mean = std = 0.5) as one kernel each

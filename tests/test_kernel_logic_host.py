@@ -48,6 +48,12 @@ test_producer_side_partials_all_kernels = G.test_producer_side_partials_all_kern
 test_sum_members = G.test_sum_members
 test_update_without_momentum = G.test_update_without_momentum
 test_byte_source_of_the_fused_update = G.test_byte_source_of_the_fused_update
+test_normalize_folded_update = G.test_normalize_folded_update
+
+
+@pytest.mark.parametrize("n,oh,ow", [(2, 16, 16), (1, 9, 37)])
+def test_stem_kernel_leaves_the_sums(n, oh, ow):
+    G.test_stem_kernel_leaves_the_sums(n, oh, ow)
 test_resize_normalize_kernels = G.test_resize_normalize_kernels
 
 

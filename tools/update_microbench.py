@@ -61,6 +61,24 @@ def main():
         g, m, d, x, xa, src = bsets[i % 4]
         _hip.abs_sum_partials(g)
         _hip.mi_update(g, None, m, d, x, 1.0, 1.6 / 255, 16 / 255, x_adv=xa, data_u8=src)
+    # round 5: the std form (the gradient operand is gy, divided by std[c] inline; no x_adv store) and the forward end
+    std = torch.tensor([0.229, 0.224, 0.225], device="cuda")
+    mean = torch.tensor([0.485, 0.456, 0.406], device="cuda")
+    for i in range(REPS):                               # steady state (21 B/element executed)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials_std(g, std)
+        _hip.mi_update(g, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, data_u8=src, std=std)
+    for i in range(REPS):                               # first iteration (17 B/element executed)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials_std(g, std)
+        _hip.mi_update(g, None, m, d, x, 1.0, 1.6 / 255, 16 / 255, data_u8=src, std=std)
+    for i in range(REPS):                               # decay 0 (13 B/element executed)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.abs_sum_partials_std(g, std)
+        _hip.mi_update(g, None, None, d, x, 0.0, 1.6 / 255, 16 / 255, data_u8=src, std=std)
+    for i in range(REPS):                               # ta_normalize_adv_fwd with the byte source (5 B in, 4 B out)
+        g, m, d, x, xa, src = bsets[i % 4]
+        _hip.normalize_adv_fwd(x, d, xa, mean, std, data_u8=src)
     torch.cuda.synchronize()
     print("byte source taken by the kernels: %s" % all(int(b[5][1].item()) == 0 for b in bsets))
     print("microbench done N=%d" % N)

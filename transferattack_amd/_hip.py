@@ -40,6 +40,10 @@ SIGNATURES = {
     "ta_mi_update": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_mi_update_u8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_u8_source_probe": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ta_normalize_adv_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_mi_update_std": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _int, _i64, _vp]),
+    "ta_abs_sum_partials_std": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_stem_tiles": (_i64, [_int, _int]),
     "ta_resize_tiles": (_i64, [_int]),
     "ta_resize_normalize_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
     "ta_resize_normalize_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
@@ -52,7 +56,7 @@ SIGNATURES = {
     "ta_dim_fwd": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_dim_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_stem7s2_prepare": (_int, [_vp, _vp, _vp]),
-    "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "ta_bias_act": (_int, [_vp, _vp, _int, _vp, _i64, _int, _i64, _vp]),
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -76,7 +80,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipExtensionError(RuntimeError):
@@ -190,12 +194,20 @@ workspace = Workspace()
 #     modifies a gradient behind torch's back (c10d collectives, dist.py) calls ``invalidate_partials(tensor)``;
 #   * producer and consumer must be on the same stream (the sums are ordered after the producer only there);
 #   * the sums are of |g|, or of |g + variance| for exactly the variance tensor the producer was given (VMI-FGSM).
-_ATTR = "_ta_partials"     # (gradient's _version, ws tensor, sums per image, producer's stream, variance tensor | None, its _version)
-stats = {"partials_reused": 0, "k1_passes": 0, "u8_source_launches": 0}
+#   * the sums are of |g / std[c]| for exactly the std vector the producer was given when the tensor is the gradient with
+#     respect to the NORMALISED input (``mi_update(..., std=...)``: the update divides inline) -- never mixed with plain sums.
+_ATTR = "_ta_partials"     # (gradient's _version, ws tensor, sums per image, producer's stream, variance tensor | None, its _version, std key | None)
+_SCALE_ATTR = "_ta_grad_scale"   # on a surrogate's INPUT tensor: the std vector its consumer will divide the input gradient by
+stats = {"partials_reused": 0, "k1_passes": 0, "u8_source_launches": 0, "std_form_launches": 0}
 
 
-def _register_partials(grad, ws, slots, variance=None):
-    setattr(grad, _ATTR, (grad._version, ws, int(slots), _stream(grad), variance, None if variance is None else variance._version))
+def _std_key(std):
+    return None if std is None else (std.data_ptr(), std.numel(), std._version)
+
+
+def _register_partials(grad, ws, slots, variance=None, std=None):
+    setattr(grad, _ATTR, (grad._version, ws, int(slots), _stream(grad), variance, None if variance is None else variance._version,
+                          _std_key(std)))
 
 
 def partials_of(grad):
@@ -205,13 +217,16 @@ def partials_of(grad):
 
 
 def invalidate_partials(*tensors):
-    """``tensors`` were modified behind torch's back (a collective, a foreign kernel): their sums are stale"""
+    """``tensors`` were modified behind torch's back (a collective, a foreign kernel): their sums -- and, for an image batch,
+    the byte source probed from its old contents (``_ta_u8``, attack.py) -- are stale"""
     for t in tensors:
         if isinstance(t, torch.Tensor):
             t.__dict__.pop(_ATTR, None)
+            t.__dict__.pop("_ta_u8", None)
             base = t._base
             if base is not None:
                 base.__dict__.pop(_ATTR, None)
+                base.__dict__.pop("_ta_u8", None)
 
 
 def _wrote(*tensors):
@@ -219,32 +234,38 @@ def _wrote(*tensors):
     invalidate_partials(*tensors)
 
 
-def _take_partials(grad, variance=None):
+def _take_partials(grad, variance=None, std=None):
     """the sums the producer attached to exactly this gradient (and, if ``variance`` is given, taken of |grad + variance|
-    for exactly that variance tensor); the attribute is consumed either way"""
+    for exactly that variance tensor; if ``std`` is given, of |grad / std[c]| for exactly that std vector); the attribute
+    is consumed either way"""
     entry = grad.__dict__.pop(_ATTR, None)
     if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
         return None                                   # the reference-order sum is never taken from a producer
-    version, ws, slots, stream, var, var_version = entry
+    version, ws, slots, stream, var, var_version, std_key = entry
     same_variance = (var is None and variance is None) or (
         var is not None and variance is not None and var.data_ptr() == variance.data_ptr() and var.shape == variance.shape
         and variance._version == var_version and var._version == var_version)
+    same_variance = same_variance and std_key == _std_key(std)
     if same_variance and grad._version == version and ws.device == grad.device and stream == _stream(grad):
         if os.environ.get("TA_DEBUG_PARTIALS") == "verify":
-            _verify_partials(grad, variance, ws, slots)
+            _verify_partials(grad, variance, ws, slots, std)
         return ws, slots
     if os.environ.get("TA_DEBUG_PARTIALS"):
-        print("partials not reused: version %d vs %d, stream %s vs %s, variance match %s" % (
+        print("partials not reused: version %d vs %d, stream %s vs %s, variance / std match %s" % (
             grad._version, version, stream, _stream(grad), same_variance), flush=True)
     return None
 
 
-def _verify_partials(grad, variance, ws, slots):
+def _verify_partials(grad, variance, ws, slots, std=None):
     """``TA_DEBUG_PARTIALS=verify``: the validity of the attached sums rests on object identity + ``_version``, which a write
     through ``.data``, a dlpack / numpy alias or a foreign kernel does not move.  This debug mode recomputes sum|g (+ v)| per
     image (fp64, one synchronising pass) and refuses sums that are not the gradient's -- run a new attack class under it once."""
     n = grad.shape[0]
-    g = grad.detach().double() if variance is None else grad.detach().double() + variance.detach().double()
+    g = grad.detach().double()
+    if std is not None:
+        g = g / std.detach().double().reshape((1, -1) + (1,) * (g.dim() - 2))
+    if variance is not None:
+        g = g + variance.detach().double()
     want = g.abs().reshape(n, -1).sum(1)
     got = ws[:n * slots].double().reshape(n, slots).sum(1)
     bad = ~((got - want).abs() <= 1e-4 * want.abs() + 1e-30)          # NaN-safe: a NaN sum must meet a NaN sum
@@ -327,30 +348,49 @@ def u8_source_probe(data):
     return u8, flag
 
 
-def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None):
+def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance=None, x_adv=None, data_u8=None,
+              std=None):
     """Fused get_momentum + update_delta; ``delta`` is updated in place, momentum_out may alias momentum_in.
     ``momentum_in`` None = first iteration; ``momentum_out`` None = the momentum is not kept (decay == 0);
     ``x_adv`` (optional) receives data + delta', the next iteration's input; ``data_u8`` (optional) is
     ``u8_source_probe(data)``: the kernel then reads one byte instead of four per element of ``data`` whenever the probe
-    found the batch byte-valued."""
+    found the batch byte-valued.  ``std`` (optional, fp32 [C]): ``grad`` is the gradient with respect to the NORMALISED
+    input -- the backbone's own output -- and the kernel divides it by std[c] inline (Normalize's backward folded in:
+    ``ta_mi_update_std``; no variance term, no ``x_adv`` in that form)."""
     n, e = _batch(grad)
     if profile_sink is not None:
         dev = grad.device
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(dev))
-        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8)
+        _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8, std)
         end.record(torch.cuda.current_stream(dev))
         bytes_per_elem = 4 * (3 + (variance is not None) + (momentum_in is not None) + 1 + (momentum_out is not None)
                               + (x_adv is not None))       # r g,(v),(m),d,x  w (m),d,(x_adv): the ALGORITHMIC bytes
-        profile_sink.append((start, end, n, e, bytes_per_elem, data_u8 is not None))
+        profile_sink.append((start, end, n, e, bytes_per_elem, data_u8 is not None, std is not None))
         return
-    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8)
+    _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8, std)
 
 
-def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8=None):
-    ready = _take_partials(grad, variance)
+def _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8=None, std=None):
+    ready = _take_partials(grad, variance, std)
     stats["partials_reused" if ready is not None else "k1_passes"] += 1
     ws, slots = ready if ready is not None else (workspace.l1(grad, n, e), 0)
+    if std is not None:
+        if variance is not None or x_adv is not None:
+            raise ValueError("the std form of the fused update takes neither a variance term nor an x_adv buffer")
+        c = grad.shape[1]
+        if std.numel() != c or grad.dim() < 2:
+            raise ValueError("std has %d entries for a gradient with %d channels" % (std.numel(), c))
+        u8, flag = data_u8 if data_u8 is not None else (None, None)
+        if u8 is not None and (u8.shape != data.shape or u8.device != data.device):
+            raise ValueError("data_u8 does not belong to data")
+        stats["std_form_launches"] += 1
+        stats["u8_source_launches"] += u8 is not None
+        _call("ta_mi_update_std", grad, _ptr(grad, name="grad"), _ptr(std, name="std"), _ptr(momentum_in, name="momentum"),
+              _ptr(momentum_out, name="momentum_out"), _ptr(delta, name="delta"), _ptr(data, name="data"),
+              _ptr(u8, torch.uint8, name="data_u8"), _ptr(flag, torch.int32, name="mismatch"), _ptr(ws), slots, float(decay),
+              float(alpha), float(epsilon), n, c, e // c)
+        return
     if data_u8 is not None:
         u8, flag = data_u8
         if u8.shape != data.shape or u8.device != data.device:
@@ -376,6 +416,32 @@ def abs_sum_partials(grad, variance=None):
     if variance is None:
         _register_partials(grad, ws, slots)
     return ws, slots
+
+
+def abs_sum_partials_std(grad, std):
+    """K1 over grad / std[c]: (ws, sums per image), registered as the partials of ``grad`` for ``mi_update(..., std=std)``"""
+    n, e = _batch(grad)
+    c = grad.shape[1]
+    slots = load().ta_update_tiles(e)
+    ws = _new_ws(grad, n * slots)
+    _call("ta_abs_sum_partials_std", grad, _ptr(grad, name="grad"), _ptr(std, name="std"), _ptr(ws), n, c, e // c)
+    _register_partials(grad, ws, slots, std=std)
+    return ws, slots
+
+
+def normalize_adv_fwd(data, delta, y, mean, std, data_u8=None):
+    """y = ((data + delta) - mean[c]) / std[c]: the add of attack.py:88 and PreprocessingModel's Normalize in one pass;
+    ``data_u8`` = ``u8_source_probe(data)``: the image is read as bytes when the probe found the batch byte-valued"""
+    n, c = data.shape[0], data.shape[1]
+    u8, flag = data_u8 if data_u8 is not None else (None, None)
+    if u8 is not None and (u8.shape != data.shape or u8.device != data.device):
+        raise ValueError("data_u8 does not belong to data")
+    if mean.numel() != c or std.numel() != c:
+        raise ValueError("mean / std have %d / %d entries for %d channels" % (mean.numel(), std.numel(), c))
+    _wrote(y)
+    _call("ta_normalize_adv_fwd", data, _ptr(data, name="data"), _ptr(u8, torch.uint8, name="data_u8"),
+          _ptr(flag, torch.int32, name="mismatch"), _ptr(delta, name="delta"), _ptr(y, name="y"), _ptr(mean, name="mean"),
+          _ptr(std, name="std"), n, c, data[0, 0].numel())
 
 
 def normalize_fwd(x, y, mean, std):
@@ -663,14 +729,23 @@ def stem7s2_prepare(weight):
     return w2
 
 
-def stem7s2_input_grad(dy, w2, dx):
+def stem7s2_input_grad(dy, w2, dx, std=None):
     """dx [n, 3, 2*oh, 2*ow] (NCHW) = d/d(input) of the 7x7 / stride 2 / padding 3 stem convolution for the output gradient
-    ``dy`` [n, 64, oh, ow] in channels_last memory"""
+    ``dy`` [n, 64, oh, ow] in channels_last memory.  ``std`` (fp32 [3], optional): the consumer will divide dx by std[c]
+    (``mi_update(..., std=std)``) -- the kernel then also leaves the sums of |dx / std[c]| per workgroup and they are attached
+    to ``dx`` as its partials, so the update reads dx exactly once and nothing else does."""
     n, k, oh, ow = dy.shape
     if k != 64 or not dy.is_contiguous(memory_format=torch.channels_last) or tuple(dx.shape) != (n, 3, 2 * oh, 2 * ow):
         raise ValueError("stem7s2_input_grad: dy must be channels_last [n, 64, oh, ow] and dx [n, 3, 2*oh, 2*ow]")
     _wrote(dx)
-    _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), n, oh, ow)
+    if std is not None and std.numel() == 3 and std.dtype == torch.float32 and std.device == dx.device and std.is_contiguous():
+        slots = load().ta_stem_tiles(oh, ow)
+        ws = _new_ws(dx, n * slots)
+        _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), _ptr(std, name="std"),
+              _ptr(ws), n, oh, ow)
+        _register_partials(dx, ws, slots, std=std)
+        return dx
+    _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), None, None, n, oh, ow)
     return dx
 
 

@@ -112,7 +112,10 @@ class _ResNetFn(torch.autograd.Function):
     threshold masks) -- the same tensors autograd would keep for the ReLUs, none of the pre-activation maps"""
 
     @staticmethod
-    def forward(ctx, x, net):
+    def forward(ctx, x, net, grad_scale=None):
+        # grad_scale: the std vector by which the consumer of d(loss)/dx will divide it (the attack loop with the surrogate's
+        # Normalize folded into its update, attack.py) -- the stem kernel then leaves the |dx / std[c]| sums with dx
+        ctx.grad_scale = grad_scale
         bottleneck = hasattr(net.layer1[0], "conv3")
         if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
             x = x.contiguous()
@@ -212,10 +215,10 @@ class _ResNetFn(torch.autograd.Function):
             g_pooled = g + pending
             g_stem = _like(torch.ops.aten.max_pool2d_with_indices_backward(g_pooled, stem, k, st, pd, [1, 1], False, idx), stem)
             _hip.relu_mask(g_stem, stem, g_stem)
-        return _stem_input_grad(net, g_stem, x), None
+        return _stem_input_grad(net, g_stem, x, ctx.grad_scale), None, None
 
 
-def _stem_input_grad(net, g_stem, x):
+def _stem_input_grad(net, g_stem, x, grad_scale=None):
     """d/d(image) through the stem convolution: the 7 x 7 / stride 2 / 3 -> 64 stem of the ResNets on the fp32-MFMA kernel
     (csrc/stem.hip; MIOpen's backward-data spends 7.5 % of a ResNet-50 iteration here), anything else through MIOpen"""
     conv = net.conv1
@@ -226,7 +229,7 @@ def _stem_input_grad(net, g_stem, x):
         if w2 is None or w2.device != conv.weight.device or net._stem_w2_version != conv.weight._version:
             w2 = net._stem_w2 = _hip.stem7s2_prepare(conv.weight)
             net._stem_w2_version = conv.weight._version
-        return _hip.stem7s2_input_grad(g_stem, w2, torch.empty(x.shape, dtype=x.dtype, device=x.device))
+        return _hip.stem7s2_input_grad(g_stem, w2, torch.empty(x.shape, dtype=x.dtype, device=x.device), std=grad_scale)
     return _conv_input_grad(g_stem, x, conv)
 
 
@@ -242,4 +245,4 @@ def _pair(v):
 
 
 def forward(net, x):
-    return _ResNetFn.apply(x, net)
+    return _ResNetFn.apply(x, net, getattr(x, _hip._SCALE_ATTR, None))

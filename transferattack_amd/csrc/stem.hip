@@ -53,8 +53,14 @@ __global__ __launch_bounds__(kBlock) void stem7s2_prepare_kernel(const float* __
     w2[idx] = v;
 }
 
+// SUMS: this kernel is the last writer of the gradient the update consumes, and with the surrogate's Normalize folded into
+// the update (ta_mi_update_std) what it writes IS the update's operand: it then also leaves, per workgroup, the sum of
+// |dx / std[c]| over the elements it stored (fixed order: lane, wave butterfly, waves in index order) -- the per-image
+// sums of |g| that get_momentum's mean needs (attack.py:128), without another pass over dx.
+template <bool SUMS>
 __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float* __restrict__ dy, const float* __restrict__ w2,
-                                                                    float* __restrict__ dx, int oh, int ow) {
+                                                                    float* __restrict__ dx, int oh, int ow,
+                                                                    const float* __restrict__ stdv, float* __restrict__ ws) {
     // 66 640 B of LDS: more than the 64 KB of every pre-gfx950 part -- this library targets MI355X (gfx950, 160 KB per CU)
     // only, as does philox.h's v_mad_u64_u32 path; the Makefile builds nothing else
     static_assert(sizeof(float) * kStemWinRows * kStemWinCols * kStemLd <= 160 * 1024, "dy window exceeds gfx950's LDS");
@@ -104,17 +110,28 @@ __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float*
 
     // -- D[4 * kk + r][col]: position j0 + mt*16 + 4*kk + r of row i0 + wave, column col = (py, px, c)
     const int col = lane & 15, i = i0 + wave;
+    float part = 0.0f;
     if (col < 12 && i < oh) {
         const int c = col % 3, px = (col / 3) & 1, py = col / 6;
         const int h = 2 * oh, wd = 2 * ow;
         float* row = dx + ((static_cast<int64_t>(n) * 3 + c) * h + (2 * i + py)) * wd + px;
+        const float sd = SUMS ? stdv[c] : 1.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = j0 + mt * 16 + 4 * kk + r;
-                if (j < ow) row[2 * j] = acc[mt][r];
+                if (j < ow) {
+                    row[2 * j] = acc[mt][r];
+                    if (SUMS) part += fabsf(acc[mt][r] / sd);
+                }
             }
+    }
+    if (SUMS) {
+        __shared__ float red[kBlock / kWave];
+        const float total = block_sum(part, red);
+        if (threadIdx.x == 0)
+            ws[(static_cast<int64_t>(n) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
     }
 }
 
@@ -128,11 +145,21 @@ extern "C" int ta_stem7s2_prepare(const float* w, float* w2, void* stream) {
     return check_launch("stem7s2_prepare");
 }
 
-extern "C" int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, int64_t n, int oh, int ow, void* stream) {
+extern "C" int64_t ta_stem_tiles(int oh, int ow) {
+    return oh > 0 && ow > 0 ? ceil_div(ow, kStemCols) * ceil_div(oh, kStemRows) : 0;
+}
+
+extern "C" int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh,
+                                     int ow, void* stream) {
     TA_REQUIRE(dy && w2 && dx && aligned16(dy) && aligned16(w2), "null or unaligned pointer");
+    TA_REQUIRE((stdv == nullptr) == (ws == nullptr), "std and the sums' buffer come together");
     TA_REQUIRE(n > 0 && n <= 65535 && oh > 0 && ow > 0 && oh <= 4096 && ow <= 4096, "shape (n=%lld, oh=%d, ow=%d)", (long long)n, oh, ow);
     const dim3 grid(static_cast<unsigned>(ceil_div(ow, kStemCols)), static_cast<unsigned>(ceil_div(oh, kStemRows)),
                     static_cast<unsigned>(n));
-    hipLaunchKernelGGL(stem7s2_input_grad_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), dy, w2, dx, oh, ow);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ws != nullptr)
+        hipLaunchKernelGGL(stem7s2_input_grad_kernel<true>, grid, dim3(kBlock), 0, st, dy, w2, dx, oh, ow, stdv, ws);
+    else
+        hipLaunchKernelGGL(stem7s2_input_grad_kernel<false>, grid, dim3(kBlock), 0, st, dy, w2, dx, oh, ow, stdv, ws);
     return check_launch("stem7s2_input_grad");
 }

@@ -20,11 +20,15 @@ namespace ta {
 // ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
-template <int VEC, bool HAS_V, bool SQUARE>
+// G_STD: g is the gradient with respect to the NORMALISED input (the backbone's own input gradient gy); the sums are of
+// |gy / std[c]| -- what ta_normalize_bwd would have summed while writing gx = gy / std[c] -- in the same per-thread order,
+// so they carry ta_normalize_bwd's bits and the pass that stores gx disappears (ta_mi_update_std divides inline).
+template <int VEC, bool HAS_V, bool SQUARE, bool G_STD = false>
 __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* __restrict__ g,
                                                                   const float* __restrict__ v,
                                                                   float* __restrict__ ws, int64_t e,
-                                                                  int tiles) {
+                                                                  int tiles, const float* __restrict__ stdv = nullptr,
+                                                                  int64_t hw = 1) {
     __shared__ float lds[kBlock / kWave];
     const int64_t img = blockIdx.y;
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
@@ -48,13 +52,19 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
         if (full[u]) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float x = HAS_V ? a[u][k] + b[u][k] : a[u][k];
+                float x = a[u][k];
+                if (G_STD) {
+                    const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+                    x = x / stdv[static_cast<int>((off + k) / hw)];
+                }
+                if (HAS_V) x = x + b[u][k];
                 acc += SQUARE ? x * x : fabsf(x);
             }
         } else if (VEC > 1) {   // ragged end of an image whose size is not a multiple of VEC
             const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
-                const float x = HAS_V ? gi[i] + vi[i] : gi[i];
+                float x = G_STD ? gi[i] / stdv[static_cast<int>(i / hw)] : gi[i];
+                if (HAS_V) x = x + vi[i];
                 acc += SQUARE ? x * x : fabsf(x);
             }
         }
@@ -80,12 +90,16 @@ constexpr int kAtenMaxLdsFloats = 16 * 1024;          // 64 KB of dynamic LDS: l
 template <bool HAS_V>
 __global__ __launch_bounds__(kBlock) void aten_order_abs_sum_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                                     float* __restrict__ ws, int64_t e, int tiles,
-                                                                    int lanes) {
+                                                                    int lanes, const float* __restrict__ stdv = nullptr,
+                                                                    int64_t hw = 1) {
     __shared__ __attribute__((aligned(16))) float aten_lds[kAtenMaxLdsFloats];     // 64 KB; one workgroup per image
     const int64_t img = blockIdx.x;
     const float* gi = g + img * e;
     const float* vi = HAS_V ? v + img * e : nullptr;
-    auto mag = [&](int64_t i) { return fabsf(HAS_V ? gi[i] + vi[i] : gi[i]); };
+    auto mag = [&](int64_t i) {          // stdv: the operand is gy, the gradient is gy / std[c] (ta_mi_update_std)
+        const float gv = stdv != nullptr ? gi[i] / stdv[static_cast<int>(i / hw)] : gi[i];
+        return fabsf(HAS_V ? gv + vi[i] : gv);
+    };
     const int cols = lanes * kAtenIlp;
     const int64_t steps = e / cols;
     const int nb1 = static_cast<int>(steps >> kAtenLevelPower);                  // full level-0 blocks
@@ -177,6 +191,50 @@ __global__ __launch_bounds__(kBlock) void normalize_fwd_kernel(const float* __re
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
                 const int c = static_cast<int>(i / hw);
                 y[img * e + i] = (x[img * e + i] - mean[c]) / stdv[c];
+            }
+        }
+    }
+}
+
+// The first kernel of an iteration when nothing but the surrogate's Normalize sits between `data + delta` (attack.py:88)
+// and the backbone: y = ((x + d) - mean[c]) / std[c] straight from the perturbation and the image -- the image read as the
+// PNG byte it was decoded from when the probe's flag says so (1 B instead of 4 B per element, as in the fused update).  The
+// fused update then no longer stores x + d' for this kernel's sake (28 -> 24 B/element algorithmic, 25 -> 21 executed).
+// Same rounding points as the add of attack.py:88 followed by Normalize: same bits.
+template <int VEC, bool X_U8>
+__global__ __launch_bounds__(kBlock) void normalize_adv_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ x_u8,
+                                                                   const int* __restrict__ u8_mismatch,
+                                                                   const float* __restrict__ delta, float* __restrict__ y,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ stdv, int64_t e, int64_t hw) {
+    static_assert(!X_U8 || VEC == 4, "the byte source is read four at a time");
+    const int64_t img = blockIdx.y;
+    const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
+    constexpr int S = Slots<VEC>::n;
+    const bool bytes = X_U8 && uniform_int(*u8_mismatch) == 0;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+        const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
+        if (off + VEC <= e) {
+            Pack<VEC> a, d, o;
+            d.load(delta + img * e + off);
+            if (X_U8 && bytes) {
+                const uint32_t pb = *reinterpret_cast<const uint32_t*>(x_u8 + img * e + off);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) a[k] = u8_to_unit((pb >> (8 * k)) & 0xffu);
+            } else {
+                a.load(x + img * e + off);
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int c = static_cast<int>((off + k) / hw);
+                o[k] = ((a[k] + d[k]) - mean[c]) / stdv[c];
+            }
+            o.store(y + img * e + off);
+        } else if (VEC > 1) {
+            for (int64_t i = off; i < e && i < off + VEC; ++i) {
+                const int c = static_cast<int>(i / hw);
+                y[img * e + i] = ((x[img * e + i] + delta[img * e + i]) - mean[c]) / stdv[c];
             }
         }
     }
@@ -312,11 +370,19 @@ constexpr int kK2Block = 512;
 // 24 (+4) -- and rebuilds x with the bits of the IEEE division (u8_to_unit).  The flag is read by the kernel itself, so
 // a batch that is NOT byte-valued (any other caller of the plug-in API) silently takes the fp32 operand: same launch,
 // same result, no synchronisation.
-template <int VEC, int BLOCK, int SLOTS, bool NT, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV, bool X_U8 = false>
+//
+// G_STD (round 5): g is gy, the gradient with respect to the NORMALISED input -- what the backbone's backward itself
+// produces -- and the kernel forms the gradient of attack.py:118-122 inline, gy / std[c] (the IEEE division
+// ta_normalize_bwd performed, utils.py:72-79's Normalize backward), so the 8 B/element pass that stored gx = gy / std[c]
+// disappears; ws then holds sums of |gy / std[c]| (ta_stem7s2_input_grad leaves them, or K1 with G_STD).  Same rounding
+// points, same bits as ta_normalize_bwd + ta_mi_update.
+template <int VEC, int BLOCK, int SLOTS, bool NT, bool HAS_V, bool HAS_MIN, bool HAS_MOUT, bool HAS_XADV, bool X_U8 = false,
+          bool G_STD = false>
 __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
     const float* __restrict__ g, const float* __restrict__ v, const float* m_in, float* m_out, float* delta,
     const float* __restrict__ x, float* __restrict__ x_adv, const float* __restrict__ ws, StepParams p, int64_t e,
-    int tiles_ws, const uint8_t* __restrict__ x_u8 = nullptr, const int* __restrict__ u8_mismatch = nullptr) {
+    int tiles_ws, const uint8_t* __restrict__ x_u8 = nullptr, const int* __restrict__ u8_mismatch = nullptr,
+    const float* __restrict__ stdv = nullptr, int hw = 1) {
     constexpr int TILE = BLOCK * VEC * SLOTS;
     static_assert(!X_U8 || VEC == 4, "the byte source is read four at a time");
     const int64_t img = blockIdx.y;
@@ -361,9 +427,12 @@ __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
         const int64_t off = (static_cast<int64_t>(u) * BLOCK + threadIdx.x) * VEC;
         if (full[u]) {
             Pack<VEC> om, od, oa;
+            // G_STD: one channel per 16-byte access (hw % VEC == 0 is the launcher's condition for the vector form)
+            const float sd = G_STD ? stdv[(static_cast<int>(blockIdx.x) * TILE + static_cast<int>(off)) / hw] : 1.0f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float gg = HAS_V ? pg[u][k] + pv[u][k] : pg[u][k];
+                const float g0 = G_STD ? pg[u][k] / sd : pg[u][k];
+                const float gg = HAS_V ? g0 + pv[u][k] : g0;
                 const float q = gg / mean;
                 const float mprev = HAS_MIN ? pm[u][k] : 0.0f;
                 const float mn = mprev * p.decay + q;
@@ -382,7 +451,9 @@ __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
             if (HAS_XADV) oa.store(x_adv + base + off);      // read again by the next kernel: keep cacheable
         } else if (VEC > 1) {
             for (int64_t i = off; i < left && i < off + VEC; ++i) {
-                const float gg = HAS_V ? g[base + i] + v[base + i] : g[base + i];
+                const float g0 = G_STD ? g[base + i] / stdv[static_cast<int>((static_cast<int64_t>(blockIdx.x) * TILE + i) / hw)]
+                                       : g[base + i];
+                const float gg = HAS_V ? g0 + v[base + i] : g0;
                 const float q = gg / mean;
                 const float mprev = HAS_MIN ? m_in[base + i] : 0.0f;
                 const float mn = mprev * p.decay + q;
@@ -550,7 +621,7 @@ static bool vec_ok(int64_t e, std::initializer_list<const void*> ptrs) {
 }
 
 static int launch_partials(const float* g, const float* v, float* ws, int64_t n, int64_t e, bool square,
-                           hipStream_t st, hipEvent_t ev_start = nullptr) {
+                           hipStream_t st, hipEvent_t ev_start = nullptr, const float* stdv = nullptr, int64_t hw = 1) {
     const hipEvent_t no_event = nullptr;
     const int tiles = static_cast<int>(ceil_div(e, kTile));
     if (const int lanes = square ? 0 : aten_sum_lanes()) {
@@ -562,16 +633,26 @@ static int launch_partials(const float* g, const float* v, float* ws, int64_t n,
                    "TA_ATEN_SUM_LANES: images of %lld elements exceed what the reference-order sum stages in LDS", (long long)e);
         if (v)
             TA_LAUNCH_TIMED(aten_order_abs_sum_kernel<true>, dim3(static_cast<unsigned>(n)), dim3(kBlock), st, ev_start,
-                            no_event, g, v, ws, e, tiles, lanes);
+                            no_event, g, v, ws, e, tiles, lanes, stdv, hw);
         else
             TA_LAUNCH_TIMED(aten_order_abs_sum_kernel<false>, dim3(static_cast<unsigned>(n)), dim3(kBlock), st, ev_start,
-                            no_event, g, v, ws, e, tiles, lanes);
+                            no_event, g, v, ws, e, tiles, lanes, stdv, hw);
         return check_launch("aten_order_abs_sum");
     }
     const dim3 grid(tiles, static_cast<unsigned>(n));
-    const bool vec = vec_ok(e, {g, v});
+    const bool vec = vec_ok(e, {g, v}) && hw % kVec == 0;
+    if (stdv != nullptr) {                      // sums of |g / std[c]| (never squared, never with a variance term)
+        if (vec)
+            TA_LAUNCH_TIMED((abs_sum_partials_kernel<4, false, false, true>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws,
+                            e, tiles, stdv, hw);
+        else
+            TA_LAUNCH_TIMED((abs_sum_partials_kernel<1, false, false, true>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws,
+                            e, tiles, stdv, hw);
+        return check_launch("abs_sum_partials (std)");
+    }
 #define TA_K1(VEC, HV, SQ) \
-    TA_LAUNCH_TIMED((abs_sum_partials_kernel<VEC, HV, SQ>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws, e, tiles)
+    TA_LAUNCH_TIMED((abs_sum_partials_kernel<VEC, HV, SQ>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws, e, tiles, \
+                    static_cast<const float*>(nullptr), static_cast<int64_t>(1))
     if (vec) {
         if (square) { TA_K1(4, false, true); }
         else if (v) { TA_K1(4, true, false); }
@@ -739,8 +820,11 @@ extern "C" int ta_normalize_bwd_accumulate(const float* gy, float* acc, const fl
 
 static int mi_update_impl(const float* g, const float* v, const float* m_in, float* m_out, float* delta,
                           const float* x, const uint8_t* x_u8, const int* u8_mismatch, float* x_adv, float* ws, int ws_slots,
-                          float decay, float alpha, float eps, int64_t n, int64_t e, void* stream) {
+                          float decay, float alpha, float eps, int64_t n, int64_t e, void* stream,
+                          const float* stdv = nullptr, int64_t hw = 1) {
     if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(stdv == nullptr || (v == nullptr && x_adv == nullptr && hw > 0 && e % hw == 0 && hw < (1ll << 31) && e < (1ll << 31)),
+               "the std form of the update takes neither a variance term nor an x_adv buffer; e = channels * hw");
     TA_REQUIRE(g && delta && x && ws && ws_slots >= 0, "null pointer");
     TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
     // ws_slots > 0 with a variance term: the producer summed |g + v| (ta_normalize_bwd with v) -- the caller's contract
@@ -749,7 +833,7 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LaunchEvents timed = claim_launch_events();          // null unless ta_timing_begin armed them
     if (ws_slots == 0)
-        if (int rc = launch_partials(g, v, ws, n, e, false, st, timed.start)) return rc;
+        if (int rc = launch_partials(g, v, ws, n, e, false, st, timed.start, stdv, hw)) return rc;
     const hipEvent_t k2_start = ws_slots == 0 ? nullptr : timed.start;
     const int tiles_ws = ws_slots > 0 ? ws_slots : static_cast<int>(ceil_div(e, kTile));
     const StepParams p{decay, alpha, -eps, eps};
@@ -759,12 +843,35 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
     // the byte source: 16-byte aligned floats, 4-byte aligned bytes, whole images of a multiple of 4 elements
     const bool u8 = x_u8 != nullptr && vec && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0;
+    if (stdv != nullptr) {
+        // g = gy / std[c] formed inline.  Vector form: one channel per 16-byte access (hw % 4 == 0)
+        const bool vec_std = vec && hw % kVec == 0;
+        const int ihw = static_cast<int>(hw);
+#define TA_MIS(VEC, BLOCK, SLOTS, NT, HMI, HMO, U8)                                                              \
+    TA_LAUNCH_TIMED((mi_update_kernel<VEC, BLOCK, SLOTS, NT, false, HMI, HMO, false, U8, true>),                  \
+                    dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),      \
+                    dim3(BLOCK), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws, \
+                    x_u8, u8_mismatch, stdv, ihw)
+#define TA_MIS_CASES(VEC, BLOCK, SLOTS, NT, U8)                                    \
+    switch ((m_in ? 2 : 0) | (m_out ? 1 : 0)) {                                     \
+        case 0: TA_MIS(VEC, BLOCK, SLOTS, NT, false, false, U8); break;             \
+        case 1: TA_MIS(VEC, BLOCK, SLOTS, NT, false, true, U8); break;              \
+        case 2: TA_MIS(VEC, BLOCK, SLOTS, NT, true, false, U8); break;              \
+        default: TA_MIS(VEC, BLOCK, SLOTS, NT, true, true, U8); break;              \
+    }
+        if (vec_std && u8) { if (nt) { TA_MIS_CASES(4, kK2Block, 1, true, true) } else { TA_MIS_CASES(4, kK2Block, 1, false, true) } }
+        else if (vec_std) { if (nt) { TA_MIS_CASES(4, kK2Block, 1, true, false) } else { TA_MIS_CASES(4, kK2Block, 1, false, false) } }
+        else { TA_MIS_CASES(1, kBlock, kTile / kBlock, false, false) }
+#undef TA_MIS_CASES
+#undef TA_MIS
+        return check_launch("mi_update (std form)");
+    }
     if (u8) {
 #define TA_MI8(NT, HV, HMI, HMO, HXA)                                                                            \
     TA_LAUNCH_TIMED((mi_update_kernel<4, kK2Block, 1, NT, HV, HMI, HMO, HXA, true>),                             \
                     dim3(static_cast<unsigned>(ceil_div(e, kK2Block * 4)), static_cast<unsigned>(n)),             \
                     dim3(kK2Block), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws, \
-                    x_u8, u8_mismatch)
+                    x_u8, u8_mismatch, static_cast<const float*>(nullptr), 1)
 #define TA_MI8_CASES(NT)                                                  \
     switch (key) {                                                        \
         case 0: TA_MI8(NT, false, false, false, false); break;            \
@@ -793,7 +900,8 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     TA_LAUNCH_TIMED((mi_update_kernel<VEC, BLOCK, SLOTS, NT, HV, HMI, HMO, HXA>),                               \
                     dim3(static_cast<unsigned>(ceil_div(e, BLOCK * VEC * SLOTS)), static_cast<unsigned>(n)),     \
                     dim3(BLOCK), st, k2_start, timed.stop, g, v, m_in, m_out, delta, x, x_adv, ws, p, e, tiles_ws,    \
-                    static_cast<const uint8_t*>(nullptr), static_cast<const int*>(nullptr))
+                    static_cast<const uint8_t*>(nullptr), static_cast<const int*>(nullptr),                      \
+                    static_cast<const float*>(nullptr), 1)
 #define TA_MI_CASES(VEC, BLOCK, SLOTS, NT)                                   \
     switch (key) {                                                           \
         case 0: TA_MI(VEC, BLOCK, SLOTS, NT, false, false, false, false); break; \
@@ -832,6 +940,39 @@ extern "C" int ta_mi_update_u8(const float* g, const float* v, const float* m_in
                                int ws_slots, float decay, float alpha, float eps, int64_t n, int64_t e, void* stream) {
     TA_REQUIRE(x_u8 && u8_mismatch, "null byte source (use ta_mi_update)");
     return mi_update_impl(g, v, m_in, m_out, delta, x, x_u8, u8_mismatch, x_adv, ws, ws_slots, decay, alpha, eps, n, e, stream);
+}
+
+extern "C" int ta_mi_update_std(const float* gy, const float* stdv, const float* m_in, float* m_out, float* delta, const float* x,
+                                const uint8_t* x_u8, const int* u8_mismatch, float* ws, int ws_slots, float decay, float alpha,
+                                float eps, int64_t n, int c, int64_t hw, void* stream) {
+    TA_REQUIRE(stdv && c > 0 && hw > 0, "null std or empty planes");
+    return mi_update_impl(gy, nullptr, m_in, m_out, delta, x, x_u8, u8_mismatch, nullptr, ws, ws_slots, decay, alpha, eps, n,
+                          static_cast<int64_t>(c) * hw, stream, stdv, hw);
+}
+
+extern "C" int ta_abs_sum_partials_std(const float* gy, const float* stdv, float* ws, int64_t n, int c, int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(gy && stdv && ws && c > 0 && hw > 0, "null pointer");
+    return launch_partials(gy, nullptr, ws, n, e, false, static_cast<hipStream_t>(stream), nullptr, stdv, hw);
+}
+
+extern "C" int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
+                                    const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(x && delta && y && mean && stdv && c > 0, "null pointer");
+    TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
+    const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = vec_ok(e, {x, delta, y});
+    if (vec && x_u8 != nullptr && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0)
+        hipLaunchKernelGGL((normalize_adv_fwd_kernel<4, true>), grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, e, hw);
+    else if (vec)
+        hipLaunchKernelGGL((normalize_adv_fwd_kernel<4, false>), grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, e, hw);
+    else
+        hipLaunchKernelGGL((normalize_adv_fwd_kernel<1, false>), grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, e, hw);
+    return check_launch("normalize_adv_fwd");
 }
 
 // x_u8[i] = round(x[i] * 255) and *mismatch |= (float(x_u8[i]) / 255 != x[i]) -- the caller zeroes *mismatch first
