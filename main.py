@@ -62,6 +62,11 @@ def get_parser():
 
 def main():
     args = get_parser()
+    # convolution algorithms: MIOpen's immediate mode by default (a heuristic pick per layer, only the chosen solver is built --
+    # a fresh box starts in seconds); TA_CONV_TUNE=1 = torch.backends.cudnn.benchmark: every applicable solver is built and
+    # timed once per (layer, batch) -- minutes on a fresh box, faster steady state (tools/cold_start.py has both)
+    if os.environ.get("TA_CONV_TUNE", "0") == "1":
+        torch.backends.cudnn.benchmark = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.GPU_ID)

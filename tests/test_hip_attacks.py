@@ -336,6 +336,58 @@ def test_main_cli_roundtrip(tmp_path, monkeypatch):
         backbones.create("resnet18", verbose=False)
 
 
+def test_deterministic_mode_writes_identical_pngs(tmp_path):
+    """TA_DETERMINISTIC=1 (attack.py::deterministic_mode): two separate processes running configs[1]'s attack (MI-FGSM,
+    ResNet-50, K=10) on one 32-image reference batch in bench.py's arrangement write byte-identical PNGs -- the reference's
+    contract is "final uint8 bit-exact" (utils.py:63-66), and without the switch MIOpen's atomics make the same command differ
+    from itself in ~0.3 % of the gradient signs (test_fused_surrogate_path_on_device prints the figure).  Also printed: what
+    the switch costs in images/s at this batch."""
+    import csv
+    import subprocess
+    import sys
+    import time
+    from PIL import Image
+    inp = tmp_path / "data"
+    (inp / "images").mkdir(parents=True)
+    xu8 = u8_images(32, 224, 12).permute(0, 2, 3, 1).numpy()
+    with open(inp / "labels.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["filename", "label", "targeted_label"])
+        for i in range(32):
+            Image.fromarray(xu8[i]).save(inp / "images" / ("%02d.png" % i))
+            w.writerow(["%02d.png" % i, (37 * i) % 1000, (37 * i + 1) % 1000])
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, TA_FOLD_BN="1", TA_CHANNELS_LAST="1", TA_ALLOW_RANDOM_INIT="1", PYTHONPATH=root)
+
+    def run(tag, deterministic):
+        out = tmp_path / tag
+        env = dict(base, TA_DETERMINISTIC="1" if deterministic else "0")
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(root, "main.py"), "--input_dir", str(inp), "--output_dir", str(out),
+                            "--attack", "mifgsm", "--model", "resnet50", "--batchsize", "32", "--profile"], env=env,
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))}, time.perf_counter() - t0, r.stdout
+
+    first, t1, _ = run("det1", True)
+    second, t2, log2 = run("det2", True)
+    assert len(first) == 32 and first.keys() == second.keys()
+    differing = [f for f in first if first[f] != second[f]]
+    loose1, _, _ = run("plain1", False)
+    loose2, t4, log4 = run("plain2", False)
+    px = lambda blobs, f: np.array(Image.open(__import__("io").BytesIO(blobs[f])))       # noqa: E731
+    noise = float(np.mean([np.mean(px(loose1, f) != px(loose2, f)) for f in loose1]))
+    moved = float(np.mean([np.mean(px(first, f) != px(loose1, f)) for f in first]))
+    grab = lambda log: [ln for ln in log.splitlines() if ln.startswith("{")][-1][:300] if "{" in log else ""   # noqa: E731
+    print("TA_DETERMINISTIC=1: %d of 32 PNGs differ between two processes (asserted 0); without it two processes differ in "
+          "%.4f%% of the uint8 values; deterministic vs default algorithms: %.4f%% of the values; process wall %.1f s (first, "
+          "incl. MIOpen kernel builds) / %.1f s deterministic, %.1f s default\n  deterministic: %s\n  default: %s"
+          % (len(differing), 100 * noise, 100 * moved, t1, t2, t4, grab(log2), grab(log4)))
+    assert not differing, differing[:5]
+    assert any(first[f] != open(inp / "images" / f, "rb").read() for f in first)       # it did attack
+
+
 def test_main_cli_resume(tmp_path, monkeypatch):
     """--resume: an interrupted run (outputs of one batch missing) recomputes exactly the missing batch, and what it
     writes equals the uninterrupted run (per-batch seeding)"""

@@ -152,6 +152,17 @@ timpmc)
   ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/$OUT/timpmc -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/timpmc.log 2>&1 )
   python tools/pmc_kernels.py $OUT/timpmc | tee $OUT/timpmc_summary.txt
   find $OUT -name "*.db" -delete ;;
+newtests5)
+  # round 5: the Normalize folded into both ends of the plain loop (ta_normalize_adv_fwd / ta_mi_update_std / stem sums)
+  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider \
+      -k "test_hip_kernels or normalize_folded or stem_input_grad" 2>&1 | grep -v Warning | tee $OUT/newtests5_pytest.txt | tail -25 ;;
+det)
+  # TA_DETERMINISTIC=1: two processes write identical PNGs; what the switch costs on the bench line
+  timeout 1500 python -m pytest tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider -k "deterministic_mode" 2>&1 | grep -v Warning | tee $OUT/det_pytest.txt | tail -12
+  TA_DETERMINISTIC=1 timeout 900 python bench.py --steps 4 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_deterministic.json ;;
+coldstart)
+  timeout 1500 python tools/cold_start.py --modes ${TA_COLD_MODES:-immediate,immediate:warm,fast,fast:warm} --keep $OUT/miopen 2> $OUT/cold_start.err | tee $OUT/cold_start.jsonl
+  du -sh $OUT/miopen/* 2>/dev/null ;;
 esac
 done
 du -sh $OUT

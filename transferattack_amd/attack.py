@@ -52,12 +52,33 @@ def takes_channels_last(backbone):
     return not ("VGG" in name.upper() and os.environ.get("TA_VGG_CHANNELS_LAST", "0") != "1")
 
 
+def deterministic_mode():
+    """``TA_DETERMINISTIC=1``: the same command on the same GPU writes the same bytes.  The reference's contract is "final uint8
+    bit-exact" (utils.py:63-66); on the CPU it reproduces itself, on a GPU the libraries' default algorithms do not -- MIOpen's
+    backward-data solvers and ATen's max-pool backward accumulate with atomics, rocBLAS may split K with them.  This switch
+    (read when an attack is constructed) asks every library for its deterministic algorithms:
+      * ``torch.backends.cudnn.deterministic``: PyTorch-ROCm then sets MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC on every
+        convolution descriptor -- MIOpen's find / immediate mode skip the solvers that use atomics;
+      * ``torch.use_deterministic_algorithms(True, warn_only=True)``: rocBLAS / hipBLASLt atomics off, ATen's deterministic
+        variants where they exist (an op without one warns instead of raising);
+    this package's own kernels never use floating-point atomics (include/ta_hip.h).  What remains outside: ATen's max-pool
+    backward on the plain module path of a CNN surrogate -- the fused ResNet path (folded BatchNorm + NHWC, bench.py's
+    arrangement) replaces it by the gather kernel ``ta_maxpool_bwd_relu``; that arrangement is the one
+    ``tests/test_hip_attacks.py::test_deterministic_mode_writes_identical_pngs`` pins.  Returns whether the mode is on."""
+    if os.environ.get("TA_DETERMINISTIC", "0") != "1":
+        return False
+    torch.backends.cudnn.deterministic = True
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    return True
+
+
 class Attack(object):
     """Base class for all attacks (same constructor as transferattack/attack.py:12-38)."""
 
     def __init__(self, attack, model_name, epsilon, targeted, random_start, norm, loss, device=None):
         if norm not in ['l2', 'linfty']:
             raise Exception("Unsupported norm {}".format(norm))
+        deterministic_mode()
         self.attack = attack
         self.model = self.load_model(model_name)
         self.epsilon = epsilon
