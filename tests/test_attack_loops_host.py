@@ -43,6 +43,12 @@ def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
 
 
 test_normalize_folded_loop_fused_resnet = A.test_normalize_folded_loop_fused_resnet
+
+
+@pytest.mark.parametrize("tag,fold_bn,channels_last,fold_normalize", A.CONDITIONED_ARRANGEMENTS)
+def test_gradient_within_1e5_on_conditioned_resnet50(golden, monkeypatch, tag, fold_bn, channels_last, fold_normalize):
+    """the GPU tier's a5 test through the kernels' host build (ATen's CPU convolutions on both sides)"""
+    A.test_gradient_within_1e5_on_conditioned_resnet50(golden, monkeypatch, tag, fold_bn, channels_last, fold_normalize)
 test_variants_run = A.test_variants_run_on_gpu
 
 
