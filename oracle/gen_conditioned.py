@@ -15,7 +15,7 @@ L2) from the fp64 evaluation of the same network.  Two mechanisms, both removed 
      The stem's max-pool has the same kind of discontinuity (two candidates of a window within rounding of each other);
      biases cannot separate those, so the windows whose top two candidates are closer than TIE are LISTED in the fixture and
      the input pixels their re-routed gradient could reach (an 11 x 11 patch each) are excluded from the comparison.
-The fixture stores only the bias moves (26 560 floats) on top of ``backbones.create("resnet50", seed)``, the tie list, the
+The fixture stores only the bias moves (22 720 floats) on top of ``backbones.create("resnet50", seed)``, the tie list, the
 labels and the REAL reference's gradient (its own ``Attack.get_grad`` through oracle/ref_shim.py) on the CPU in fp32, plus
 the fp64 evaluation's distance from it.
 
