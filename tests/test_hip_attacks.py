@@ -361,7 +361,8 @@ def test_gradient_accuracy_vs_fp64(name, n):
           "%.4f%%, sign flips %.4f%%" % (name, e_cpu, e_gpu, 100 * within, 100 * flips))
     # the 224-pixel random-init networks get the absolute floor of test_fold_bn_channels_last_is_the_same_surrogate: the
     # device's error is a run-to-run noisy quantity there, and a ratio of two such numbers must not carry a -x tier
-    assert e_gpu <= max(4 * e_cpu, 1e-5 if name == "toy_cnn" else 3e-2)
+    # floors per surrogate (round 5, ADVICE): 1.5x the worst device figure of rounds 2-4 instead of one 3e-2 for all
+    assert e_gpu <= max(4 * e_cpu, {"toy_cnn": 1e-5, "resnet18": 1e-2, "resnet50": 2.5e-2}[name])
     assert flips <= 0.01
 
 

@@ -13,6 +13,8 @@ gradient replaced by the recorded one.  By induction the iterates coincide, so
 Tier 2 -- the arrangement bench.py measures (eval-mode BatchNorm folded into the convolutions + NHWC) computes the same
 function as the reference-literal one: logits and input-gradients of both, on the device, against an fp64 ground truth.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,7 +234,13 @@ def test_fold_bn_channels_last_is_the_same_surrogate(monkeypatch, name):
     flips = float((torch.sign(got["bench"][1]) != torch.sign(got["literal"][1])).float().mean())
     print("%s: rel-L2 error vs fp64 truth (logits, input-gradient): reference-literal %.2e %.2e; folded-BN + NHWC %.2e %.2e; "
           "gradient sign flips between the two %.3f%%" % (name, e_lit[0], e_lit[1], e_bench[0], e_bench[1], 100 * flips))
-    assert e_bench[0] <= max(4 * e_lit[0], 1e-5) and e_bench[1] <= max(4 * e_lit[1], 3e-2)
+    # per-surrogate floors from the spread measured over rounds 2-4 on MI355X (~1.5x the worst figure of either
+    # arrangement): a surrogate several times worse than it has ever been fails; 3e-2 stays for the VGG-16 NHWC pair only
+    floor = {"resnet18": 1e-2, "resnet50": 2.5e-2, "mobilenet_v2": 2e-2, "inception_v3": 2.8e-2, "vgg16": 1e-2,
+             "vit_base_patch16_224": 1e-5}[name]
+    if os.environ.get("TA_VGG_CHANNELS_LAST") == "1":
+        floor = 3e-2
+    assert e_bench[0] <= max(4 * e_lit[0], 1e-5) and e_bench[1] <= max(4 * e_lit[1], floor)
     assert flips <= 0.01
 
 
