@@ -45,6 +45,10 @@ def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
 test_normalize_folded_loop_fused_resnet = A.test_normalize_folded_loop_fused_resnet
 
 
+def test_vmi_neighbours_stacked_equal_one_by_one(monkeypatch):
+    A.test_vmi_neighbours_stacked_equal_one_by_one(monkeypatch, "toy_cnn")
+
+
 @pytest.mark.parametrize("tag,fold_bn,channels_last,fold_normalize", A.CONDITIONED_ARRANGEMENTS)
 def test_gradient_within_1e5_on_conditioned_resnet50(golden, monkeypatch, tag, fold_bn, channels_last, fold_normalize):
     """the GPU tier's a5 test through the kernels' host build (ATen's CPU convolutions on both sides)"""

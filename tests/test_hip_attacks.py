@@ -249,6 +249,25 @@ def test_normalize_folded_loop_fused_resnet(monkeypatch):
     assert diff <= 3 * noise + 2e-4
 
 
+@pytest.mark.parametrize("backbone", ["toy_cnn", "vit_tiny_patch16_224"])
+def test_vmi_neighbours_stacked_equal_one_by_one(monkeypatch, backbone):
+    """VMI-FGSM's folded loop with k neighbour samples per surrogate evaluation (gradient/vmifgsm.py::_neighbor_stack)
+    against one evaluation per neighbour (vmifgsm.py:46-58's shape): same Philox draws, same accumulation order, per-slice
+    batch-mean losses -- the final delta may differ only where the surrogate's libraries round a k * N batch differently."""
+    out = {}
+    for k in ("1", "4", "2"):
+        monkeypatch.setenv("TA_VMI_STACK", k)
+        torch.manual_seed(5)
+        before = _hip.stats["partials_reused"]
+        out[k], _ = _loop(monkeypatch, True, "vmifgsm", backbone, n=2, epoch=2, num_neighbor=4)
+        assert _hip.stats["partials_reused"] == before + 2
+    for k in ("4", "2"):
+        diff = float((out[k] != out["1"]).float().mean())
+        print("VMI-FGSM / %s: %s neighbours per evaluation vs one: delta differs in %.5f%% of the elements" % (backbone, k, 100 * diff))
+        assert diff <= 2e-4
+    assert float(out["4"].abs().max()) > 0
+
+
 def conditioned_fixture(golden):
     """(images, labels, fixture, mask of comparable elements, builder of the conditioned ResNet-50): the surrogate of
     oracle/gen_conditioned.py -- the seeded ResNet-50 with gamma * 0.2 on every block's last BatchNorm and every ReLU-feeding

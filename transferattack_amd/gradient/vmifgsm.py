@@ -71,11 +71,38 @@ class VMIFGSM(Attack):
                 return None
         return pre.normalize.mean.reshape(-1).contiguous(), pre.normalize.std.reshape(-1).contiguous()
 
-    def _backbone_grad(self, y, label):
-        """d loss / d y for an already normalised input ``y`` (a fresh leaf) through ``self.model[1]``"""
+    def _backbone_grad(self, y, label, stack=1):
+        """d loss / d y for an already normalised input ``y`` (a fresh leaf) through ``self.model[1]``.  ``stack`` > 1: ``y``
+        holds that many neighbour samples of the batch one after the other ([stack * N, ...]) and the loss is the SUM of the
+        neighbours' own batch-mean losses (``get_loss`` per slice, as vmifgsm.py:50-53 calls it per neighbour), so every slice
+        of the result is that neighbour's gradient with the reference's 1 / N scaling."""
         y.requires_grad_(True)
-        loss = self.get_loss(self.model[1](y), label)
+        logits = self.model[1](y)
+        if stack == 1:
+            loss = self.get_loss(logits, label)
+        else:
+            n = y.shape[0] // stack
+            loss = self.get_loss(logits[:n], label)
+            for j in range(1, stack):
+                loss = loss + self.get_loss(logits[j * n:(j + 1) * n], label)
         return torch.autograd.grad(loss, y, retain_graph=False, create_graph=False)[0].contiguous()
+
+    def _neighbor_stack(self, n):
+        """How many of the ``num_neighbor`` samples go through the surrogate in ONE evaluation (round 5).  The samples of an
+        iteration are independent (vmifgsm.py:46-58 loops over them only because autograd.grad is called per sample): stacking
+        k of them runs the surrogate on k * N images -- fewer, larger launches and 1 / k of the host-side dispatch work per
+        image; slices are accumulated in neighbour order, so the variance keeps its rounding sequence.  ``TA_VMI_STACK=k`` sets
+        it (1 = one evaluation per neighbour, the reference's shape); default: the largest divisor of num_neighbor with
+        k * N <= 160 images (measured on ViT-B/16)."""
+        import os
+        want = os.environ.get("TA_VMI_STACK", "")
+        if want.isdigit() and int(want) >= 1:
+            k = min(int(want), self.num_neighbor)
+        else:
+            k = max(1, min(self.num_neighbor, 160 // max(n, 1)))
+        while self.num_neighbor % k:
+            k -= 1
+        return k
 
     def _forward_folded(self, data, label, mean, std):
         delta = self.init_delta(data).detach()
@@ -90,13 +117,18 @@ class VMIFGSM(Attack):
             if self.grad_probe is not None:                               # test hook: sees what get_grad would return
                 self.grad_probe(it, grad)
             acc = torch.empty_like(data)
-            for i in range(self.num_neighbor):
-                noise = None
-                if self.noise_source is not None:
-                    noise = self.noise_source(data.shape, -self.radius, self.radius).to(self.device).contiguous()
-                y = torch.empty_like(data)
-                _hip.vmi_neighbor_normalized(data, delta, y, mean, std, self.radius, self.rng_seed, self._next_offset(), noise)
-                _hip.normalize_bwd_accumulate(self._backbone_grad(y, label), acc, std, first=(i == 0))
+            n, k = data.shape[0], self._neighbor_stack(data.shape[0])
+            for base in range(0, self.num_neighbor, k):
+                ys = torch.empty((k * n,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
+                for j in range(k):                                  # draws in neighbour order: the Philox offsets of the
+                    noise = None                                    # one-by-one loop
+                    if self.noise_source is not None:
+                        noise = self.noise_source(data.shape, -self.radius, self.radius).to(self.device).contiguous()
+                    _hip.vmi_neighbor_normalized(data, delta, ys[j * n:(j + 1) * n], mean, std, self.radius, self.rng_seed,
+                                                 self._next_offset(), noise)
+                gys = self._backbone_grad(ys, label, stack=k)
+                for j in range(k):                                  # accumulated in neighbour order
+                    _hip.normalize_bwd_accumulate(gys[j * n:(j + 1) * n], acc, std, first=(base + j == 0))
             new_variance = torch.empty_like(data)
             _hip.variance_finalize(acc, grad, new_variance, self.num_neighbor)
             m_out = momentum if momentum is not None else (None if self.decay == 0 else torch.empty_like(data))
