@@ -267,6 +267,124 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     TA_PHASE(0, 5);
 }
 
+// Row-band form of the forward (round 5).  PMC on the lane-per-column kernel (profiles/r04/dim_tim_pmc_n160_r4b.txt): HBM
+// traffic 1.96 x the algorithmic bytes at less than half the bandwidth, 57 % of a wave's life in s_waitcnt.  Both come from
+// the tile shape: a 32 x <= 64-column tile reads row segments of ~230 bytes that start and end inside cache lines, which its
+// left / right neighbours -- on other XCDs, i.e. behind other L2s -- fetch again; and five barrier-separated phases each do
+// seven elements' worth of work per lane.  Here a workgroup owns R output rows x ALL columns of a plane:
+//   * one LANE per column (resize <= 256: a padded-image column in the first half, an output column in the second), so every
+//     row of x is read once, whole and aligned; only the <= 3 rows between two bands are read twice;
+//   * the two VERTICAL passes need no exchange at all: a lane's column stays in its own registers.  The loops run over the
+//     SOURCE rows with compile-time indices (all x loads of the lane are issued up front, 2 * SH registers) and, inside, a
+//     wave-uniform `while` emits the destination rows that became computable -- the row taps (LDS, one broadcast read) decide
+//     WHEN, a uniform select decides WHICH of the two newest source rows is the first operand: no dynamic register index;
+//   * the one HORIZONTAL exchange (H2 reads its two padded columns from other lanes) goes through LDS: one barrier.
+// Same four fused-multiply-add expressions in the same order as the kernels above (ATen's: width first, then height): same bits.
+template <int R, int MH, int SH>      // output rows per band; bounds of the padded-window rows / x rows behind a band
+__global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __restrict__ x, float* __restrict__ y, int size,
+                                                              int resize, int rnd, int top, int left, float scale1,
+                                                              float scale2, int bands) {
+    __shared__ int r1_i0[MH], r1_i1[MH];                 // window row p -> x rows (first resample), valid rows only
+    __shared__ float r1_l0[MH], r1_l1[MH];
+    __shared__ int r2_i0[R], r2_i1[R];                   // output row r -> window rows (second resample)
+    __shared__ float r2_l0[R], r2_l1[R];
+    __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];       // the zero-padded, rescaled window: [p][padded column]
+    const int t = static_cast<int>(threadIdx.x);
+    const int plane = static_cast<int>(blockIdx.x) / bands;
+    const int band = static_cast<int>(blockIdx.x) - plane * bands;
+    const int oy0 = band * R, th = min(R, size - oy0);
+    const float* xp = x + static_cast<int64_t>(plane) * size * size;
+    float* yp = y + static_cast<int64_t>(plane) * size * size;
+
+    // -- the band's window (wave-uniform values, computed by every lane alike)
+    const int py_lo = make_tap_scaled(oy0, resize, scale2).i0, py_hi = make_tap_scaled(oy0 + th - 1, resize, scale2).i1;
+    const int mh = py_hi - py_lo + 1;                                     // <= MH (host-checked)
+    const int p_a = max(top - py_lo, 0), p_b = min(top + rnd - 1 - py_lo, mh - 1);     // window rows inside the rescaled image
+    const bool any_rows = p_a <= p_b;
+    const int sr_lo = any_rows ? make_tap_scaled(py_lo + p_a - top, size, scale1).i0 : 0;
+    const int sr_hi = any_rows ? make_tap_scaled(py_lo + p_b - top, size, scale1).i1 : 0;     // sr_hi - sr_lo < SH (host-checked)
+    if (t < th) {
+        const Tap tp = make_tap_scaled(oy0 + t, resize, scale2);
+        r2_i0[t] = tp.i0 - py_lo; r2_i1[t] = tp.i1 - py_lo; r2_l0[t] = tp.l0; r2_l1[t] = tp.l1;
+    }
+    {
+        const int p = t - 64;                                             // waves 1.. build the window's row table
+        if (p >= p_a && p <= p_b) {
+            const Tap tp = make_tap_scaled(py_lo + p - top, size, scale1);
+            r1_i0[p] = tp.i0 - sr_lo; r1_i1[p] = tp.i1 - sr_lo; r1_l0[p] = tp.l0; r1_l1[p] = tp.l1;
+        }
+    }
+    // -- this lane's columns: padded column t (first resample), output column t (second resample)
+    const int rx = t - left;
+    const bool col_ok = t < resize && rx >= 0 && rx < rnd;
+    Tap tx1{0, 0, 0.f, 0.f}, tx2{0, 0, 0.f, 0.f};
+    if (col_ok) tx1 = make_tap_scaled(rx, size, scale1);
+    if (t < size) tx2 = make_tap_scaled(t, resize, scale2);
+    // -- all loads of the lane, back to back (lanes outside the image read column 0 of a valid row: in bounds, never used)
+    float xa[SH], xb[SH];
+    {
+        const char* base = reinterpret_cast<const char*>(xp);
+        const unsigned c0 = static_cast<unsigned>(tx1.i0) * 4u, c1 = static_cast<unsigned>(tx1.i1) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+#pragma unroll
+        for (int j = 0; j < SH; ++j) {
+            const unsigned row = static_cast<unsigned>(min(sr_lo + j, sr_hi)) * row_bytes;
+            xa[j] = *reinterpret_cast<const float*>(base + (row + c0));
+            xb[j] = *reinterpret_cast<const float*>(base + (row + c1));
+        }
+    }
+    __syncthreads();                                                      // the row tables are ready
+    // -- H1 + V1 down the lane's padded column: mid[p][t]
+    {
+        float* out = mid + t;
+        int p = 0;
+        for (; p < min(p_a, mh); ++p) out[p * kBlock] = 0.0f;             // zero padding above the image (dim.py:65)
+        float t_prev = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SH; ++j) {
+            const float t_cur = fmaf(tx1.l0, xa[j], tx1.l1 * xb[j]);      // H1: row sr_lo + j of x at this lane's column
+            while (p <= p_b) {
+                const int i1 = __builtin_amdgcn_readfirstlane(r1_i1[p]);
+                if (i1 > j) break;                                        // needs a row of x not reached yet
+                const int i0 = __builtin_amdgcn_readfirstlane(r1_i0[p]);
+                const float a = i0 == j ? t_cur : t_prev;                 // i0 is j or j - 1 (taps are monotone, i1 - i0 <= 1)
+                const float v = fmaf(r1_l0[p], a, r1_l1[p] * t_cur);      // V1
+                out[p * kBlock] = col_ok ? v : 0.0f;                      // zero padding left / right of the image
+                ++p;
+            }
+            t_prev = t_cur;
+        }
+        for (p = max(p_b + 1, p_a); p < mh; ++p) out[p * kBlock] = 0.0f;  // zero padding below
+    }
+    __syncthreads();
+    // -- H2 + V2 down the lane's output column
+    if (t < size) {
+        const float* m0 = mid + tx2.i0;
+        const float* m1 = mid + tx2.i1;
+        char* base = reinterpret_cast<char*>(yp);
+        unsigned out = static_cast<unsigned>(oy0 * size + t) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        int r = 0;
+        float u_prev = 0.0f;
+#pragma unroll
+        for (int p = 0; p < MH; ++p) {
+            if (p < mh) {                                                 // (uniform)
+                const float u_cur = fmaf(tx2.l0, m0[p * kBlock], tx2.l1 * m1[p * kBlock]);      // H2: window row p
+                while (r < th) {
+                    const int i1 = __builtin_amdgcn_readfirstlane(r2_i1[r]);
+                    if (i1 > p) break;
+                    const int i0 = __builtin_amdgcn_readfirstlane(r2_i0[r]);
+                    const float a = i0 == p ? u_cur : u_prev;
+                    *reinterpret_cast<float*>(base + out) = fmaf(r2_l0[r], a, r2_l1[r] * u_cur);  // V2
+                    out += row_bytes;
+                    ++r;
+                }
+                u_prev = u_cur;
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------- backward
 constexpr int kDimBwdTile = 32;         // 32 x 32 pixels of gx per workgroup
 constexpr int kDimBwdMaxMid = 104;      // side of the LDS-resident window of d(rescaled); rate <= ~2.9 (OPS; 62.5 KB of LDS at 224 -> 649)
@@ -749,12 +867,61 @@ static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
 
 extern "C" int64_t ta_dim_bwd_tiles(int size, int resize) { return ta_dim_bwd_tiles_impl(size, resize); }
 
+// the kernels' make_tap_scaled on the host (fmaf is the exact fused operation here as well)
+static void host_tap(int o, int in_size, float scale, int* i0, int* i1) {
+    float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    int a = static_cast<int>(src);
+    a = a > in_size - 1 ? in_size - 1 : a;
+    *i0 = a;
+    *i1 = a + (a < in_size - 1 ? 1 : 0);
+}
+
+// largest window (padded rows, rows of x) behind any R-row band of the forward for this geometry
+static void fwd_band_bounds(int size, int resize, int rnd, int top, int rows, int* mh_max, int* sh_max) {
+    const float scale1 = static_cast<float>(size) / static_cast<float>(rnd), scale2 = static_cast<float>(resize) / static_cast<float>(size);
+    *mh_max = *sh_max = 0;
+    for (int oy0 = 0; oy0 < size; oy0 += rows) {
+        const int th = size - oy0 < rows ? size - oy0 : rows;
+        int lo, hi, unused;
+        host_tap(oy0, resize, scale2, &lo, &unused);
+        host_tap(oy0 + th - 1, resize, scale2, &unused, &hi);
+        const int mh = hi - lo + 1;
+        *mh_max = mh > *mh_max ? mh : *mh_max;
+        const int p_a = top - lo > 0 ? top - lo : 0, p_b = top + rnd - 1 - lo < mh - 1 ? top + rnd - 1 - lo : mh - 1;
+        if (p_a <= p_b) {
+            int s_lo, s_hi;
+            host_tap(lo + p_a - top, size, scale1, &s_lo, &unused);
+            host_tap(lo + p_b - top, size, scale1, &unused, &s_hi);
+            *sh_max = s_hi - s_lo + 1 > *sh_max ? s_hi - s_lo + 1 : *sh_max;
+        }
+    }
+}
+
 extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top, int left,
                           void* stream) {
     TA_REQUIRE(x && y && x != y, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // lane-per-column kernel: every geometry with resize <= ~2 * size (all the reference draws: resize_rate 1.1)
+    // row-band kernel (round 5): one lane per column, a band of 32 output rows x every column per workgroup -- the geometries
+    // the reference draws at 224 pixels (resize_rate 1.1: resize = 246); TA_DIM_BAND=0 selects the tile kernels below
+    {
+        const char* env = getenv("TA_DIM_BAND");
+        if (resize <= kBlock && rnd >= size && resize >= size && (env == nullptr || atoi(env) != 0)) {
+            constexpr int R = 32, MH = 40, SH = 40;
+            int mh_max, sh_max;
+            fwd_band_bounds(size, resize, rnd, top, R, &mh_max, &sh_max);
+            const int bands = static_cast<int>(ceil_div(size, R));
+            if (mh_max <= MH && sh_max <= SH && planes * bands < (1ll << 31)) {
+                const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
+                const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+                hipLaunchKernelGGL((dim_fwd_band_kernel<R, MH, SH>), dim3(static_cast<unsigned>(planes * bands)), dim3(kBlock), 0, st,
+                                   x, y, size, resize, rnd, top, left, scale1, scale2, bands);
+                return check_launch("dim_fwd_band");
+            }
+        }
+    }
+    // lane-per-column kernel: every geometry with resize <= ~2 * size
     if (static_cast<int64_t>(size) * size < (1ll << 30)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
         const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
