@@ -741,6 +741,154 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 }
 
 
+// Row-band form of the backward (round 5), the counterpart of dim_fwd_band_kernel: a workgroup owns R rows of gx x ALL columns
+// of a plane, one lane per column (of d(rescaled) in stage A, of gx in stage B).  Both stages are still ATen's 2-D gathers in
+// its accumulation order -- acc = fma(wy * wx, g, acc) over the hits, rows outer, columns inner -- but they run over the SOURCE
+// rows with compile-time indices: every source row is read ONCE per lane (stage A: the lane's two output columns of a gy row,
+// all rows' loads issued up front; stage B: the lane's three rescaled columns of a `mid` row from LDS) and kept in a rolling
+// window of 2 (3) rows of registers; a wave-uniform `while` emits the target rows whose LAST hit row has just arrived and a
+// uniform select picks the window row for each hit slot.  One barrier between the stages.  Reads per target element: 2 global
+// + 3 LDS (the tile kernel: 4 global + 9 LDS), whole aligned rows of gy (no horizontal over-fetch).
+// SA = 2, SB = 3 (at most two outputs touch a padded index, at most three rescaled pixels an index of x): the host checks
+// both with the kernels' own tap arithmetic and falls back to the tile kernels otherwise.
+template <int R, int MH, int OH>          // rows of gx per band; bounds of the d(rescaled) rows / gy rows behind a band
+__global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                              float* __restrict__ ws, int size, int resize, int rnd, int top,
+                                                              int left, float scale1, float scale2, int bands, int ws_tiles) {
+    constexpr int SA = 2, SB = 3;
+    __shared__ __attribute__((aligned(16))) Hit rowB[R];                // band row iy          -> rescaled rows
+    __shared__ __attribute__((aligned(16))) Hit rowA[MH];               // window row (padded)  -> output rows
+    __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];     // d(rescaled) window: [p][rescaled column]
+    __shared__ float red[kBlock / kWave];
+    const int t = static_cast<int>(threadIdx.x);
+    const int plane = static_cast<int>(blockIdx.x) / bands;
+    const int band = static_cast<int>(blockIdx.x) - plane * bands;
+    const int iy0 = band * R, th = min(R, size - iy0);
+    const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
+    char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
+
+    // -- window of d(rescaled) rows behind the band (uniform), then the two row tables
+    const Hit h_first = find_hits(iy0, size, rnd, scale1), h_last = find_hits(iy0 + th - 1, size, rnd, scale1);
+    const int ry_lo = h_first.first, ry_hi = h_last.first + h_last.n - 1;
+    const int mh = ry_hi - ry_lo + 1;                                   // 1 .. MH (host-checked)
+    if (t < th) rowB[t] = find_hits(iy0 + t, size, rnd, scale1);
+    if (t >= 64 && t - 64 < mh) rowA[t - 64] = find_hits(ry_lo + (t - 64) + top, resize, size, scale2);
+    // -- this lane's columns
+    Hit hxa = find_hits(min(t, rnd - 1) + left, resize, size, scale2);  // stage A: rescaled column t -> output columns
+    if (t >= rnd) hxa.n = 0;
+    Hit hxb = find_hits(min(t, size - 1), size, rnd, scale1);           // stage B: column t of gx -> rescaled columns
+    if (t >= size) { hxb.n = 0; hxb.both = 0u; }
+    const bool any_both_xa = __builtin_amdgcn_readfirstlane(__any(hxa.both != 0u)) != 0;
+    const bool any_both_xb = __builtin_amdgcn_readfirstlane(__any(hxb.both != 0u)) != 0;
+    // -- gy rows behind the window (uniform): first hit of its first row .. last hit of its last row
+    const Hit a_first = find_hits(ry_lo + top, resize, size, scale2), a_last = find_hits(ry_hi + top, resize, size, scale2);
+    const int oy_lo = a_first.first, oy_hi = max(a_last.first + a_last.n - 1, oy_lo);          // oy_hi - oy_lo < OH (host-checked)
+    // -- all loads of the lane, back to back
+    float ga[OH], gb[OH];
+    {
+        const unsigned c0 = static_cast<unsigned>(min(hxa.first, size - 1)) * 4u, c1 = static_cast<unsigned>(min(hxa.first + 1, size - 1)) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+#pragma unroll
+        for (int j = 0; j < OH; ++j) {
+            const unsigned row = static_cast<unsigned>(min(oy_lo + j, oy_hi)) * row_bytes;
+            ga[j] = *reinterpret_cast<const float*>(gyp + (row + c0));
+            gb[j] = *reinterpret_cast<const float*>(gyp + (row + c1));
+        }
+    }
+    __syncthreads();                                                    // the row tables are ready
+    // -- stage A down the lane's rescaled column: mid[p][t]
+    {
+        float* out = mid + t;
+        int p = 0;
+        float pa = 0.0f, pb = 0.0f;                                     // the previous gy row at this lane's two columns
+#pragma unroll
+        for (int j = 0; j < OH; ++j) {
+            while (p < mh) {
+                const Hit* hy = &rowA[p];
+                const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - oy_lo;
+                const int n_y = __builtin_amdgcn_readfirstlane(hy->n);                 // <= SA
+                if (first_y + n_y - 1 > j) break;                        // its last hit row has not arrived
+                const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+                float acc = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < SA; ++ky)
+                    if (ky < n_y) {
+                        const bool cur = first_y + ky == j;              // the hit row is row j or row j - 1 (uniform)
+                        const float g0 = cur ? ga[j] : pa, g1 = cur ? gb[j] : pb;
+                        if (!any_both_xa && both_y == 0u) {
+                            acc = hit_accumulate<true>(acc, g0, hy->w[ky], 0.0f, false, hxa, 0);
+                            acc = hit_accumulate<true>(acc, g1, hy->w[ky], 0.0f, false, hxa, 1);
+                        } else {
+                            acc = hit_accumulate<false>(acc, g0, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxa, 0);
+                            acc = hit_accumulate<false>(acc, g1, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxa, 1);
+                        }
+                    }
+                out[p * kBlock] = acc;
+                ++p;
+            }
+            pa = ga[j];
+            pb = gb[j];
+        }
+    }
+    __syncthreads();
+    // -- stage B down the lane's column of gx
+    float asum = 0.0f;
+    {
+        int col[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) col[k] = min(max(hxb.first - 0, 0) + k, rnd - 1);       // rescaled columns = LDS columns
+        unsigned out = static_cast<unsigned>(iy0 * size + min(t, size - 1)) * 4u;
+        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        int r = 0;
+        float m1[SB] = {0.0f, 0.0f, 0.0f}, m2[SB] = {0.0f, 0.0f, 0.0f};     // window rows p - 1, p - 2 at the lane's columns
+#pragma unroll
+        for (int p = 0; p < MH; ++p) {
+            if (p < mh) {                                                // (uniform)
+                float m0[SB];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) m0[k] = mid[p * kBlock + col[k]];
+                while (r < th) {
+                    const Hit* hy = &rowB[r];
+                    const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
+                    const int n_y = __builtin_amdgcn_readfirstlane(hy->n);             // 1 .. SB
+                    if (first_y + n_y - 1 > p) break;
+                    const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ky = 0; ky < SB; ++ky)
+                        if (ky < n_y) {
+                            const int back = p - (first_y + ky);         // 0, 1 or 2 rows ago (uniform)
+#pragma unroll
+                            for (int kx = 0; kx < SB; ++kx) {
+                                const float g = back == 0 ? m0[kx] : (back == 1 ? m1[kx] : m2[kx]);
+                                if (!any_both_xb && both_y == 0u)
+                                    acc = hit_accumulate<true>(acc, g, hy->w[ky], 0.0f, false, hxb, kx);
+                                else
+                                    acc = hit_accumulate<false>(acc, g, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxb, kx);
+                            }
+                        }
+                    if (t < size) {
+                        *reinterpret_cast<float*>(gxp + out) = acc;
+                        asum += fabsf(acc);
+                    }
+                    out += row_bytes;
+                    ++r;
+                }
+#pragma unroll
+                for (int k = 0; k < SB; ++k) { m2[k] = m1[k]; m1[k] = m0[k]; }
+            }
+        }
+    }
+    const float total = block_sum(asum, red);
+    if (ws != nullptr && t == 0) {
+        // the caller sized ws for ta_dim_bwd_tiles(size, resize) sums per plane (the tile kernels' count): the band's sum goes
+        // to slot `band`, the slots no band owns get an exact zero
+        float* w = ws + static_cast<int64_t>(plane) * ws_tiles;
+        w[band] = total;
+        for (int k = bands + band; k < ws_tiles; k += bands) w[k] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // PreprocessingModel with a Resize (reference: transferattack/utils.py:50-53, 72-79 -- Inception-v3: 224 -> 299, mean = std =
 // 0.5):  y = (bilinear_{in->out}(x) - mean[c]) / std[c]  as ONE kernel each way, with the DIM kernels' taps and rounding
@@ -957,11 +1105,69 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     return check_launch("dim_fwd");
 }
 
+// outputs of a 1-D resample (in_size -> out_size) that touch source index t: [first, last], -1 if none (host form of find_hits)
+static void host_hits(int t, int in_size, int out_size, float scale, int* first, int* last) {
+    *first = -1; *last = -2;
+    const float est = (static_cast<float>(t) - 0.5f) / scale - 0.5f;
+    int c = static_cast<int>(floorf(est)) - 1;
+    c = c < 0 ? 0 : c;
+    for (int o = c; o < out_size && o < c + 8; ++o) {
+        int i0, i1;
+        host_tap(o, in_size, scale, &i0, &i1);
+        if (i0 == t || i1 == t) {
+            if (*first < 0) *first = o;
+            *last = o;
+        } else if (*first >= 0) {
+            break;
+        }
+    }
+}
+
+// largest window (d(rescaled) rows, gy rows) behind any R-row band of the backward for this geometry
+static void bwd_band_bounds(int size, int resize, int rnd, int top, int rows, int* mh_max, int* oh_max) {
+    const float scale1 = static_cast<float>(size) / static_cast<float>(rnd), scale2 = static_cast<float>(resize) / static_cast<float>(size);
+    *mh_max = *oh_max = 0;
+    for (int iy0 = 0; iy0 < size; iy0 += rows) {
+        const int th = size - iy0 < rows ? size - iy0 : rows;
+        int f0, l0, f1, l1;
+        host_hits(iy0, size, rnd, scale1, &f0, &l0);
+        host_hits(iy0 + th - 1, size, rnd, scale1, &f1, &l1);
+        if (f0 < 0 || f1 < 0) { *mh_max = *oh_max = 1 << 20; return; }     // an index nobody touches: not a geometry for this kernel
+        const int mh = l1 - f0 + 1;
+        *mh_max = mh > *mh_max ? mh : *mh_max;
+        int a0, b0, a1, b1;
+        host_hits(f0 + top, resize, size, scale2, &a0, &b0);
+        host_hits(l1 + top, resize, size, scale2, &a1, &b1);
+        if (a0 < 0 || a1 < 0) { *mh_max = *oh_max = 1 << 20; return; }
+        *oh_max = b1 - a0 + 1 > *oh_max ? b1 - a0 + 1 : *oh_max;
+    }
+}
+
 extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
                           int left, void* stream) {
     TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // row-band kernel (round 5): the geometries the reference draws at 224 pixels; TA_DIM_BAND=0 selects the tile kernels below.
+    // ws keeps the tile kernels' layout (ta_dim_bwd_tiles sums per plane: the count depends on (size, resize) only)
+    {
+        const char* env = getenv("TA_DIM_BAND");
+        if (resize <= kBlock && rnd >= size && resize > size && (env == nullptr || atoi(env) != 0) &&
+            max_hits(size, rnd) <= 3 && max_hits(resize, size) <= 2) {
+            constexpr int R = 32, MH = 40, OH = 40;
+            int mh_max, oh_max;
+            bwd_band_bounds(size, resize, rnd, top, R, &mh_max, &oh_max);
+            const int bands = static_cast<int>(ceil_div(size, R));
+            const int64_t ws_tiles = ta_dim_bwd_tiles_impl(size, resize);
+            if (mh_max <= MH && oh_max <= OH && planes * bands < (1ll << 31) && ws_tiles >= bands && ws_tiles < (1 << 30)) {
+                const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
+                const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+                hipLaunchKernelGGL((dim_bwd_band_kernel<R, MH, OH>), dim3(static_cast<unsigned>(planes * bands)), dim3(kBlock), 0, st,
+                                   gy, gx, ws, size, resize, rnd, top, left, scale1, scale2, bands, static_cast<int>(ws_tiles));
+                return check_launch("dim_bwd_band");
+            }
+        }
+    }
     // lane-per-column gather: resize > size, resize <= 1.5 * size and < 2^28 elements per plane (the choice depends on
     // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives)
     if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {

@@ -640,7 +640,7 @@ static int launch_partials(const float* g, const float* v, float* ws, int64_t n,
         return check_launch("aten_order_abs_sum");
     }
     const dim3 grid(tiles, static_cast<unsigned>(n));
-    const bool vec = vec_ok(e, {g, v}) && hw % kVec == 0;
+    const bool vec = vec_ok(e, {g, v}) && (stdv == nullptr || hw % kVec == 0);
     if (stdv != nullptr) {                      // sums of |g / std[c]| (never squared, never with a variance term)
         if (vec)
             TA_LAUNCH_TIMED((abs_sum_partials_kernel<4, false, false, true>), grid, dim3(kBlock), st, ev_start, no_event, g, v, ws,
