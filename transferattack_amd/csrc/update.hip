@@ -37,6 +37,8 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
     constexpr int S = Slots<VEC>::n;
     Pack<VEC> a[S], b[S];
     bool full[S];
+    const TileChannels<kTile> ch(G_STD ? tile0 : 0, G_STD ? hw : 1, e);
+    const float s0 = G_STD ? stdv[ch.c_lo] : 1.0f, s1 = G_STD ? stdv[ch.c_hi] : 1.0f;
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
                 float x = a[u][k];
                 if (G_STD) {
                     const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
-                    x = x / stdv[static_cast<int>((off + k) / hw)];
+                    x = x / ch.pick(stdv, s0, s1, off + k);
                 }
                 if (HAS_V) x = x + b[u][k];
                 acc += SQUARE ? x * x : fabsf(x);
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(kBlock) void normalize_fwd_kernel(const float* __re
     const int64_t img = blockIdx.y;
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
     constexpr int S = Slots<VEC>::n;
+    const TileChannels<kTile> ch(tile0, hw, e);
+    const float m0 = mean[ch.c_lo], m1 = mean[ch.c_hi], s0 = stdv[ch.c_lo], s1 = stdv[ch.c_hi];
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -182,10 +186,8 @@ __global__ __launch_bounds__(kBlock) void normalize_fwd_kernel(const float* __re
             Pack<VEC> a, o;
             a.load(x + img * e + off);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int c = static_cast<int>((off + k) / hw);
-                o[k] = (a[k] - mean[c]) / stdv[c];
-            }
+            for (int k = 0; k < VEC; ++k)
+                o[k] = (a[k] - ch.pick(mean, m0, m1, off + k)) / ch.pick(stdv, s0, s1, off + k);
             o.store(y + img * e + off);
         } else if (VEC > 1) {
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
@@ -212,6 +214,8 @@ __global__ __launch_bounds__(kBlock) void normalize_adv_fwd_kernel(const float* 
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
     constexpr int S = Slots<VEC>::n;
     const bool bytes = X_U8 && uniform_int(*u8_mismatch) == 0;
+    const TileChannels<kTile> ch(tile0, hw, e);
+    const float m0 = mean[ch.c_lo], m1 = mean[ch.c_hi], s0 = stdv[ch.c_lo], s1 = stdv[ch.c_hi];
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -226,10 +230,8 @@ __global__ __launch_bounds__(kBlock) void normalize_adv_fwd_kernel(const float* 
                 a.load(x + img * e + off);
             }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int c = static_cast<int>((off + k) / hw);
-                o[k] = ((a[k] + d[k]) - mean[c]) / stdv[c];
-            }
+            for (int k = 0; k < VEC; ++k)
+                o[k] = ((a[k] + d[k]) - ch.pick(mean, m0, m1, off + k)) / ch.pick(stdv, s0, s1, off + k);
             o.store(y + img * e + off);
         } else if (VEC > 1) {
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
@@ -251,6 +253,8 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __re
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
     constexpr int S = Slots<VEC>::n;
     float acc = 0.0f;
+    const TileChannels<kTile> ch(tile0, hw, e);
+    const float s0 = stdv[ch.c_lo], s1 = stdv[ch.c_hi];
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -260,8 +264,7 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __re
             if (HAS_V) b.load(v + img * e + off);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const int c = static_cast<int>((off + k) / hw);
-                o[k] = a[k] / stdv[c];
+                o[k] = a[k] / ch.pick(stdv, s0, s1, off + k);
                 acc += fabsf(HAS_V ? o[k] + b[k] : o[k]);    // same per-thread order as abs_sum_partials_kernel
             }
             o.store(gx + img * e + off);
@@ -293,6 +296,8 @@ __global__ __launch_bounds__(kBlock) void vmi_neighbor_norm_kernel(const float* 
     const int64_t img = blockIdx.y;
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
     constexpr int S = Slots<VEC>::n;
+    const TileChannels<kTile> ch(tile0, hw, e);
+    const float m0 = mean[ch.c_lo], m1 = mean[ch.c_hi], s0 = stdv[ch.c_lo], s1 = stdv[ch.c_hi];
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -310,10 +315,8 @@ __global__ __launch_bounds__(kBlock) void vmi_neighbor_norm_kernel(const float* 
                 r[0] = uniform1(static_cast<uint64_t>(at), seed, offset, radius);
             }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int c = static_cast<int>((off + k) / hw);
-                o[k] = (((a[k] + d[k]) + r[k]) - mean[c]) / stdv[c];
-            }
+            for (int k = 0; k < VEC; ++k)
+                o[k] = (((a[k] + d[k]) + r[k]) - ch.pick(mean, m0, m1, off + k)) / ch.pick(stdv, s0, s1, off + k);
             o.store(y + at);
         } else if (VEC > 1) {
             for (int64_t i = off; i < e && i < off + VEC; ++i) {
@@ -332,6 +335,8 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_accumulate_kernel(const 
     const int64_t img = blockIdx.y;
     const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kTile;
     constexpr int S = Slots<VEC>::n;
+    const TileChannels<kTile> ch(tile0, hw, e);
+    const float s0 = stdv[ch.c_lo], s1 = stdv[ch.c_hi];
 #pragma unroll
     for (int u = 0; u < S; ++u) {
         const int64_t off = tile0 + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * VEC;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void normalize_bwd_accumulate_kernel(const 
             if (!FIRST) o.load(acc + img * e + off);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                const float g = a[k] / stdv[static_cast<int>((off + k) / hw)];
+                const float g = a[k] / ch.pick(stdv, s0, s1, off + k);
                 o[k] = FIRST ? g : o[k] + g;
             }
             o.store(acc + img * e + off);
@@ -414,6 +419,10 @@ __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
             }
         }
     }
+    // G_STD: the tile's (at most two) channels and their std -- one 32-bit scalar division and two scalar loads, in the
+    // shadow of the operands' loads issued above
+    const TileChannels<TILE> ch(G_STD ? static_cast<int64_t>(blockIdx.x) * TILE : 0, G_STD ? hw : 1, e);
+    const float sd0 = G_STD ? stdv[ch.c_lo] : 1.0f, sd1 = G_STD ? stdv[ch.c_hi] : 1.0f;
     if (X_U8 && bytes) {
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u)
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void mi_update_kernel(
         if (full[u]) {
             Pack<VEC> om, od, oa;
             // G_STD: one channel per 16-byte access (hw % VEC == 0 is the launcher's condition for the vector form)
-            const float sd = G_STD ? stdv[(static_cast<int>(blockIdx.x) * TILE + static_cast<int>(off)) / hw] : 1.0f;
+            const float sd = G_STD ? ch.pick(stdv, sd0, sd1, static_cast<int64_t>(blockIdx.x) * TILE + off) : 1.0f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float g0 = G_STD ? pg[u][k] / sd : pg[u][k];
@@ -677,6 +686,13 @@ static int check_batch(int64_t n, int64_t e) {
     return 0;
 }
 
+// the kernels that index per-channel constants address an image with 32-bit offsets
+static int check_planes(int64_t n, int64_t e) {
+    if (int rc = check_batch(n, e)) return rc;
+    TA_REQUIRE(e < (1ll << 31), "images of %lld elements exceed the 2^31 the per-channel kernels address", (long long)e);
+    return 0;
+}
+
 extern "C" int64_t ta_update_tiles(int64_t e) { return e > 0 ? ceil_div(e, kTile) : 0; }
 
 extern "C" int64_t ta_l1_workspace_floats(int64_t n, int64_t e) {
@@ -762,7 +778,7 @@ extern "C" int ta_update_delta_l2(const float* delta_in, const float* x, const f
 extern "C" int ta_normalize_fwd(const float* x, float* y, const float* mean, const float* stdv, int64_t n, int c,
                                 int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(x && y && mean && stdv && c > 0, "null pointer");
     const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -776,7 +792,7 @@ extern "C" int ta_normalize_fwd(const float* x, float* y, const float* mean, con
 extern "C" int ta_normalize_bwd(const float* gy, float* gx, const float* stdv, const float* v, float* ws, int64_t n, int c,
                                 int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(gy && gx && stdv && ws && c > 0, "null pointer");
     const int tiles = static_cast<int>(ceil_div(e, kTile));
     const dim3 grid(tiles, static_cast<unsigned>(n));
@@ -792,7 +808,7 @@ extern "C" int ta_vmi_neighbor_normalized(const float* x, const float* delta, co
                                           const float* stdv, float radius, uint64_t seed, uint64_t offset, int64_t n, int c,
                                           int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(x && delta && y && mean && stdv && c > 0, "null pointer");
     const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -807,7 +823,7 @@ extern "C" int ta_vmi_neighbor_normalized(const float* x, const float* delta, co
 extern "C" int ta_normalize_bwd_accumulate(const float* gy, float* acc, const float* stdv, int first, int64_t n, int c,
                                            int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(gy && acc && stdv && c > 0 && gy != acc, "null or aliased pointers");
     const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -952,7 +968,7 @@ extern "C" int ta_mi_update_std(const float* gy, const float* stdv, const float*
 
 extern "C" int ta_abs_sum_partials_std(const float* gy, const float* stdv, float* ws, int64_t n, int c, int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(gy && stdv && ws && c > 0 && hw > 0, "null pointer");
     return launch_partials(gy, nullptr, ws, n, e, false, static_cast<hipStream_t>(stream), nullptr, stdv, hw);
 }
@@ -960,7 +976,7 @@ extern "C" int ta_abs_sum_partials_std(const float* gy, const float* stdv, float
 extern "C" int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
                                     const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream) {
     const int64_t e = static_cast<int64_t>(c) * hw;
-    if (int rc = check_batch(n, e)) return rc;
+    if (int rc = check_planes(n, e)) return rc;
     TA_REQUIRE(x && delta && y && mean && stdv && c > 0, "null pointer");
     TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
     const dim3 grid(static_cast<unsigned>(ceil_div(e, kTile)), static_cast<unsigned>(n));

@@ -60,6 +60,34 @@ __device__ __forceinline__ float u8_to_unit(uint32_t k) {
 // a value every lane holds alike, moved to a scalar register so that a branch on it is a scalar branch
 __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Channel of an element of an image of C planes of hw elements, for the elements of ONE workgroup tile [tile0, tile0 + TILE).
+// A tile no longer than a plane holds at most two channels: the first is a wave-uniform value (ONE 32-bit scalar division per
+// workgroup; the per-channel constants come in through scalar loads), an element is in the second iff it lies past the plane
+// boundary -- one compare per element instead of a 64-bit division per element (which cost the Normalize kernels a third of
+// their bandwidth).  Shorter planes (tiny test images) keep a 32-bit division per element.  Images of < 2^31 elements
+// (host-checked).
+template <int TILE>
+struct TileChannels {
+    unsigned hw, next;
+    int c_lo, c_hi;
+    bool two;
+    __device__ __forceinline__ TileChannels(int64_t tile0, int64_t hw_, int64_t e) {
+        hw = static_cast<unsigned>(hw_);
+        c_lo = static_cast<int>(static_cast<unsigned>(tile0) / hw);        // uniform: blockIdx-derived
+        const unsigned long long nx = static_cast<unsigned long long>(c_lo + 1) * hw;
+        next = nx > 0xffffffffull ? 0xffffffffu : static_cast<unsigned>(nx);
+        c_hi = nx < static_cast<unsigned long long>(e) ? c_lo + 1 : c_lo;   // the plane after this one, if the image has one
+        two = hw_ >= TILE;
+    }
+    __device__ __forceinline__ int of(int64_t off) const {
+        return two ? (static_cast<unsigned>(off) >= next ? c_hi : c_lo) : static_cast<int>(static_cast<unsigned>(off) / hw);
+    }
+    // table[channel of off] (t0 / t1 = table[c_lo] / table[c_hi], preloaded by the caller: scalar loads)
+    __device__ __forceinline__ float pick(const float* __restrict__ table, float t0, float t1, int64_t off) const {
+        return two ? (static_cast<unsigned>(off) >= next ? t1 : t0) : table[static_cast<unsigned>(off) / hw];
+    }
+};
+
 struct StepParams {
     float decay, alpha, neg_eps, eps;
 };
