@@ -188,11 +188,13 @@ def check_rates(config, tag, g, x, label, adv):
 def test_asr1000_mifgsm_resnet50(tag, arrangement):
     """BASELINE.json configs[1]: MI-FGSM, ResNet-50, eps 16/255, alpha 1.6/255, K = 10, the 1000-image set"""
     g = fixture("mifgsm")
-    before = _hip.stats["k1_passes"]
+    before = dict(_hip.stats)
     x, label, adv, agree, seconds = run_config("configs[1]", "mifgsm", arrangement, g)
     print("\nconfigs[1] [%s]: %d images in %.1f s (%.0f images/s incl. upload, quantise, download); first-iteration "
           "gradient sign agreement with the reference %.3f %%" % (tag, len(label), seconds, len(label) / seconds, 100 * agree))
-    assert _hip.stats["k1_passes"] == before, "the fused update re-read the gradient"
+    assert _hip.stats["std_form_launches"] > before["std_form_launches"], "the loop did not fold the Normalize into its ends"
+    if arrangement:         # bench.py's arrangement: the stem kernel leaves the |gy / std| sums -- no pass re-reads the gradient
+        assert _hip.stats["k1_passes"] == before["k1_passes"], "the fused update re-read the gradient"
     assert agree >= 0.99
     check_rates("configs[1] MI-FGSM / ResNet-50", tag, g, x, label, adv)
 

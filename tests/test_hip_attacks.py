@@ -173,11 +173,21 @@ def test_long_tail_attacks_gpu_vs_reference(golden, name, kw):
 def test_variants_run_on_gpu(golden):
     g = golden("loops_toy")
     x, label = t(g["x_u8"]).float() / 255, t(g["label"])
+    import os
     before = dict(_hip.stats)
-    x224 = u8_images(2, 224, 9).float() / 255                             # 224 px: no resize in PreprocessingModel, so
-    make("mifgsm")(x224, label[:2])                                       # the Normalize backward is the producer of g
-    assert _hip.stats["partials_reused"] - before["partials_reused"] == 10   # and feeds all 10 fused updates: no K1 pass
-    assert _hip.stats["k1_passes"] == before["k1_passes"]
+    x224 = u8_images(2, 224, 9).float() / 255                             # 224 px: no resize in PreprocessingModel
+    make("mifgsm")(x224, label[:2])                                       # -> the loop with the Normalize folded into its ends:
+    assert _hip.stats["std_form_launches"] - before["std_form_launches"] == 10   # ta_mi_update_std; this backbone's backward is
+    assert _hip.stats["k1_passes"] - before["k1_passes"] == 10            # not ours, so a sum-only pass over gy precedes it
+    old = os.environ.get("TA_FOLD_NORMALIZE")
+    os.environ["TA_FOLD_NORMALIZE"] = "0"                                 # the hook-by-hook loop: the Normalize backward is the
+    try:                                                                  # producer of g and feeds all 10 fused updates
+        mid = dict(_hip.stats)
+        make("mifgsm")(x224, label[:2])
+        assert _hip.stats["partials_reused"] - mid["partials_reused"] == 10 and _hip.stats["k1_passes"] == mid["k1_passes"]
+    finally:
+        os.environ.pop("TA_FOLD_NORMALIZE") if old is None else os.environ.__setitem__("TA_FOLD_NORMALIZE", old)
+    before = dict(_hip.stats)
     make("mifgsm")(x, label)                                              # 32 px -> resized to 224: bilinear backward is
     assert _hip.stats["k1_passes"] - before["k1_passes"] == 10            # the producer, the update runs its own K1
     d = make("mifgsm", targeted=True)(x, [label, t(g["target"])])

@@ -174,10 +174,14 @@ def test_end_to_end_at_config_size(golden, name, model):
     n = len(g["label"])
     x = u8_images(n, 224, int(g["seed_images"])).float() / 255
     atk = product_attack(name, [backbones.create(model, seed=int(g["seed_weights"]), verbose=False)])
-    before = _hip.stats["partials_reused"]
+    before = dict(_hip.stats)
     torch.manual_seed(int(g["seed_draws"]) if "seed_draws" in g.files else 0)
     delta = atk(x, t(g["label"])).cpu()
-    assert _hip.stats["partials_reused"] == before + 10, "the fused update re-read the gradient"
+    if name == "mifgsm":      # the plain loop folds the Normalize into its ends; this surrogate's backward (module path) is
+        # MIOpen's, so a sum-only pass over gy precedes each update (4 + 21 instead of 8 + 25 B/element)
+        assert _hip.stats["std_form_launches"] == before["std_form_launches"] + 10
+    else:
+        assert _hip.stats["partials_reused"] == before["partials_reused"] + 10, "the fused update re-read the gradient"
     assert float(delta.abs().max()) <= EPS + 1e-7
     adv = x + delta
     assert float(adv.min()) >= 0.0 and float(adv.max()) <= 1.0 + 1e-7
