@@ -163,6 +163,28 @@ det)
 coldstart)
   timeout 1500 python tools/cold_start.py --modes ${TA_COLD_MODES:-immediate,immediate:warm,fast,fast:warm} --keep $OUT/miopen 2> $OUT/cold_start.err | tee $OUT/cold_start.jsonl
   du -sh $OUT/miopen/* 2>/dev/null ;;
+dimab)
+  # DIM: row-band kernels (round 5) against the tile kernels, event timing + rocprofv3 durations + HBM counters at N = 160
+  timeout 300 python tools/tim_microbench.py 2>&1 | tee $OUT/dim_band_vs_tiles.txt
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/dimtrace -o trace -- python $R/tools/tim_microbench.py > $R/$OUT/dimtrace.log 2>&1 )
+  f=$(find $OUT/dimtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dim_kernel_stats_n160.csv && grep -E "Name|dim_|dwconv" "$f" | cut -c1-200
+  find $OUT/dimtrace -name "*kernel_trace.csv" -delete; find $OUT/dimtrace -name "*.db" -delete
+  for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/dimpmc_$tag -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_$tag.log 2>&1 )
+  python tools/pmc_kernels.py $OUT/dimpmc_$tag | tee -a $OUT/dimpmc_summary.txt
+  done
+  find $OUT -name "*.db" -delete ;;
+vmistack)
+  # configs[3]: VMI-FGSM / ViT-B/16, k neighbour samples per surrogate evaluation
+  for k in ${TA_VMI_KS:-1 5 10}; do
+  TA_VMI_STACK=$k timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32_stack$k.json | cut -c1-400
+  done ;;
+newtests5b)
+  timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
+      -k "test_hip_kernels or normalize_folded or conditioned or stacked or variants_run" 2>&1 | grep -v Warning | tee $OUT/newtests5b_pytest.txt | tail -40 ;;
+detcold)
+  TA_DETERMINISTIC=1 timeout 900 python tools/cold_start.py --modes immediate,immediate:warm --root /tmp/ta_cold_det 2> $OUT/cold_start_det.err | tee $OUT/cold_start_deterministic.jsonl ;;
 esac
 done
 du -sh $OUT

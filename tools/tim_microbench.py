@@ -16,9 +16,20 @@ for n in sizes:
     o = torch.empty_like(g[0])
     w = torch.rand(15, 15, device="cuda")
     w = (w / w.sum()).contiguous()
+    def tiles(fn):
+        """the same call with the round-2..4 tile kernels (TA_DIM_BAND=0) instead of the round-5 row-band kernels"""
+        def call(i):
+            os.environ["TA_DIM_BAND"] = "0"
+            try:
+                fn(i)
+            finally:
+                os.environ.pop("TA_DIM_BAND")
+        return call
+    fwd = lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
+    bwd = lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
     for name, call in (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                       ("dim_fwd", lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)),
-                       ("dim_bwd", lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5))):
+                       ("dim_fwd (row bands)", fwd), ("dim_bwd (row bands)", bwd),
+                       ("dim_fwd (tiles, TA_DIM_BAND=0)", tiles(fwd)), ("dim_bwd (tiles, TA_DIM_BAND=0)", tiles(bwd))):
         for i in range(6):
             call(i)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
