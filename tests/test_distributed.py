@@ -500,3 +500,13 @@ def test_main_cli_coalesced_batches_equal_reference_batches(tmp_path, monkeypatc
     _cli(str(tmp_path / "data"), str(tmp_path / "dim_k4"), "dim", "toy_cnn", "--coalesce", "4", "--profile")
     line = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
     assert line["reference_batches_per_device_batch"] == 1
+
+
+def test_world2_readiness_script_over_gloo():
+    """tests/tools/world2_child.py -- what tests/test_hip_rccl.py::test_world2_over_rccl runs on two GPUs over RCCL -- over
+    gloo, the kernels from their host build in both ranks: the script's logic is exercised here, so the first node with
+    two devices meets known-good code."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_hip_rccl as R
+    for rank, (rc, text) in enumerate(R._world2("gloo", timeout=1200)):
+        assert rc == 0 and "world-2 rank %d ok (gloo)" % rank in text, text[-4000:]

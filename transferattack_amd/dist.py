@@ -160,7 +160,14 @@ class ShardedEnsemble(nn.Module):
         self.mode = mode
         self.type_name = 'ensemble'
         self.device = next(local_model.parameters()).device
-        self.index = dist.get_group_rank(group, dist.get_rank()) if group is not None else dist.get_rank()
+        self._index = None                      # this member's place in the stack: only mode 'ind' needs it (resolved lazily,
+                                                # so constructing the module needs no process group)
+
+    @property
+    def index(self):
+        if self._index is None:
+            self._index = dist.get_group_rank(self.group, dist.get_rank()) if self.group is not None else dist.get_rank()
+        return self._index
 
     def forward(self, x):
         if x.requires_grad:

@@ -118,6 +118,12 @@ class _ResizeNormalizeFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+def _observed(module):
+    """does anybody watch this module's calls (forward / pre / backward hooks)?  Then its own forward must run."""
+    return bool(module._forward_hooks or module._forward_pre_hooks or module._backward_hooks
+                or getattr(module, "_backward_pre_hooks", None))
+
+
 class PreprocessingModel(nn.Module):
     """normalize(resize(x)) in front of the backbone -- utils.py:72-79."""
 
@@ -130,7 +136,8 @@ class PreprocessingModel(nn.Module):
         size = self.resize.size
         if (x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2] < size and 2 * size <= 3 * x.shape[-1]
                 and max(size, x.shape[-1]) <= 1024 and os.environ.get("TA_RESIZE_KERNEL", "1") != "0"
-                and not (self.resize._forward_hooks or self.normalize._forward_hooks)):
+                and x.shape[1] == self.normalize.mean.numel() == self.normalize.std.numel()      # else: the modules' broadcast error
+                and not any(_observed(m) for m in (self.resize, self.normalize))):
             # the attack path of a 299-pixel member: one fused kernel each way instead of F.interpolate + Normalize
             return _ResizeNormalizeFn.apply(x, self.normalize.mean.reshape(-1).contiguous(),
                                             self.normalize.std.reshape(-1).contiguous(), size)
