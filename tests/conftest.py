@@ -44,6 +44,7 @@ _GPU_TIERS = (
     ("test_hip_rccl.py", None, 5),
     ("test_hip_configs.py", None, 6),
     ("test_hip_asr1000.py", None, 7),
+    ("test_hip_asr_trained.py", None, 7),
 )
 
 
