@@ -84,7 +84,8 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      /* only used on wave-uniform values */
 #define __builtin_assume(cond) ((void)0)
-namespace hipcpu { int wave_any(int pred); void mfma_f32_16x16x4(float a, float b, float (&c)[4]); }
+namespace hipcpu { int wave_any(int pred); int readlane(int v, int src); void mfma_f32_16x16x4(float a, float b, float (&c)[4]); }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipcpu::readlane(v, lane); }   /* every live lane calls it */
 struct f32x4 {                                   /* clang's ext_vector_type(4) float: .x/.y/.z/.w and [] */
     float x, y, z, w;
     float& operator[](int i) { return (&x)[i]; }

@@ -1,4 +1,5 @@
 // TEST INFRASTRUCTURE -- runtime half of tests/hipcpu/hip/hip_runtime.h (see there).
+#include <cstring>
 #include <stdarg.h>
 #include <stdio.h>
 #include <sys/mman.h>
@@ -189,6 +190,21 @@ void mfma_f32_16x16x4(float a, float b, float (&c)[4]) {
     wave_barrier(w, wave);
     for (unsigned reg = 0; reg < 4; ++reg)
         for (unsigned k = 0; k < 4; ++k) c[reg] = fmaf(arow[reg][k], bcol[k], c[reg]);
+}
+
+// v_readlane_b32: every (live) lane of the wave calls it with the same source lane and gets that lane's value
+int readlane(int v, int src) {
+    Worker* w = worker;
+    const unsigned t = w->current, wave = t / 64, lane = t & 63;
+    float bits;
+    memcpy(&bits, &v, 4);
+    w->slots[64 * wave + lane] = bits;
+    wave_barrier(w, wave);
+    const float got = w->slots[64 * wave + (static_cast<unsigned>(src) & 63u)];
+    wave_barrier(w, wave);
+    int out;
+    memcpy(&out, &got, 4);
+    return out;
 }
 
 int wave_any(int pred) {                                  // every lane of the wave must call it (as on the device)

@@ -280,16 +280,20 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
 //     WHEN, a uniform select decides WHICH of the two newest source rows is the first operand: no dynamic register index;
 //   * the one HORIZONTAL exchange (H2 reads its two padded columns from other lanes) goes through LDS: one barrier.
 // Same four fused-multiply-add expressions in the same order as the kernels above (ATen's: width first, then height): same bits.
+// wave-uniform row tables without memory: lane l of every wave HOLDS the entry of row l in its registers (a band has fewer
+// than 64 rows) and v_readlane_b32 fetches the entry of the -- wave-uniform -- row the loop is at: a few cycles, where an LDS
+// table cost a round trip per row inside a serial loop (the first version of these kernels, profiles/r05: 2 x slower than
+// the tile kernels for that reason alone)
+__device__ __forceinline__ int lane_get(int v, int row) { return __builtin_amdgcn_readlane(v, row); }
+__device__ __forceinline__ float lane_get(float v, int row) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), row)); }
+
 template <int R, int MH, int SH>      // output rows per band; bounds of the padded-window rows / x rows behind a band
 __global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __restrict__ x, float* __restrict__ y, int size,
                                                               int resize, int rnd, int top, int left, float scale1,
                                                               float scale2, int bands) {
-    __shared__ int r1_i0[MH], r1_i1[MH];                 // window row p -> x rows (first resample), valid rows only
-    __shared__ float r1_l0[MH], r1_l1[MH];
-    __shared__ int r2_i0[R], r2_i1[R];                   // output row r -> window rows (second resample)
-    __shared__ float r2_l0[R], r2_l1[R];
+    static_assert(MH <= 64 && R <= 64, "one lane per row of the tables");
     __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];       // the zero-padded, rescaled window: [p][padded column]
-    const int t = static_cast<int>(threadIdx.x);
+    const int t = static_cast<int>(threadIdx.x), lane = t & 63;
     const int plane = static_cast<int>(blockIdx.x) / bands;
     const int band = static_cast<int>(blockIdx.x) - plane * bands;
     const int oy0 = band * R, th = min(R, size - oy0);
@@ -303,17 +307,10 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __res
     const bool any_rows = p_a <= p_b;
     const int sr_lo = any_rows ? make_tap_scaled(py_lo + p_a - top, size, scale1).i0 : 0;
     const int sr_hi = any_rows ? make_tap_scaled(py_lo + p_b - top, size, scale1).i1 : 0;     // sr_hi - sr_lo < SH (host-checked)
-    if (t < th) {
-        const Tap tp = make_tap_scaled(oy0 + t, resize, scale2);
-        r2_i0[t] = tp.i0 - py_lo; r2_i1[t] = tp.i1 - py_lo; r2_l0[t] = tp.l0; r2_l1[t] = tp.l1;
-    }
-    {
-        const int p = t - 64;                                             // waves 1.. build the window's row table
-        if (p >= p_a && p <= p_b) {
-            const Tap tp = make_tap_scaled(py_lo + p - top, size, scale1);
-            r1_i0[p] = tp.i0 - sr_lo; r1_i1[p] = tp.i1 - sr_lo; r1_l0[p] = tp.l0; r1_l1[p] = tp.l1;
-        }
-    }
+    // -- row tables, one row per lane: window row `lane` -> x rows; output row `lane` -> window rows
+    const Tap row1 = make_tap_scaled(min(max(py_lo + lane - top, 0), rnd - 1), size, scale1);
+    const Tap row2 = make_tap_scaled(min(oy0 + lane, size - 1), resize, scale2);
+    const int r1_i0 = row1.i0 - sr_lo, r1_i1 = row1.i1 - sr_lo, r2_i0 = row2.i0 - py_lo, r2_i1 = row2.i1 - py_lo;
     // -- this lane's columns: padded column t (first resample), output column t (second resample)
     const int rx = t - left;
     const bool col_ok = t < resize && rx >= 0 && rx < rnd;
@@ -333,7 +330,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __res
             xb[j] = *reinterpret_cast<const float*>(base + (row + c1));
         }
     }
-    __syncthreads();                                                      // the row tables are ready
     // -- H1 + V1 down the lane's padded column: mid[p][t]
     {
         float* out = mid + t;
@@ -344,11 +340,9 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __res
         for (int j = 0; j < SH; ++j) {
             const float t_cur = fmaf(tx1.l0, xa[j], tx1.l1 * xb[j]);      // H1: row sr_lo + j of x at this lane's column
             while (p <= p_b) {
-                const int i1 = __builtin_amdgcn_readfirstlane(r1_i1[p]);
-                if (i1 > j) break;                                        // needs a row of x not reached yet
-                const int i0 = __builtin_amdgcn_readfirstlane(r1_i0[p]);
-                const float a = i0 == j ? t_cur : t_prev;                 // i0 is j or j - 1 (taps are monotone, i1 - i0 <= 1)
-                const float v = fmaf(r1_l0[p], a, r1_l1[p] * t_cur);      // V1
+                if (lane_get(r1_i1, p) > j) break;                        // needs a row of x not reached yet
+                const float a = lane_get(r1_i0, p) == j ? t_cur : t_prev; // i0 is j or j - 1 (taps are monotone, i1 - i0 <= 1)
+                const float v = fmaf(lane_get(row1.l0, p), a, lane_get(row1.l1, p) * t_cur);      // V1
                 out[p * kBlock] = col_ok ? v : 0.0f;                      // zero padding left / right of the image
                 ++p;
             }
@@ -357,25 +351,30 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __res
         for (p = max(p_b + 1, p_a); p < mh; ++p) out[p * kBlock] = 0.0f;  // zero padding below
     }
     __syncthreads();
-    // -- H2 + V2 down the lane's output column
-    if (t < size) {
-        const float* m0 = mid + tx2.i0;
-        const float* m1 = mid + tx2.i1;
+    // -- H2 + V2 down the lane's output column (every lane walks the loop -- the row tables live in all of them -- and only
+    // the lanes that own an output column store)
+    {
+        float ma[MH], mb[MH];                                             // the lane's two window columns, all rows, up front
+#pragma unroll
+        for (int p = 0; p < MH; ++p) {
+            ma[p] = mid[p * kBlock + tx2.i0];                             // (rows >= mh: in bounds, never used)
+            mb[p] = mid[p * kBlock + tx2.i1];
+        }
         char* base = reinterpret_cast<char*>(yp);
-        unsigned out = static_cast<unsigned>(oy0 * size + t) * 4u;
+        unsigned out = static_cast<unsigned>(oy0 * size + min(t, size - 1)) * 4u;
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        const bool owns = t < size;
         int r = 0;
         float u_prev = 0.0f;
 #pragma unroll
         for (int p = 0; p < MH; ++p) {
             if (p < mh) {                                                 // (uniform)
-                const float u_cur = fmaf(tx2.l0, m0[p * kBlock], tx2.l1 * m1[p * kBlock]);      // H2: window row p
+                const float u_cur = fmaf(tx2.l0, ma[p], tx2.l1 * mb[p]);  // H2: window row p
                 while (r < th) {
-                    const int i1 = __builtin_amdgcn_readfirstlane(r2_i1[r]);
-                    if (i1 > p) break;
-                    const int i0 = __builtin_amdgcn_readfirstlane(r2_i0[r]);
-                    const float a = i0 == p ? u_cur : u_prev;
-                    *reinterpret_cast<float*>(base + out) = fmaf(r2_l0[r], a, r2_l1[r] * u_cur);  // V2
+                    if (lane_get(r2_i1, r) > p) break;
+                    const float a = lane_get(r2_i0, r) == p ? u_cur : u_prev;
+                    const float v = fmaf(lane_get(row2.l0, r), a, lane_get(row2.l1, r) * u_cur);   // V2
+                    if (owns) *reinterpret_cast<float*>(base + out) = v;
                     out += row_bytes;
                     ++r;
                 }
@@ -756,23 +755,28 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __res
                                                               float* __restrict__ ws, int size, int resize, int rnd, int top,
                                                               int left, float scale1, float scale2, int bands, int ws_tiles) {
     constexpr int SA = 2, SB = 3;
-    __shared__ __attribute__((aligned(16))) Hit rowB[R];                // band row iy          -> rescaled rows
-    __shared__ __attribute__((aligned(16))) Hit rowA[MH];               // window row (padded)  -> output rows
+    static_assert(MH <= 64 && R <= 64, "one lane per row of the tables");
     __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];     // d(rescaled) window: [p][rescaled column]
     __shared__ float red[kBlock / kWave];
-    const int t = static_cast<int>(threadIdx.x);
+    const int t = static_cast<int>(threadIdx.x), lane = t & 63;
     const int plane = static_cast<int>(blockIdx.x) / bands;
     const int band = static_cast<int>(blockIdx.x) - plane * bands;
     const int iy0 = band * R, th = min(R, size - iy0);
     const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
     char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
 
-    // -- window of d(rescaled) rows behind the band (uniform), then the two row tables
+    // -- window of d(rescaled) rows behind the band (uniform)
     const Hit h_first = find_hits(iy0, size, rnd, scale1), h_last = find_hits(iy0 + th - 1, size, rnd, scale1);
     const int ry_lo = h_first.first, ry_hi = h_last.first + h_last.n - 1;
     const int mh = ry_hi - ry_lo + 1;                                   // 1 .. MH (host-checked)
-    if (t < th) rowB[t] = find_hits(iy0 + t, size, rnd, scale1);
-    if (t >= 64 && t - 64 < mh) rowA[t - 64] = find_hits(ry_lo + (t - 64) + top, resize, size, scale2);
+    // -- gy rows behind the window (uniform): first hit of its first row .. last hit of its last row
+    const Hit a_first = find_hits(ry_lo + top, resize, size, scale2), a_last = find_hits(ry_hi + top, resize, size, scale2);
+    const int oy_lo = a_first.first, oy_hi = max(a_last.first + a_last.n - 1, oy_lo);          // oy_hi - oy_lo < OH (host-checked)
+    // -- row tables, one row per lane (lane_get): band row `lane` of gx -> rescaled rows; window row `lane` -> output rows
+    const Hit rowB = find_hits(min(iy0 + lane, size - 1), size, rnd, scale1);
+    const Hit rowA = find_hits(min(ry_lo + lane, ry_hi) + top, resize, size, scale2);
+    const int rowA_first = rowA.first - oy_lo, rowB_first = rowB.first - ry_lo;
+    const int rowA_both = static_cast<int>(rowA.both), rowB_both = static_cast<int>(rowB.both);
     // -- this lane's columns
     Hit hxa = find_hits(min(t, rnd - 1) + left, resize, size, scale2);  // stage A: rescaled column t -> output columns
     if (t >= rnd) hxa.n = 0;
@@ -780,9 +784,6 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __res
     if (t >= size) { hxb.n = 0; hxb.both = 0u; }
     const bool any_both_xa = __builtin_amdgcn_readfirstlane(__any(hxa.both != 0u)) != 0;
     const bool any_both_xb = __builtin_amdgcn_readfirstlane(__any(hxb.both != 0u)) != 0;
-    // -- gy rows behind the window (uniform): first hit of its first row .. last hit of its last row
-    const Hit a_first = find_hits(ry_lo + top, resize, size, scale2), a_last = find_hits(ry_hi + top, resize, size, scale2);
-    const int oy_lo = a_first.first, oy_hi = max(a_last.first + a_last.n - 1, oy_lo);          // oy_hi - oy_lo < OH (host-checked)
     // -- all loads of the lane, back to back
     float ga[OH], gb[OH];
     {
@@ -795,7 +796,6 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __res
             gb[j] = *reinterpret_cast<const float*>(gyp + (row + c1));
         }
     }
-    __syncthreads();                                                    // the row tables are ready
     // -- stage A down the lane's rescaled column: mid[p][t]
     {
         float* out = mid + t;
@@ -804,23 +804,23 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < OH; ++j) {
             while (p < mh) {
-                const Hit* hy = &rowA[p];
-                const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - oy_lo;
-                const int n_y = __builtin_amdgcn_readfirstlane(hy->n);                 // <= SA
+                const int first_y = lane_get(rowA_first, p), n_y = lane_get(rowA.n, p);          // n_y <= SA
                 if (first_y + n_y - 1 > j) break;                        // its last hit row has not arrived
-                const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+                const unsigned both_y = static_cast<unsigned>(lane_get(rowA_both, p));
                 float acc = 0.0f;
 #pragma unroll
                 for (int ky = 0; ky < SA; ++ky)
                     if (ky < n_y) {
                         const bool cur = first_y + ky == j;              // the hit row is row j or row j - 1 (uniform)
                         const float g0 = cur ? ga[j] : pa, g1 = cur ? gb[j] : pb;
+                        const float wy = lane_get(rowA.w[ky], p);
                         if (!any_both_xa && both_y == 0u) {
-                            acc = hit_accumulate<true>(acc, g0, hy->w[ky], 0.0f, false, hxa, 0);
-                            acc = hit_accumulate<true>(acc, g1, hy->w[ky], 0.0f, false, hxa, 1);
+                            acc = hit_accumulate<true>(acc, g0, wy, 0.0f, false, hxa, 0);
+                            acc = hit_accumulate<true>(acc, g1, wy, 0.0f, false, hxa, 1);
                         } else {
-                            acc = hit_accumulate<false>(acc, g0, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxa, 0);
-                            acc = hit_accumulate<false>(acc, g1, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxa, 1);
+                            const float wy2 = lane_get(rowA.w2[ky], p);
+                            acc = hit_accumulate<false>(acc, g0, wy, wy2, (both_y >> ky) & 1u, hxa, 0);
+                            acc = hit_accumulate<false>(acc, g1, wy, wy2, (both_y >> ky) & 1u, hxa, 1);
                         }
                     }
                 out[p * kBlock] = acc;
@@ -831,43 +831,50 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __res
         }
     }
     __syncthreads();
-    // -- stage B down the lane's column of gx
+    // -- stage B down the lane's column of gx (every lane walks the loop: the row tables live in all of them)
     float asum = 0.0f;
     {
         int col[SB];
 #pragma unroll
-        for (int k = 0; k < SB; ++k) col[k] = min(max(hxb.first - 0, 0) + k, rnd - 1);       // rescaled columns = LDS columns
+        for (int k = 0; k < SB; ++k) col[k] = min(max(hxb.first, 0) + k, rnd - 1);            // rescaled columns = LDS columns
+        // the lane's three rescaled columns of window row p, a rolling window of three rows in registers; row p + 1 is read
+        // from LDS while row p is consumed (a depth-1 software pipeline: the loop never waits for the row it needs)
+        float m0[SB], m1[SB] = {0.0f, 0.0f, 0.0f}, m2[SB] = {0.0f, 0.0f, 0.0f}, nxt[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) nxt[k] = mid[col[k]];
         unsigned out = static_cast<unsigned>(iy0 * size + min(t, size - 1)) * 4u;
         const unsigned row_bytes = 4u * static_cast<unsigned>(size);
+        const bool owns = t < size;
         int r = 0;
-        float m1[SB] = {0.0f, 0.0f, 0.0f}, m2[SB] = {0.0f, 0.0f, 0.0f};     // window rows p - 1, p - 2 at the lane's columns
 #pragma unroll
         for (int p = 0; p < MH; ++p) {
             if (p < mh) {                                                // (uniform)
-                float m0[SB];
 #pragma unroll
-                for (int k = 0; k < SB; ++k) m0[k] = mid[p * kBlock + col[k]];
+                for (int k = 0; k < SB; ++k) {
+                    m0[k] = nxt[k];
+                    if (p + 1 < MH) nxt[k] = mid[(p + 1) * kBlock + col[k]];                    // (rows >= mh: in bounds, never used)
+                }
                 while (r < th) {
-                    const Hit* hy = &rowB[r];
-                    const int first_y = __builtin_amdgcn_readfirstlane(hy->first) - ry_lo;
-                    const int n_y = __builtin_amdgcn_readfirstlane(hy->n);             // 1 .. SB
+                    const int first_y = lane_get(rowB_first, r), n_y = lane_get(rowB.n, r);      // 1 .. SB
                     if (first_y + n_y - 1 > p) break;
-                    const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
+                    const unsigned both_y = static_cast<unsigned>(lane_get(rowB_both, r));
                     float acc = 0.0f;
 #pragma unroll
                     for (int ky = 0; ky < SB; ++ky)
                         if (ky < n_y) {
                             const int back = p - (first_y + ky);         // 0, 1 or 2 rows ago (uniform)
+                            const float wy = lane_get(rowB.w[ky], r);
+                            const float wy2 = (!any_both_xb && both_y == 0u) ? 0.0f : lane_get(rowB.w2[ky], r);
 #pragma unroll
                             for (int kx = 0; kx < SB; ++kx) {
                                 const float g = back == 0 ? m0[kx] : (back == 1 ? m1[kx] : m2[kx]);
                                 if (!any_both_xb && both_y == 0u)
-                                    acc = hit_accumulate<true>(acc, g, hy->w[ky], 0.0f, false, hxb, kx);
+                                    acc = hit_accumulate<true>(acc, g, wy, 0.0f, false, hxb, kx);
                                 else
-                                    acc = hit_accumulate<false>(acc, g, hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hxb, kx);
+                                    acc = hit_accumulate<false>(acc, g, wy, wy2, (both_y >> ky) & 1u, hxb, kx);
                             }
                         }
-                    if (t < size) {
+                    if (owns) {
                         *reinterpret_cast<float*>(gxp + out) = acc;
                         asum += fabsf(acc);
                     }
@@ -1056,15 +1063,21 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     {
         const char* env = getenv("TA_DIM_BAND");
         if (resize <= kBlock && rnd >= size && resize >= size && (env == nullptr || atoi(env) != 0)) {
-            constexpr int R = 32, MH = 40, SH = 40;
+            constexpr int R = 32;
             int mh_max, sh_max;
             fwd_band_bounds(size, resize, rnd, top, R, &mh_max, &sh_max);
             const int bands = static_cast<int>(ceil_div(size, R));
-            if (mh_max <= MH && sh_max <= SH && planes * bands < (1ll << 31)) {
-                const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
-                const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
-                hipLaunchKernelGGL((dim_fwd_band_kernel<R, MH, SH>), dim3(static_cast<unsigned>(planes * bands)), dim3(kBlock), 0, st,
-                                   x, y, size, resize, rnd, top, left, scale1, scale2, bands);
+            const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
+            const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+            const dim3 grid(static_cast<unsigned>(planes * bands));
+            if (planes * bands < (1ll << 31) && mh_max <= 36 && sh_max <= 37) {      // 224 -> 246: 36 KB of LDS, 4 workgroups per CU
+                hipLaunchKernelGGL((dim_fwd_band_kernel<R, 36, 37>), grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, bands);
+                return check_launch("dim_fwd_band");
+            }
+            if (planes * bands < (1ll << 31) && mh_max <= 40 && sh_max <= 40) {
+                hipLaunchKernelGGL((dim_fwd_band_kernel<R, 40, 40>), grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
+                                   scale1, scale2, bands);
                 return check_launch("dim_fwd_band");
             }
         }
@@ -1154,16 +1167,23 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
         const char* env = getenv("TA_DIM_BAND");
         if (resize <= kBlock && rnd >= size && resize > size && (env == nullptr || atoi(env) != 0) &&
             max_hits(size, rnd) <= 3 && max_hits(resize, size) <= 2) {
-            constexpr int R = 32, MH = 40, OH = 40;
+            constexpr int R = 32;
             int mh_max, oh_max;
             bwd_band_bounds(size, resize, rnd, top, R, &mh_max, &oh_max);
             const int bands = static_cast<int>(ceil_div(size, R));
             const int64_t ws_tiles = ta_dim_bwd_tiles_impl(size, resize);
-            if (mh_max <= MH && oh_max <= OH && planes * bands < (1ll << 31) && ws_tiles >= bands && ws_tiles < (1 << 30)) {
-                const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
-                const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
-                hipLaunchKernelGGL((dim_bwd_band_kernel<R, MH, OH>), dim3(static_cast<unsigned>(planes * bands)), dim3(kBlock), 0, st,
-                                   gy, gx, ws, size, resize, rnd, top, left, scale1, scale2, bands, static_cast<int>(ws_tiles));
+            const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
+            const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
+            const dim3 grid(static_cast<unsigned>(planes * bands));
+            const bool fits = planes * bands < (1ll << 31) && ws_tiles >= bands && ws_tiles < (1 << 30);
+            if (fits && mh_max <= 37 && oh_max <= 35) {                             // 224 -> 246: 37 KB of LDS, 4 workgroups per CU
+                hipLaunchKernelGGL((dim_bwd_band_kernel<R, 37, 35>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, left,
+                                   scale1, scale2, bands, static_cast<int>(ws_tiles));
+                return check_launch("dim_bwd_band");
+            }
+            if (fits && mh_max <= 40 && oh_max <= 40) {
+                hipLaunchKernelGGL((dim_bwd_band_kernel<R, 40, 40>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, left,
+                                   scale1, scale2, bands, static_cast<int>(ws_tiles));
                 return check_launch("dim_bwd_band");
             }
         }
