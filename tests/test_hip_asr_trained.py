@@ -13,7 +13,7 @@ Asserted per victim ("vs label" rows, the white-box row included when it is belo
   * the review's ONE-sample bound |ASR_gpu - ASR_ref| <= 3 sqrt(p (1 - p) / n) + 1 / n -- on trained, well-conditioned toy
     networks the two trajectories stay correlated, so the strict bound holds (it is ~2 sigma of the paired difference only
     when they decorrelate, as on the random-init ResNet-50);
-  * first-iteration gradient signs equal to the reference's in >= 99.9 %."""
+First-iteration gradient sign agreement is printed only (see the end of the test)."""
 import os
 import time
 import zlib
@@ -110,4 +110,7 @@ def test_asr_against_trained_victims(monkeypatch, config, fold_normalize):
         if asserted:
             assert r["p_value"] >= A.P_MIN, r
             assert abs(r["p_gpu"] - r["p_ref"]) <= bound, r
-    assert informative >= 2 and agree >= 0.999
+    # (the sign agreement is printed, not asserted: a trained network is saturated on its clean inputs -- loss ~1e-6, softmax
+    # gradient p - onehot at the resolution of fp32 -- so the FIRST gradient is rounding noise on any implementation, the
+    # reference's own CPU path at another thread count included; from the second iteration on the loss is O(1))
+    assert informative >= 2
