@@ -41,7 +41,6 @@ def test_trained_victims_fixture_is_consistent(config):
     """tests/golden/asr_trained_<config>.npz + trained_toys.npz (oracle/gen_asr_trained.py): the committed weights classify the
     regenerated clean test images correctly (so main.py:90's literal rate is a transfer rate), the image set is the one the
     reference attacked (CRC), and the reference's rates are informative for the three held-out victims."""
-    import zlib
     import gen_asr_trained as T
     path = os.path.join(GOLDEN_DIR, "asr_trained_%s.npz" % config)
     if not (os.path.isfile(path) and os.path.isfile(T.TOYS)):
@@ -49,11 +48,8 @@ def test_trained_victims_fixture_is_consistent(config):
     g = np.load(path)
     n, nets = int(g["n_images"]), [str(v) for v in g["nets"]]
     assert nets == list(T.NETS) and g["adv_pred"].shape == (len(nets), n) and int(g["batch"]) == 32
-    xu8, label = T.make_images(64, int(g["seed_images"]))
-    full_crc = zlib.crc32(T.make_images(n, int(g["seed_images"]))[0].numpy().tobytes())
+    xu8, label = T.make_images(64, int(g["seed_images"]))          # (the GPU test regenerates all 1000 and checks their CRC)
     assert np.array_equal(label.numpy(), g["label"][:64].astype(np.int64))
-    if full_crc != int(g["images_crc32"][0]):
-        pytest.skip("this host's libm renders the synthetic test set differently (CRC mismatch): the GPU test skips here too")
     for v, name in enumerate(nets):
         pred = T.predict(T.load_trained(name), xu8.float() / 255).numpy()
         assert np.array_equal(pred, g["clean_pred"][v][:64].astype(np.int64)) and (pred == label.numpy()).mean() >= 0.99

@@ -183,6 +183,10 @@ vmistack)
 newtests5b)
   timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
       -k "test_hip_kernels or normalize_folded or conditioned or stacked or variants_run" 2>&1 | grep -v Warning | tee $OUT/newtests5b_pytest.txt | tail -40 ;;
+trained)
+  timeout 900 python -m pytest tests/test_hip_asr_trained.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr_trained_pytest.txt | tail -30 ;;
+dts)
+  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json | cut -c1-1500 ;;
 detcold)
   TA_DETERMINISTIC=1 timeout 900 python tools/cold_start.py --modes immediate,immediate:warm --root /tmp/ta_cold_det 2> $OUT/cold_start_det.err | tee $OUT/cold_start_deterministic.jsonl ;;
 esac
