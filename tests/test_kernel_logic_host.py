@@ -57,6 +57,9 @@ def test_stem_kernel_leaves_the_sums(n, oh, ow):
 test_resize_normalize_kernels = G.test_resize_normalize_kernels
 
 
+test_dim_row_band_kernels = G.test_dim_row_band_kernels
+
+
 def test_bad_arguments_fail_loudly():
     """the library's own argument checks (TA_EINVAL + message) and the binding's dtype check; the device check of the
     binding is the one thing the stand-in replaces, see tests/test_host_logic.py::test_no_cpu_fallback for it"""

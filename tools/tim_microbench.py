@@ -16,20 +16,24 @@ for n in sizes:
     o = torch.empty_like(g[0])
     w = torch.rand(15, 15, device="cuda")
     w = (w / w.sum()).contiguous()
-    def tiles(fn):
-        """the same call with the round-2..4 tile kernels (TA_DIM_BAND=0) instead of the round-5 row-band kernels"""
+    def with_env(fn, **env):
+        """the same call under an environment knob of the DIM launchers (read per call)"""
         def call(i):
-            os.environ["TA_DIM_BAND"] = "0"
+            os.environ.update(env)
             try:
                 fn(i)
             finally:
-                os.environ.pop("TA_DIM_BAND")
+                for k in env:
+                    os.environ.pop(k)
         return call
     fwd = lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
     bwd = lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
     for name, call in (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                       ("dim_fwd (row bands)", fwd), ("dim_bwd (row bands)", bwd),
-                       ("dim_fwd (tiles, TA_DIM_BAND=0)", tiles(fwd)), ("dim_bwd (tiles, TA_DIM_BAND=0)", tiles(bwd))):
+                       ("dim_fwd (tiles, XCD-contiguous order: default)", fwd), ("dim_bwd (tiles, XCD-contiguous order: default)", bwd),
+                       ("dim_fwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(fwd, TA_DIM_XCD="0")),
+                       ("dim_bwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(bwd, TA_DIM_XCD="0")),
+                       ("dim_fwd (row bands, TA_DIM_BAND=1)", with_env(fwd, TA_DIM_BAND="1")),
+                       ("dim_bwd (row bands, TA_DIM_BAND=1)", with_env(bwd, TA_DIM_BAND="1"))):
         for i in range(6):
             call(i)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

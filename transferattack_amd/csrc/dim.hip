@@ -146,11 +146,23 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
+// XCD-aware tile order (MI355X: 8 XCDs, each with its own L2; the dispatcher hands workgroup b to XCD b % 8).  The tiles of a
+// plane overlap in the cache lines at their left / right edges and in the rows between bands: with the hardware's own order
+// four horizontally adjacent tiles sit on four different XCDs and every shared line is fetched from HBM four times (PMC: 1.96 x
+// the algorithmic bytes in the forward).  Logical tile id = (b % 8) * ceil(n / 8) + b / 8 gives each XCD a CONTIGUOUS run of
+// tiles -- neighbours share an L2.  `swizzle` = 0 keeps the hardware order (TA_DIM_XCD=0).
+__device__ __forceinline__ int xcd_tile(int b, int n, int swizzle) {
+    if (!swizzle) return b;
+    const int per = (n + 7) >> 3;
+    const int id = (b & 7) * per + (b >> 3);
+    return id;                                           // ids >= n (ragged last chunk) are skipped by the caller
+}
+
 template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y) {
+                                                               int tiles_y, int total, int swizzle) {
     constexpr int ROWS = 4 * RPW;
     TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
@@ -162,7 +174,8 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
     const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(blockIdx.x);
+    const int tid = xcd_tile(static_cast<int>(blockIdx.x), total, swizzle);
+    if (tid >= total) return;                                          // (the grid is padded to a multiple of 8 workgroups)
     const int plane = tid / tiles;                                     // grid < 2^31 (host-checked)
     const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
                                                                float* __restrict__ ws, int size, int resize, int rnd,
                                                                int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y) {
+                                                               int tiles_y, int total, int swizzle) {
     constexpr int ROWS = 4 * RPW;
     TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
@@ -603,7 +616,8 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = tiles_x * tiles_y;
-    const int tid = static_cast<int>(blockIdx.x);
+    const int tid = xcd_tile(static_cast<int>(blockIdx.x), total, swizzle);
+    if (tid >= total) return;                           // (the grid is padded to a multiple of 8 workgroups)
     const int group = tid / tiles;                      // PP consecutive planes share this tile's tables (the geometry
     const int t = tid - group * tiles;                  // is the same for every plane: built once, used PP times)
     const int tyi = t / tiles_x;
@@ -1022,6 +1036,12 @@ static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
 
 extern "C" int64_t ta_dim_bwd_tiles(int size, int resize) { return ta_dim_bwd_tiles_impl(size, resize); }
 
+// TA_DIM_XCD=0: the hardware's own workgroup order instead of the XCD-contiguous one (A/B measurements)
+static int xcd_order() {
+    const char* env = getenv("TA_DIM_XCD");
+    return (env == nullptr || atoi(env) != 0) ? 1 : 0;
+}
+
 // the kernels' make_tap_scaled on the host (fmaf is the exact fused operation here as well)
 static void host_tap(int o, int in_size, float scale, int* i0, int* i1) {
     float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
@@ -1062,7 +1082,7 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     // the reference draws at 224 pixels (resize_rate 1.1: resize = 246); TA_DIM_BAND=0 selects the tile kernels below
     {
         const char* env = getenv("TA_DIM_BAND");
-        if (resize <= kBlock && rnd >= size && resize >= size && (env == nullptr || atoi(env) != 0)) {
+        if (resize <= kBlock && rnd >= size && resize >= size && env != nullptr && atoi(env) != 0) {
             constexpr int R = 32;
             int mh_max, sh_max;
             fwd_band_bounds(size, resize, rnd, top, R, &mh_max, &sh_max);
@@ -1094,14 +1114,16 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             // (one plane per workgroup: sharing the forward's taps over the three planes of an image was measured slower at
             // every size, r2e / r2f: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480)
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
-            TA_REQUIRE(lane_blocks < (1ll << 31), "too many tiles");
-            const dim3 grid(static_cast<unsigned>(lane_blocks));
+            TA_REQUIRE(lane_blocks < (1ll << 31) - 8, "too many tiles");
+            const int swz = xcd_order();
+            const dim3 grid(static_cast<unsigned>(swz ? ceil_div(lane_blocks, 8) * 8 : lane_blocks));
+            const int total = static_cast<int>(lane_blocks);
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y);
+                                   scale1, scale2, tw, tiles_x, tiles_y, total, swz);
             else
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y);
+                                   scale1, scale2, tw, tiles_x, tiles_y, total, swz);
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -1165,7 +1187,7 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
     // ws keeps the tile kernels' layout (ta_dim_bwd_tiles sums per plane: the count depends on (size, resize) only)
     {
         const char* env = getenv("TA_DIM_BAND");
-        if (resize <= kBlock && rnd >= size && resize > size && (env == nullptr || atoi(env) != 0) &&
+        if (resize <= kBlock && rnd >= size && resize > size && env != nullptr && atoi(env) != 0 &&
             max_hits(size, rnd) <= 3 && max_hits(resize, size) <= 2) {
             constexpr int R = 32;
             int mh_max, oh_max;
@@ -1202,18 +1224,20 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             // when that still leaves >= 10 workgroups per CU: 116 -> 109 us at 480 planes, but 27 -> 32 us at 96 (r2e)
             const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
-            TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31), "too many tiles");
-            const dim3 grid(static_cast<unsigned>(lane_blocks));
+            TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31) - 8, "too many tiles");
+            const int swz = xcd_order();
+            const dim3 grid(static_cast<unsigned>(swz ? ceil_div(lane_blocks, 8) * 8 : lane_blocks));
+            const int total = static_cast<int>(lane_blocks);
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
             const bool two_a = max_hits(resize, size) <= 2;    // stage A: outputs per padded index (<= 2 whenever resize > size)
 #define TA_DIM_BWD_PP(RPW, SB, SA)                                                                                       \
     do {                                                                                                                 \
         if (pp == 3)                                                                                                     \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total, swz);                \
         else                                                                                                             \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total, swz);                \
     } while (0)
 #define TA_DIM_BWD(RPW, SB) do { if (two_a) TA_DIM_BWD_PP(RPW, SB, 2); else TA_DIM_BWD_PP(RPW, SB, 3); } while (0)
             if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }
