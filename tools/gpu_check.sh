@@ -175,6 +175,17 @@ dimab)
   python tools/pmc_kernels.py $OUT/dimpmc_$tag | tee -a $OUT/dimpmc_summary.txt
   done
   find $OUT -name "*.db" -delete ;;
+dimab2)
+  timeout 300 python tools/tim_microbench.py 2>&1 | tee $OUT/dim_variants.txt
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/dimtrace -o trace -- python $R/tools/tim_microbench.py > $R/$OUT/dimtrace.log 2>&1 )
+  f=$(find $OUT/dimtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dim_kernel_stats_n160.csv
+  find $OUT/dimtrace -name "*kernel_trace.csv" -delete; find $OUT/dimtrace -name "*.db" -delete
+  for v in 1 0; do
+  echo "== tile kernels, TA_DIM_XCD=$v (1 = XCD-contiguous tile order, the default; 0 = the hardware's order)" | tee -a $OUT/dimpmc_summary.txt
+  ( cd /tmp && TA_N=160 TA_DIM_VARIANTS=0 TA_DIM_XCD=$v timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/dimpmc_xcd$v -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_xcd$v.log 2>&1 )
+  python tools/pmc_kernels.py $OUT/dimpmc_xcd$v | tee -a $OUT/dimpmc_summary.txt
+  done
+  find $OUT -name "*.db" -delete ;;
 vmistack)
   # configs[3]: VMI-FGSM / ViT-B/16, k neighbour samples per surrogate evaluation
   for k in ${TA_VMI_KS:-1 5 10}; do

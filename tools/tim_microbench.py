@@ -28,12 +28,16 @@ for n in sizes:
         return call
     fwd = lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
     bwd = lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
-    for name, call in (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                       ("dim_fwd (tiles, XCD-contiguous order: default)", fwd), ("dim_bwd (tiles, XCD-contiguous order: default)", bwd),
-                       ("dim_fwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(fwd, TA_DIM_XCD="0")),
-                       ("dim_bwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(bwd, TA_DIM_XCD="0")),
-                       ("dim_fwd (row bands, TA_DIM_BAND=1)", with_env(fwd, TA_DIM_BAND="1")),
-                       ("dim_bwd (row bands, TA_DIM_BAND=1)", with_env(bwd, TA_DIM_BAND="1"))):
+    if os.environ.get("TA_DIM_VARIANTS", "1") == "0":             # counter runs: one variant per process (env set outside)
+        cases = (("dim_fwd", fwd), ("dim_bwd", bwd))
+    else:
+        cases = (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
+                 ("dim_fwd (tiles, XCD-contiguous order: default)", fwd), ("dim_bwd (tiles, XCD-contiguous order: default)", bwd),
+                 ("dim_fwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(fwd, TA_DIM_XCD="0")),
+                 ("dim_bwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(bwd, TA_DIM_XCD="0")),
+                 ("dim_fwd (row bands, TA_DIM_BAND=1)", with_env(fwd, TA_DIM_BAND="1")),
+                 ("dim_bwd (row bands, TA_DIM_BAND=1)", with_env(bwd, TA_DIM_BAND="1")))
+    for name, call in cases:
         for i in range(6):
             call(i)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
