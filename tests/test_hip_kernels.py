@@ -592,8 +592,8 @@ def test_dim_random(size, rate, geoms):
 def test_dim_row_band_kernels(golden, monkeypatch):
     """the row-band forms of the DIM pair (TA_DIM_BAND=1: one lane per column, a band of 32 rows x all columns per workgroup,
     vertical passes over compile-time source rows, row tables fetched with v_readlane) and the tile kernels in the hardware's
-    own workgroup order (TA_DIM_XCD=0): the same bits as the default kernels -- golden tensors and random geometries"""
-    for env in (dict(TA_DIM_BAND="1"), dict(TA_DIM_XCD="0")):
+    XCD-contiguous workgroup order (TA_DIM_XCD=1): the same bits as the default kernels -- golden tensors and random geometries"""
+    for env in (dict(TA_DIM_BAND="1"), dict(TA_DIM_XCD="1")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         test_dim_golden(golden)

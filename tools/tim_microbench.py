@@ -32,9 +32,9 @@ for n in sizes:
         cases = (("dim_fwd", fwd), ("dim_bwd", bwd))
     else:
         cases = (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                 ("dim_fwd (tiles, XCD-contiguous order: default)", fwd), ("dim_bwd (tiles, XCD-contiguous order: default)", bwd),
-                 ("dim_fwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(fwd, TA_DIM_XCD="0")),
-                 ("dim_bwd (tiles, hardware order, TA_DIM_XCD=0)", with_env(bwd, TA_DIM_XCD="0")),
+                 ("dim_fwd (tiles, hardware order: default)", fwd), ("dim_bwd (tiles, hardware order: default)", bwd),
+                 ("dim_fwd (tiles, XCD-contiguous order, TA_DIM_XCD=1)", with_env(fwd, TA_DIM_XCD="1")),
+                 ("dim_bwd (tiles, XCD-contiguous order, TA_DIM_XCD=1)", with_env(bwd, TA_DIM_XCD="1")),
                  ("dim_fwd (row bands, TA_DIM_BAND=1)", with_env(fwd, TA_DIM_BAND="1")),
                  ("dim_bwd (row bands, TA_DIM_BAND=1)", with_env(bwd, TA_DIM_BAND="1")))
     for name, call in cases:

@@ -150,7 +150,7 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
 // plane overlap in the cache lines at their left / right edges and in the rows between bands: with the hardware's own order
 // four horizontally adjacent tiles sit on four different XCDs and every shared line is fetched from HBM four times (PMC: 1.96 x
 // the algorithmic bytes in the forward).  Logical tile id = (b % 8) * ceil(n / 8) + b / 8 gives each XCD a CONTIGUOUS run of
-// tiles -- neighbours share an L2.  `swizzle` = 0 keeps the hardware order (TA_DIM_XCD=0).
+// tiles -- neighbours share an L2.  `swizzle` = 0 keeps the hardware order (the default: see xcd_order below).
 __device__ __forceinline__ int xcd_tile(int b, int n, int swizzle) {
     if (!swizzle) return b;
     const int per = (n + 7) >> 3;
@@ -1036,10 +1036,13 @@ static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
 
 extern "C" int64_t ta_dim_bwd_tiles(int size, int resize) { return ta_dim_bwd_tiles_impl(size, resize); }
 
-// TA_DIM_XCD=0: the hardware's own workgroup order instead of the XCD-contiguous one (A/B measurements)
+// TA_DIM_XCD=1: the XCD-contiguous tile order instead of the hardware's own.  Measured (r5d, N = 160): it removes the
+// over-fetch entirely (FETCH_SIZE forward 184 -> 94 MB, backward 137 -> 91 MB = 1.0 x the algorithmic bytes) and buys NOTHING --
+// forward 54.9 vs 48.8 us, backward 95.5 vs 95.9 us: the redundant lines came from the Infinity Cache, the kernels are not
+// bandwidth-bound.  Off by default; kept as the measurement's switch.
 static int xcd_order() {
     const char* env = getenv("TA_DIM_XCD");
-    return (env == nullptr || atoi(env) != 0) ? 1 : 0;
+    return (env != nullptr && atoi(env) != 0) ? 1 : 0;
 }
 
 // the kernels' make_tap_scaled on the host (fmaf is the exact fused operation here as well)
