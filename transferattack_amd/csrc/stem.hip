@@ -10,13 +10,12 @@
 //   M = output positions (n, i, j) on the dy grid,   K = 16 window taps x 64 channels = 1024,   N = 4 phases x 3 channels = 12 (-> 16)
 //
 // on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fixed-order fp32 accumulation, deterministic -- no
-// atomics).  A workgroup owns 4 rows x 32 columns of positions; the 7 x 35 window of dy behind them is staged in LDS in two
-// halves of 32 channels (pixel stride 36 dwords: the eight lanes of a 16-byte read group fall on 32 distinct banks; 35 KB, so
-// four workgroups fit a CU -- the one-pass 67 KB window of rounds 3-4 allowed two), each wave owns one row = two
-// 16-position tiles, and per tap and half reads its A operands with two ds_read_b128 per tile (a lane's eight k-values are
-// contiguous channels: K is enumerated as channel = 32 * half + 8 * kk + s for MFMA step s, lane quarter kk).  The B operand
-// -- the prepared weights W2[half][tap][s][kk][col], 64 KB, built once per model by ta_stem7s2_prepare -- is read straight
-// from L2: 64 consecutive floats per MFMA, one coalesced load per wave.  dy: channels_last [N, OH, OW, 64]; dx: NCHW [N, 3, 2*OH, 2*OW].
+// atomics).  A workgroup owns 4 rows x 32 columns of positions; the 7 x 35 x 64 window of dy behind them is staged ONCE in
+// LDS (row stride 68 dwords: the eight lanes of a 16-byte read group fall on 32 distinct banks), each wave owns one row =
+// two 16-position tiles, and per tap reads its A operands with four ds_read_b128 per tile (a lane's sixteen k-values are
+// contiguous channels: K is enumerated as channel = 16 * kk + s for MFMA step s, lane quarter kk).  The B operand -- the
+// prepared weights W2[tap][s][kk][col], 64 KB, built once per model by ta_stem7s2_prepare -- is read straight from
+// L2: 64 consecutive floats per MFMA, one coalesced load per wave.  dy: channels_last [N, OH, OW, 64]; dx: NCHW [N, 3, 2*OH, 2*OW].
 // Useful work is 49/64 of the taps and 12/16 of the columns: 57 % of the MFMA slots.
 #include "ta_common.h"
 
@@ -26,12 +25,8 @@ constexpr int kStemRows = 4;                    // output-position rows per work
 constexpr int kStemCols = 32;                   // output-position columns per workgroup (two 16-row MFMA tiles per wave)
 constexpr int kStemWinRows = kStemRows + 3;     // dy rows behind them
 constexpr int kStemWinCols = kStemCols + 3;
+constexpr int kStemLd = 68;                     // dwords per staged dy pixel (64 channels + 4: bank spread)
 constexpr int kStemK = 64;                      // output channels of the convolution = K per tap
-constexpr int kStemHalf = 32;                   // channels staged at a time (round 5): the window is 35 KB instead of 67 KB, so
-                                                // FOUR workgroups share a CU's 160 KB of LDS instead of two -- one stages or
-                                                // waits for its weights while the others multiply
-constexpr int kStemLd = kStemHalf + 4;          // dwords per staged dy pixel (32 channels + 4: the eight lanes of a 16-byte read
-                                                // group -- consecutive pixels, stride 36 -- fall on 32 distinct banks)
 
 typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,18 +38,17 @@ __device__ __forceinline__ stem_f32x4 stem_mfma(float a, float b, stem_f32x4 c) 
 #endif
 }
 
-// W2[half][tap = a*4+b][s < 8][kk][col]  <-  w[k = 32*half + 8*kk + s][c][ky = 5-2a+py][kx = 5-2b+px],
-// col = (py*2 + px)*3 + c  (12..15: zero)
+// W2[tap = a*4+b][s][kk][col]  <-  w[k = 16*kk + s][c][ky = 5-2a+py][kx = 5-2b+px],  col = (py*2 + px)*3 + c  (12..15: zero)
 __global__ __launch_bounds__(kBlock) void stem7s2_prepare_kernel(const float* __restrict__ w, float* __restrict__ w2) {
-    const int idx = blockIdx.x * kBlock + threadIdx.x;          // one thread per W2 element: 2 * 16 * 8 * 4 * 16 = 16384
+    const int idx = blockIdx.x * kBlock + threadIdx.x;          // one thread per W2 element: 16 * 16 * 4 * 16 = 16384
     if (idx >= 16 * 16 * 4 * 16) return;
-    const int col = idx & 15, kk = (idx >> 4) & 3, s = (idx >> 6) & 7, tap = (idx >> 9) & 15, half = idx >> 13;
+    const int col = idx & 15, kk = (idx >> 4) & 3, s = (idx >> 6) & 15, tap = idx >> 10;
     const int a = tap >> 2, b = tap & 3;
     float v = 0.0f;
     if (col < 12) {
         const int c = col % 3, px = (col / 3) & 1, py = col / 6;
         const int ky = 5 - 2 * a + py, kx = 5 - 2 * b + px;
-        if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w[((kStemHalf * half + 8 * kk + s) * 3 + c) * 49 + ky * 7 + kx];
+        if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w[((16 * kk + s) * 3 + c) * 49 + ky * 7 + kx];
     }
     w2[idx] = v;
 }
@@ -67,7 +61,9 @@ template <bool SUMS>
 __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float* __restrict__ dy, const float* __restrict__ w2,
                                                                     float* __restrict__ dx, int oh, int ow,
                                                                     const float* __restrict__ stdv, float* __restrict__ ws) {
-    static_assert(sizeof(float) * kStemWinRows * kStemWinCols * kStemLd <= 40 * 1024, "four workgroups per CU need <= 40 KB each");
+    // 66 640 B of LDS: more than the 64 KB of every pre-gfx950 part -- this library targets MI355X (gfx950, 160 KB per CU)
+    // only, as does philox.h's v_mad_u64_u32 path; the Makefile builds nothing else
+    static_assert(sizeof(float) * kStemWinRows * kStemWinCols * kStemLd <= 160 * 1024, "dy window exceeds gfx950's LDS");
     __shared__ __attribute__((aligned(16))) float win[kStemWinRows * kStemWinCols * kStemLd];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,43 +71,40 @@ __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float*
     const int n = static_cast<int>(blockIdx.z);
     const float* dyn = dy + static_cast<int64_t>(n) * oh * ow * kStemK;
 
+    // -- stage the dy window (rows i0-1 .. i0+5, columns j0-1 .. j0+33, zeros outside the map): one float4 per step
+    for (int q = threadIdx.x; q < kStemWinRows * kStemWinCols * (kStemK / 4); q += kBlock) {
+        const int pix = q >> 4, c4 = (q & 15) * 4;
+        const int wr = pix / kStemWinCols, wc = pix - wr * kStemWinCols;
+        const int oy = i0 - 1 + wr, ox = j0 - 1 + wc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy >= 0 && oy < oh && ox >= 0 && ox < ow)
+            v = *reinterpret_cast<const float4*>(dyn + (static_cast<int64_t>(oy) * ow + ox) * kStemK + c4);
+        *reinterpret_cast<float4*>(win + pix * kStemLd + c4) = v;
+    }
+    __syncthreads();
+
     const int m = lane & 15, kk = lane >> 4;
     stem_f32x4 acc[2];
     acc[0] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = stem_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int half = 0; half < kStemK / kStemHalf; ++half) {
-        if (half != 0) __syncthreads();                         // every wave is done with the previous half's window
-        // -- stage this half of the dy window (rows i0-1 .. i0+5, columns j0-1 .. j0+33, zeros outside the map): one float4 per step
-        for (int q = threadIdx.x; q < kStemWinRows * kStemWinCols * (kStemHalf / 4); q += kBlock) {
-            const int pix = q >> 3, c4 = (q & 7) * 4;
-            const int wr = pix / kStemWinCols, wc = pix - wr * kStemWinCols;
-            const int oy = i0 - 1 + wr, ox = j0 - 1 + wc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy >= 0 && oy < oh && ox >= 0 && ox < ow)
-                v = *reinterpret_cast<const float4*>(dyn + (static_cast<int64_t>(oy) * ow + ox) * kStemK + half * kStemHalf + c4);
-            *reinterpret_cast<float4*>(win + pix * kStemLd + c4) = v;
-        }
-        __syncthreads();
-        const float* wl = w2 + half * (16 * 8 * 64) + lane;     // B: 64 consecutive floats per (half, tap, s)
+    const float* wl = w2 + lane;                                // B: 64 consecutive floats per (tap, s)
 #pragma unroll
-        for (int tap = 0; tap < 16; ++tap) {
-            const int a = tap >> 2, b = tap & 3;
-            float bv[8];
+    for (int tap = 0; tap < 16; ++tap) {
+        const int a = tap >> 2, b = tap & 3;
+        float bv[16];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) bv[s] = wl[(tap * 8 + s) * 64];
+        for (int s = 0; s < 16; ++s) bv[s] = wl[(tap * 16 + s) * 64];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float* ap = win + ((wave + a) * kStemWinCols + mt * 16 + m + b) * kStemLd + kk * 8;
-                float av[8];
+        for (int mt = 0; mt < 2; ++mt) {
+            const float* ap = win + ((wave + a) * kStemWinCols + mt * 16 + m + b) * kStemLd + kk * 16;
+            float av[16];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(ap + 4 * q);
-                    av[4 * q] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
-                }
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc[mt] = stem_mfma(av[s], bv[s], acc[mt]);
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(ap + 4 * q);
+                av[4 * q] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
             }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[mt] = stem_mfma(av[s], bv[s], acc[mt]);
         }
     }
 
