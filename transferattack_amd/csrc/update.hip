@@ -855,7 +855,8 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     const StepParams p{decay, alpha, -eps, eps};
     const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
     // stream past the caches only when one launch moves more than the Infinity Cache can hold
-    const bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
+    bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
+    if (const char* force = getenv("TA_K2_NT")) nt = vec && atoi(force) != 0;       // tuning knob (tools/k2_inloop_probe.py)
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
     // the byte source: 16-byte aligned floats, 4-byte aligned bytes, whole images of a multiple of 4 elements
     const bool u8 = x_u8 != nullptr && vec && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0;
