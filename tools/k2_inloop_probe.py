@@ -28,7 +28,13 @@ big_b = torch.empty_like(big_a)
 e = 3 * 224 * 224
 
 
-def run(tag, with_stem, flush):
+tiny = torch.zeros(64, device="cuda")
+tim_w = torch.rand(15, 15, device="cuda")
+tim_w = (tim_w / tim_w.sum()).contiguous()
+tim_in, tim_out = torch.randn(N, 3, 224, 224, device="cuda"), torch.empty(N, 3, 224, 224, device="cuda")
+
+
+def run(tag, with_stem, flush, bridge=None):
     _hip.timing_begin(REPS + 4)
     for i in range(REPS):
         m, d, x, src = sets[i % 3]
@@ -39,6 +45,15 @@ def run(tag, with_stem, flush):
         else:
             gy = torch.empty(N, 3, 224, 224, device="cuda").copy_(sets[(i + 1) % 3][0]).mul_(1e-4)
             _hip.abs_sum_partials_std(gy, std)
+        if bridge == "noop":
+            tiny.add_(1.0)                                   # a ~2 us kernel between the producer and the update
+        elif bridge == "copy":
+            big_b.copy_(big_a)                               # ~200 us of pure memory traffic right before the update
+        elif bridge == "tim":
+            saved = getattr(gy, "_ta_partials", None)
+            _hip.depthwise_conv2d_same(tim_in, tim_out, tim_w)   # ~110 us of VALU work (no matrix cores) right before the update
+        elif bridge == "k1":
+            saved = gy.__dict__.pop("_ta_partials", None)    # drop the stem's sums: the update runs its sum-only pass first
         _hip.mi_update(gy, m, m, d, x, 1.0, 1.6 / 255, 16 / 255, data_u8=src, std=std)
     torch.cuda.synchronize()
     ms = _hip.timing_end()[3:]
@@ -52,3 +67,8 @@ run("stand-alone (K1-std pass in front, operands rotating)", False, False)
 run("stand-alone, 600 MB copy between iterations", False, True)
 run("after the stem kernel (as in the loop), 600 MB copy between iterations", True, True)
 run("after the stem kernel, no copy", True, False)
+run("stem kernel -> 2 us kernel -> update", True, False, "noop")
+run("stem kernel -> 600 MB copy -> update", True, False, "copy")
+run("stem kernel -> TIM convolution (VALU) -> update", True, False, "tim")
+run("stem kernel -> sum-only pass + update (timed together)", True, False, "k1")
+run("600 MB copy -> update (no stem kernel)", False, False, "copy")
