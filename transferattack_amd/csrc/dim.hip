@@ -280,152 +280,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     TA_PHASE(0, 5);
 }
 
-// The lane-per-column forward with MORE BYTES IN FLIGHT (round 5, after the phase clock: 53-56 % of a workgroup's life is the
-// wait for its one batch of x loads -- profiles/r05/dim_phase_clock_r5h.txt -- and Little's law with ~60 KB in flight per CU at
-// that latency gives the ~4 TB/s the kernel reaches, whatever its traffic).  A workgroup owns PAIR consecutive tiles and issues
-// the loads of ALL of them before it touches the first: tile k + 1's gathers fly under tile k's four LDS phases.  Everything a
-// tile's loads need (plane, window origin, this lane's column tap, the x rows behind the window) is computed from the tap
-// arithmetic directly -- wave-uniform values, no LDS table -- so nothing orders the loads behind a barrier; the row tables of
-// both resamples are built in ONE phase (one barrier fewer per tile than dim_fwd_lanes_kernel).  Same arithmetic, same bits.
-struct FwdTile {
-    const float* xp;
-    float* yp;
-    int oy0, ox0, th, twc, py_lo, mh, px_lo, p_a, p_b, sr_lo, sh;
-    bool col_ok;
-    Tap tx1, tx2;
-};
-
-template <int RPW, int PAIR>
-__global__ __launch_bounds__(kBlock) void dim_fwd_pair_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int size, int resize, int rnd, int top, int left,
-                                                              float scale1, float scale2, int tw, int tiles_x,
-                                                              int tiles_y, int total) {
-    constexpr int ROWS = 4 * RPW;
-    __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
-    __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
-    __shared__ __attribute__((aligned(16))) float T[ROWS * 64];        // H1 result; re-used as `u` by H2 / V2
-    __shared__ __attribute__((aligned(16))) float mid[ROWS * 64];      // the zero-padded, rescaled window
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles = tiles_x * tiles_y;
-
-    auto geometry = [&](int tid) {
-        FwdTile g;
-        const int plane = tid / tiles;
-        const int t = tid - plane * tiles;
-        const int tyi = t / tiles_x;
-        g.oy0 = tyi * kDimLaneRows;
-        g.ox0 = (t - tyi * tiles_x) * tw;
-        g.th = min(kDimLaneRows, size - g.oy0);
-        g.twc = min(tw, size - g.ox0);
-        g.xp = x + static_cast<int64_t>(plane) * size * size;
-        g.yp = y + static_cast<int64_t>(plane) * size * size;
-        g.px_lo = make_tap_scaled(g.ox0, resize, scale2).i0;                                   // taps are monotone
-        const int px_hi = make_tap_scaled(g.ox0 + g.twc - 1, resize, scale2).i1;
-        g.py_lo = make_tap_scaled(g.oy0, resize, scale2).i0;
-        const int py_hi = make_tap_scaled(g.oy0 + g.th - 1, resize, scale2).i1;
-        g.mh = py_hi - g.py_lo + 1;                                                            // <= ROWS - 1 (host-checked)
-        const int mw = px_hi - g.px_lo + 1;                                                    // <= 64
-        g.p_a = max(top - g.py_lo, 0);
-        g.p_b = min(top + rnd - 1 - g.py_lo, g.mh - 1);
-        const bool any_rows = g.p_a <= g.p_b;
-        g.sr_lo = any_rows ? make_tap_scaled(g.py_lo + g.p_a - top, size, scale1).i0 : 0;
-        g.sh = any_rows ? make_tap_scaled(g.py_lo + g.p_b - top, size, scale1).i1 - g.sr_lo + 1 : 0;
-        const int rx = g.px_lo + lane - left;
-        g.col_ok = lane < mw && rx >= 0 && rx < rnd;
-        g.tx1 = Tap{0, 0, 0.f, 0.f};
-        if (g.col_ok) g.tx1 = make_tap_scaled(rx, size, scale1);
-        g.tx2 = Tap{0, 0, 0.f, 0.f};
-        if (lane < g.twc) g.tx2 = make_tap_scaled(g.ox0 + lane, resize, scale2);
-        return g;
-    };
-    auto issue = [&](const FwdTile& g, float (&a)[RPW], float (&b)[RPW]) {
-        const char* base = reinterpret_cast<const char*>(g.xp);
-        const int w0 = min(wave, max(g.sh - 1, 0));
-        const unsigned row0 = static_cast<unsigned>((g.sr_lo + w0) * size), bstep = 16u * static_cast<unsigned>(size);
-        const unsigned b0 = (row0 + static_cast<unsigned>(g.tx1.i0)) * 4u, b1 = (row0 + static_cast<unsigned>(g.tx1.i1)) * 4u;
-        const int last = max(g.sh - 1 - w0, 0);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const unsigned off = static_cast<unsigned>(min(4 * i, last & ~3)) * (bstep / 4u);
-            a[i] = *reinterpret_cast<const float*>(base + (b0 + off));
-            b[i] = *reinterpret_cast<const float*>(base + (b1 + off));
-        }
-    };
-    auto process = [&](const FwdTile& g, const float (&a)[RPW], const float (&b)[RPW]) {
-        // -- row tables of both resamples, one phase
-        if (static_cast<int>(threadIdx.x) < g.th) ty2[threadIdx.x] = make_tap_scaled(g.oy0 + threadIdx.x, resize, scale2);
-        {
-            const int p = static_cast<int>(threadIdx.x) - 64;
-            if (p >= g.p_a && p <= g.p_b) ty1[p] = make_tap_scaled(g.py_lo + p - top, size, scale1);
-        }
-        // -- H1: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1])
-        {
-            float* out = T + wave * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) out[i * 256] = fmaf(g.tx1.l0, a[i], g.tx1.l1 * b[i]);
-        }
-        __syncthreads();
-        // -- V1
-        {
-            const float* Tc = T + lane - g.sr_lo * 64;
-            float* out = mid + wave * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int p = wave + 4 * i;
-                float val = 0.0f;
-                if (g.col_ok && p >= g.p_a && p <= g.p_b) {
-                    const Tap ty = ty1[p];
-                    val = fmaf(ty.l0, Tc[ty.i0 * 64], ty.l1 * Tc[ty.i1 * 64]);
-                }
-                out[i * 256] = val;
-            }
-        }
-        __syncthreads();
-        // -- H2 (u overwrites T: every lane is past V1)
-        float* u = T;
-        if (lane < g.twc) {
-            const float* m0 = mid + wave * 64 + (g.tx2.i0 - g.px_lo);
-            const float* m1 = mid + wave * 64 + (g.tx2.i1 - g.px_lo);
-            float* out = u + wave * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-                if (wave + 4 * i < g.mh) out[i * 256] = fmaf(g.tx2.l0, m0[i * 256], g.tx2.l1 * m1[i * 256]);
-        }
-        __syncthreads();
-        // -- V2
-        if (lane < g.twc) {
-            const float* uc = u + lane - g.py_lo * 64;
-            char* base = reinterpret_cast<char*>(g.yp);
-            const unsigned first = static_cast<unsigned>((g.oy0 + wave) * size + g.ox0 + lane) * 4u, bstep = 16u * static_cast<unsigned>(size);
-#pragma unroll
-            for (int i = 0; i < kDimLaneRows / 4; ++i) {
-                const int r = wave + 4 * i;
-                if (r < g.th) {
-                    const Tap ty = ty2[r];
-                    *reinterpret_cast<float*>(base + (first + i * bstep)) = fmaf(ty.l0, uc[ty.i0 * 64], ty.l1 * uc[ty.i1 * 64]);
-                }
-            }
-        }
-    };
-
-    const int first_tile = static_cast<int>(blockIdx.x) * PAIR;
-    FwdTile g[PAIR];
-    float a[PAIR][RPW], b[PAIR][RPW];
-#pragma unroll
-    for (int q = 0; q < PAIR; ++q) {
-        g[q] = geometry(min(first_tile + q, total - 1));                // (a ragged last workgroup repeats its last tile's loads)
-        issue(g[q], a[q], b[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < PAIR; ++q) {
-        if (first_tile + q < total) {                                   // (uniform)
-            if (q != 0) __syncthreads();                                // the previous tile's V2 is done with ty2 / u
-            process(g[q], a[q], b[q]);
-        }
-    }
-}
-
 // Row-band form of the forward (round 5).  PMC on the lane-per-column kernel (profiles/r04/dim_tim_pmc_n160_r4b.txt): HBM
 // traffic 1.96 x the algorithmic bytes at less than half the bandwidth, 57 % of a wave's life in s_waitcnt.  Both come from
 // the tile shape: a 32 x <= 64-column tile reads row segments of ~230 bytes that start and end inside cache lines, which its
@@ -1191,13 +1045,6 @@ static int xcd_order() {
     return (env != nullptr && atoi(env) != 0) ? 1 : 0;
 }
 
-// tiles per workgroup of the forward / backward lane kernels whose loads are all issued up front (TA_DIM_PAIR; 0 = one-tile kernels)
-static int dim_pair() {
-    const char* env = getenv("TA_DIM_PAIR");
-    const int v = env == nullptr ? 2 : atoi(env);
-    return v <= 0 ? 0 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1));
-}
-
 // the kernels' make_tap_scaled on the host (fmaf is the exact fused operation here as well)
 static void host_tap(int o, int in_size, float scale, int* i0, int* i1) {
     float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
@@ -1271,21 +1118,6 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             // every size, r2e / r2f: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480)
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31) - 8, "too many tiles");
-            // PAIR tiles per workgroup, all loads issued up front (TA_DIM_PAIR = 1 | 2 | 4; 0 = the one-tile kernel of rounds 2-4)
-            const int pair = dim_pair();
-            if (pair > 0) {
-                const int total = static_cast<int>(lane_blocks);
-                const dim3 pgrid(static_cast<unsigned>(ceil_div(lane_blocks, pair)));
-#define TA_DIM_FWD_PAIR(RPW)                                                                                              \
-    do {                                                                                                                  \
-        if (pair == 1) hipLaunchKernelGGL((dim_fwd_pair_kernel<RPW, 1>), pgrid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total); \
-        else if (pair == 2) hipLaunchKernelGGL((dim_fwd_pair_kernel<RPW, 2>), pgrid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total); \
-        else hipLaunchKernelGGL((dim_fwd_pair_kernel<RPW, 4>), pgrid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total); \
-    } while (0)
-                if (rows <= 40) TA_DIM_FWD_PAIR(10); else TA_DIM_FWD_PAIR(17);
-#undef TA_DIM_FWD_PAIR
-                return check_launch("dim_fwd_pair");
-            }
             const int swz = xcd_order();
             const dim3 grid(static_cast<unsigned>(swz ? ceil_div(lane_blocks, 8) * 8 : lane_blocks));
             const int total = static_cast<int>(lane_blocks);
