@@ -653,6 +653,19 @@ def test_partials_registry_rules(monkeypatch):
     _hip.abs_sum_partials(grad)
     assert reused()                                                            # fresh sums pass the verification
     monkeypatch.delenv("TA_DEBUG_PARTIALS")
+    # the same trap, and the same debug mode, for the byte source cached on an image batch (attack.py::_attach_byte_source)
+    from transferattack_amd.attack import Attack
+    data = (torch.randint(0, 256, (2, 3, 8, 8), generator=torch.Generator().manual_seed(1), dtype=torch.uint8).float() / 255).to(DEV)
+    Attack._attach_byte_source(data)
+    assert Attack._byte_source_of(data) is not None
+    data.data[0, 0, 0, 0] = 0.123                                              # behind torch's back: the cached bytes are stale
+    assert Attack._byte_source_of(data) is not None
+    monkeypatch.setenv("TA_DEBUG_PARTIALS", "verify")
+    with pytest.raises(_hip.HipExtensionError, match="stale"):
+        Attack._byte_source_of(data)
+    monkeypatch.delenv("TA_DEBUG_PARTIALS")
+    _hip.invalidate_partials(data)                                             # what every writer of this package does
+    assert Attack._byte_source_of(data) is None
     _hip.abs_sum_partials(grad)
     monkeypatch.setattr(_hip, "_stream", lambda like=None: 12345)
     assert not reused()                                                        # consumer "on another stream"

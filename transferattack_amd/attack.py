@@ -246,7 +246,16 @@ class Attack(object):
     def _byte_source_of(data):
         """(bytes, mismatch flag) attached to ``data`` by ``_attach_byte_source``, if ``data`` still has the probed version"""
         src = getattr(data, "_ta_u8", None)                 # (version of data when probed, bytes, mismatch flag)
-        return src[1:] if src is not None and src[0] == data._version else None
+        if src is None or src[0] != data._version:
+            return None
+        if os.environ.get("TA_DEBUG_PARTIALS") == "verify":
+            # the cached bytes rest on torch's version counter, which a write through .data / dlpack / a foreign kernel does
+            # not move (every writer of THIS package drops the attribute): this debug mode probes again and refuses stale bytes
+            again = _hip.u8_source_probe(data)
+            if not (torch.equal(again[0], src[1]) and int(again[1].item()) == int(src[2].item())):
+                raise _hip.HipExtensionError("TA_DEBUG_PARTIALS=verify: the byte source attached to this image batch is stale "
+                                             "(the tensor was modified without torch noticing)")
+        return src[1:]
 
     @staticmethod
     def _attach_byte_source(data):

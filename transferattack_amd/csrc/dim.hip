@@ -1081,8 +1081,8 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     TA_REQUIRE(x && y && x != y, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // row-band kernel (round 5): one lane per column, a band of 32 output rows x every column per workgroup -- the geometries
-    // the reference draws at 224 pixels (resize_rate 1.1: resize = 246); TA_DIM_BAND=0 selects the tile kernels below
+    // row-band kernel (round 5; opt-in, TA_DIM_BAND=1: measured slower than the tile kernels below): one lane per column, a band
+    // of 32 output rows x every column per workgroup -- the geometries the reference draws at 224 pixels (resize = 246)
     {
         const char* env = getenv("TA_DIM_BAND");
         if (resize <= kBlock && rnd >= size && resize >= size && env != nullptr && atoi(env) != 0) {
@@ -1186,7 +1186,7 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
     TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // row-band kernel (round 5): the geometries the reference draws at 224 pixels; TA_DIM_BAND=0 selects the tile kernels below.
+    // row-band kernel (round 5; opt-in, TA_DIM_BAND=1): the geometries the reference draws at 224 pixels.
     // ws keeps the tile kernels' layout (ta_dim_bwd_tiles sums per plane: the count depends on (size, resize) only)
     {
         const char* env = getenv("TA_DIM_BAND");
