@@ -62,6 +62,7 @@ def run(config, g, fold_normalize, monkeypatch):
         inner = base.get_grad
         type(atk).get_grad = lambda self, loss, delta, **kw: (lambda gr: (probe(0, gr), gr)[1])(inner(self, loss, delta, **kw))
     adv = np.empty((n, 224, 224, 3), np.uint8)
+    launches = _hip.stats["std_form_launches"]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in range((n + batch - 1) // batch):
@@ -70,6 +71,7 @@ def run(config, g, fold_normalize, monkeypatch):
         adv[lo:hi] = quantize_images(x[lo:hi], atk(x[lo:hi], label[lo:hi]))
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
+    assert (_hip.stats["std_form_launches"] > launches) == (bool(fold_normalize) and config == "mifgsm"), "wrong loop form ran"
     k = int(g["sign_images"])
     got = first[0][:k].cpu().numpy()
     ref_pos = np.unpackbits(g["sign_bits"])[:got.size].reshape(got.shape).astype(bool)

@@ -248,10 +248,14 @@ def test_normalize_folded_loop_fused_resnet(monkeypatch):
     order than ta_normalize_bwd's, so a momentum within rounding of zero may take the other sign: bounded like the kernel tests."""
     for k_, v in (("TA_FOLD_BN", "1"), ("TA_CHANNELS_LAST", "1"), ("TA_FUSED_GLUE", "1"), ("TA_STEM_KERNEL", "1"), ("TA_ALLOW_RANDOM_INIT", "1")):
         monkeypatch.setenv(k_, v)
-    plain, st0 = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=3)
-    again, _ = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=3)
-    folded, st1 = _loop(monkeypatch, True, "mifgsm", model_name="resnet18", n=2, epoch=3)
-    assert st1["std_form_launches"] == 3 and st1["partials_reused"] == 3 and st1["k1_passes"] == 0
+    # TWO iterations: the first step does not depend on the sums at all (sign(g / mean) = sign(g)), the second uses both
+    # iterations' sums (momentum) on an identical second gradient.  From the third on, the handful of pixels whose momentum was
+    # within rounding of zero have moved the input of a chaotic random-init network and the comparison measures that network,
+    # not the kernels (r5k: 4.6 % of the elements after three iterations on a box where the hook loop reproduced itself to 0.02 %)
+    plain, st0 = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=2)
+    again, _ = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=2)
+    folded, st1 = _loop(monkeypatch, True, "mifgsm", model_name="resnet18", n=2, epoch=2)
+    assert st1["std_form_launches"] == 2 and st1["partials_reused"] == 2 and st1["k1_passes"] == 0
     assert st0["std_form_launches"] == 0 and st0["k1_passes"] == 0
     noise = float((plain != again).float().mean())
     diff = float((plain != folded).float().mean())

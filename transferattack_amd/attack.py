@@ -184,9 +184,8 @@ class Attack(object):
         pre = model[0]
         if type(pre.resize) is not _Resize or type(pre.normalize) is not _Normalize:
             return None
-        for m in (model, pre, pre.resize, pre.normalize):
-            if (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None)
-                    or m.training):
+        for m in (model, pre, pre.resize, pre.normalize):      # (these three modules behave alike in train and eval mode)
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
                 return None
         if (data.dim() != 4 or data.dtype != torch.float32 or not data.is_contiguous()
                 or data.shape[-1] != pre.resize.size or data.shape[-2] != pre.resize.size
