@@ -198,6 +198,9 @@ trained)
   timeout 900 python -m pytest tests/test_hip_asr_trained.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr_trained_pytest.txt | tail -30 ;;
 dts)
   timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json | cut -c1-1500 ;;
+retest)
+  timeout 600 python -m pytest tests/test_hip_attacks.py tests/test_hip_asr1000.py tests/test_hip_asr_trained.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
+      -k "fused_resnet or mifgsm_resnet50 or (trained and mifgsm) or registry_rules" 2>&1 | grep -v Warning | tee $OUT/retest_pytest.txt | tail -40 ;;
 detcold)
   TA_DETERMINISTIC=1 timeout 900 python tools/cold_start.py --modes immediate,immediate:warm --root /tmp/ta_cold_det 2> $OUT/cold_start_det.err | tee $OUT/cold_start_deterministic.jsonl ;;
 esac
