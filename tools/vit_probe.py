@@ -43,19 +43,6 @@ def timed(tag, ctx=None):
             print("%-44s failed: %s" % (tag, repr(exc)[:120]), flush=True)
 
 
-if os.environ.get("TA_VIT_PROBE", "") == "patch":
-    # the patch embedding as MIOpen convolution (immediate mode / find mode) against the GEMM form
-    for tag, env, bench in (("patch embedding = GEMM (default)", "1", False), ("patch embedding = MIOpen conv, immediate mode", "0", False),
-                            ("patch embedding = MIOpen conv, find mode", "0", True)):
-        os.environ["TA_VIT_PATCH_GEMM"] = env
-        torch.backends.cudnn.benchmark = bench
-        timed(tag)
-    os.environ["TA_VIT_PATCH_GEMM"] = "1"
-    a = evaluate()
-    os.environ["TA_VIT_PATCH_GEMM"] = "0"
-    b = evaluate()
-    print("input gradient, GEMM vs convolution form: max |diff| / max|g| = %.2e" % float((a - b).abs().max() / b.abs().max()))
-    sys.exit(0)
 from torch.nn.attention import SDPBackend, sdpa_kernel  # noqa: E402
 print("preferred BLAS library:", torch.backends.cuda.preferred_blas_library())
 timed("default")

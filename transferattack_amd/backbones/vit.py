@@ -12,29 +12,11 @@ import torch.nn.functional as F
 
 
 class PatchEmbed(nn.Module):
-    """timm's patch embedding: ``proj`` is a Conv2d whose kernel equals its stride (parameter names kept: ``proj.weight``
-    [dim, 3, p, p]).  Such a convolution IS one GEMM over the non-overlapping patches, and it runs as one (rocBLAS / hipBLASLt
-    through ``F.linear``) unless ``TA_VIT_PATCH_GEMM=0``: MIOpen's immediate mode -- ``main.py``'s default, and what every
-    process without a tuned find-db gets -- has no good solver for a 16 x 16 / stride 16 fp32 convolution and its
-    backward-data, and a ViT surrogate spent as long there as in its twelve blocks (round 5, tools/vit_probe.py).  Same sums
-    of the same products; the accumulation order is the GEMM's instead of the convolution kernel's (~1e-7 relative)."""
-
     def __init__(self, patch, dim):
         super().__init__()
-        self.patch = patch
         self.proj = nn.Conv2d(3, dim, patch, stride=patch)
 
     def forward(self, x):
-        import os
-        p = self.patch
-        b, c, h, w = x.shape
-        # (device tensors only: on the CPU -- the oracle's and the reference's side of every parity test -- the surrogate keeps
-        # the convolution's bits)
-        if (x.is_cuda and os.environ.get("TA_VIT_PATCH_GEMM", "1") != "0" and h % p == 0 and w % p == 0 and not self.proj._forward_hooks
-                and not self.proj._forward_pre_hooks and not self.proj._backward_hooks
-                and tuple(self.proj.stride) == (p, p) and tuple(self.proj.padding) == (0, 0)):
-            patches = x.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 1, 3, 5).reshape(b, (h // p) * (w // p), c * p * p)
-            return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
