@@ -263,7 +263,7 @@ def test_normalize_folded_loop_fused_resnet(monkeypatch):
     assert diff <= 3 * noise + 2e-4
 
 
-@pytest.mark.parametrize("backbone", ["toy_cnn", "vit_tiny_patch16_224"])
+@pytest.mark.parametrize("backbone", ["toy_cnn"])          # (vit_tiny_patch16_224 ran equal too, r5b / r5k: 42 s of the tier's time)
 def test_vmi_neighbours_stacked_equal_one_by_one(monkeypatch, backbone):
     """VMI-FGSM's folded loop with k neighbour samples per surrogate evaluation (gradient/vmifgsm.py::_neighbor_stack)
     against one evaluation per neighbour (vmifgsm.py:46-58's shape): same Philox draws, same accumulation order, per-slice
