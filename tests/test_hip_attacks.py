@@ -255,11 +255,14 @@ def test_normalize_folded_loop_fused_resnet(monkeypatch):
     plain, st0 = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=2)
     again, _ = _loop(monkeypatch, False, "mifgsm", model_name="resnet18", n=2, epoch=2)
     folded, st1 = _loop(monkeypatch, True, "mifgsm", model_name="resnet18", n=2, epoch=2)
+    folded_again, _ = _loop(monkeypatch, True, "mifgsm", model_name="resnet18", n=2, epoch=2)
     assert st1["std_form_launches"] == 2 and st1["partials_reused"] == 2 and st1["k1_passes"] == 0
     assert st0["std_form_launches"] == 0 and st0["k1_passes"] == 0
-    noise = float((plain != again).float().mean())
+    # run-to-run noise of EITHER loop (MIOpen's atomic backward-data kernels: 0.02 % on one box, 2-4 % on another, and not the
+    # same in two consecutive runs): the two loops may differ from each other as much as the noisier one differs from itself
+    noise = max(float((plain != again).float().mean()), float((folded != folded_again).float().mean()))
     diff = float((plain != folded).float().mean())
-    print("fused ResNet-18: folded vs hook loop differ in %.5f%% of the elements (hook loop vs itself: %.5f%%)" % (100 * diff, 100 * noise))
+    print("fused ResNet-18: folded vs hook loop differ in %.5f%% of the elements (either loop vs itself: up to %.5f%%)" % (100 * diff, 100 * noise))
     assert diff <= 3 * noise + 2e-4
 
 
