@@ -233,10 +233,11 @@ def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
     plain, st0 = _loop(monkeypatch, False, name, backbone, **kw)
     again, _ = _loop(monkeypatch, False, name, backbone, **kw)
     folded, st1 = _loop(monkeypatch, True, name, backbone, **kw)
+    folded_again, _ = _loop(monkeypatch, True, name, backbone, **kw)
     k = kw.get("epoch", 1 if name == "fgsm" else 10)
     assert st0["std_form_launches"] == 0 and st1["std_form_launches"] == k
     assert float(folded.abs().max()) > 0 and float(folded.abs().max()) <= EPS + 1e-7
-    noise = float((plain != again).float().mean())
+    noise = max(float((plain != again).float().mean()), float((folded != folded_again).float().mean()))
     diff = float((plain != folded).float().mean())
     print("%s / %s: folded vs hook loop differ in %.5f%% of the elements (hook loop vs itself: %.5f%%)" % (name, backbone, 100 * diff, 100 * noise))
     assert diff <= 3 * noise + (0.0 if noise == 0.0 else 1e-4)
