@@ -113,7 +113,9 @@ int ta_mi_update_u8(const float* g, const float* v, const float* m_in, float* m_
  *                            |gy / std[c]| per image (ta_stem7s2_input_grad leaves them); ws_slots == 0: a sum-only pass
  *                            over gy runs first (ta_abs_sum_partials_std; ws = scratch as for ta_mi_update).  e = c * hw.
  *                            Same rounding points as ta_normalize_bwd + ta_mi_update: same bits.
- *   ta_abs_sum_partials_std  K1 over gy / std[c]: ta_normalize_bwd's sums (bit for bit) without its store. */
+ *   ta_abs_sum_partials_std  K1 over gy / std[c]: ta_normalize_bwd's sums without its store -- bit for bit when hw % 4 == 0 (every
+ *                            image plane this path sees; a plane size that is not a multiple of 4 takes the scalar form, whose
+ *                            fixed summation order is another one: equal to fp32 summation error). */
 int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
                          const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream);
 int ta_mi_update_std(const float* gy, const float* stdv, const float* m_in, float* m_out, float* delta, const float* x,
