@@ -36,6 +36,10 @@ One JSON line on rank 0, with
                 delta, x; write m, delta -- what the launch does, since round 5 it stores no x + delta);
                 ``frac_algorithmic``: every operand priced as fp32; ``traffic``: the committed PMC passes
                 (profiles/pmc_update_kernel.json) priced per launch.
+  config.literal  the SAME attack timed in the reference-literal arrangement for a few steps (``--literal-steps``): batches of
+                32, NCHW, separate BatchNorm, nn.Module execution, MIOpen immediate mode -- what main.py runs with no
+                environment set; ``images_per_s``, the update's ``update_frac`` (executed bytes; a sum-only pass precedes each
+                update there: ``k1_passes``)
   cpu_baseline  the oracle (oracle/fgsm_oracle.py = the reference's ATen CPU arithmetic) on the host cores: 32 images (the
                 reference's batch), all K=10 iterations, at the best of a thread sweep from 8 to every hardware thread
                 (``cores`` = physical cores, ``threads_used``, ``thread_sweep_images_per_s``); kind "reference" where
@@ -71,12 +75,17 @@ def parse(argv=None):
     p.add_argument("--channels-last", type=int, default=1, help="run the surrogate in NHWC memory format")
     p.add_argument("--cpu-images", type=int, default=32, help="images of the CPU-baseline sample (0 = skip); 32 = the reference's batch")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
+    p.add_argument("--literal-steps", type=int, default=3,
+                   help="also time the reference-literal arrangement (batch 32, NCHW, separate BatchNorm, MIOpen immediate "
+                        "mode) for this many steps -> config.literal (0 = skip)")
     p.add_argument("--kernel-times", type=int, default=0,
                    help="time every HIP kernel call of the loop with events (config.kernels); for the transform attacks")
     # the four flags below exist for tests/test_bench_ranks.py: the multi-rank reporting path (barrier, MAX all-reduce of
     # the time, all-gather of the rates, the sharded-ensemble layout) on gloo / CPU tensors with the kernels' host build
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU tests)")
     p.add_argument("--device", default="cuda", help="cuda (= HIP); cpu only under the tests' host stand-in of the kernels")
+    p.add_argument("--share-device", type=int, default=0,
+                   help="diagnostic: every rank drives device 0 (with --backend gloo; the one-GPU cold-start probe of staged_warmup)")
     p.add_argument("--image-size", type=int, default=224)
     p.add_argument("--classes", type=int, default=1000)
     return p.parse_args(argv)
@@ -328,7 +337,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not args.share_device:
         sys.exit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, visible))
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -347,13 +356,16 @@ def open_world(args):
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting what actually runs" % (args.gpus, world),
               file=sys.stderr)
+    if args.share_device:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"              # transferattack_amd.utils.default_device reads it
     if args.device == "cuda":
         torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
-            if args.device == "cuda":
+            if args.device == "cuda" and args.backend == "nccl":
                 dist.init_process_group(args.backend, device_id=torch.device("cuda", local))
             else:
                 dist.init_process_group(args.backend)
@@ -385,13 +397,46 @@ def device_sync(args):
         torch.cuda.synchronize()
 
 
-def timed_region(step, args, world, before=None):
-    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + device synchronisation on both sides.
-    -> (seconds between the two brackets on this rank, seconds until this rank's own last step finished)."""
-    import torch.distributed as dist
+def staged_warmup(step, args, world, rank, independent=True):
+    """The W untimed warm-up steps, rank 0 FIRST.  bench.py runs MIOpen in find mode (``cudnn.benchmark``): on a fresh node the
+    first process spends minutes building and timing every applicable solver of every convolution (285-333 s for ResNet-50 at
+    batch 125, profiles/r05/cold_start_main_1000png_r5a.jsonl) and leaves the result in MIOpen's user find-db and kernel
+    cache -- files shared by all ranks of the node.  N ranks entering that find at once would do the same work N times,
+    contending for the same files and for the host's cores (every solver is a clang job).  So ranks 1..N-1 wait on the host
+    (a gloo barrier: no RCCL kernel spinning on their GPUs, no collective watchdog) until rank 0 has warmed up, then warm up
+    together against the populated databases (find-db hits, kernels loaded from the cache).  Wall ~ cold(1) + warm(1) instead
+    of N contending cold starts.  ``TA_BENCH_STAGED_WARMUP=0`` lets all ranks start together (the comparison run of
+    profiles/r06).  -> seconds this rank spent in (waiting, its own warm-up)."""
+    # (``independent`` False: the ranks' steps exchange data -- the sharded ensemble's all-reduces -- so no rank can step alone)
+    staged = independent and world > 1 and args.warmup > 0 and os.environ.get("TA_BENCH_STAGED_WARMUP", "1") != "0"
+    waited = 0.0
+    group = None
+    if staged:
+        import datetime
+        import torch.distributed as dist
+        group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
+        if rank != 0:
+            t0 = time.perf_counter()
+            dist.barrier(group=group)             # released when rank 0 arrives, i.e. after its warm-up
+            waited = time.perf_counter() - t0
+    t0 = time.perf_counter()
     for i in range(args.warmup):
         step(i)
     device_sync(args)
+    warm = time.perf_counter() - t0
+    if staged and rank == 0:
+        import torch.distributed as dist
+        dist.barrier(group=group)
+    return waited, warm, staged
+
+
+def timed_region(step, args, world, before=None, rank=0, independent=True):
+    """W untimed warm-up steps (rank 0 first: ``staged_warmup``), then EXACTLY K steps bracketed by barrier + device
+    synchronisation on both sides.
+    -> (seconds between the two brackets on this rank, seconds until this rank's own last step finished,
+        (seconds waited for rank 0's warm-up, seconds of this rank's own warm-up, was the warm-up staged))."""
+    import torch.distributed as dist
+    startup = staged_warmup(step, args, world, rank, independent)
     if world > 1:
         dist.barrier()
     device_sync(args)
@@ -405,7 +450,7 @@ def timed_region(step, args, world, before=None):
     if world > 1:
         dist.barrier()
     device_sync(args)
-    return time.perf_counter() - t0, mine
+    return time.perf_counter() - t0, mine, startup
 
 
 def over_ranks(dt, rate, world, dev):
@@ -414,6 +459,8 @@ def over_ranks(dt, rate, world, dev):
     if world == 1:
         return dt, [rate], 1, "none (single process)"
     import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        dev = "cpu"                                 # (the CPU tests, and the shared-device cold-start probe)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     rates = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
@@ -442,15 +489,20 @@ def roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken=False
     executed = [b - 3 * rec[2] * rec[3] * int(t) for b, rec, t in zip(algorithmic, sink, u8)]
     contract = [rec[2] * rec[3] * BYTES_PER_ELEM for rec in sink]                 # 24 B/element, nothing else
     steady = [i for i, b in enumerate(algorithmic) if b == max(algorithmic)]
-    k1 = _hip.stats["k1_passes"]
-    if k1:                                       # a K1 pass inside a call re-reads g: 4 B/element more are requested by it
-        executed = [b + 4.0 * rec[2] * rec[3] * min(1.0, k1 / len(sink)) for b, rec in zip(executed, sink)]
+    # a sum pass of its own inside a call re-reads g: 4 B/element more are requested by exactly the launches that ran one
+    # (recorded per launch by _hip.mi_update; records of older shape fall back to the process-wide counter)
+    ran_k1 = [bool(rec[7]) if len(rec) > 7 else _hip.stats["k1_passes"] > 0 for rec in sink]
+    k1 = sum(ran_k1)
+    executed = [b + 4.0 * rec[2] * rec[3] * int(r) for b, rec, r in zip(executed, sink, ran_k1)]
     total_us = sum(durs_us)
     achieved = sum(executed) / total_us / 1e3                                   # GB/s over the launches of the timed region
     std_form = sum(1 for rec in sink if len(rec) > 6 and rec[6])
     pmc = committed_pmc_traffic(sink, _hip)
     st_us = sum(durs_us[i] for i in steady)
     return {"bound": "hbm",
+            # what ``achieved`` / ``frac`` price: "executed-bytes/2" = requested bytes incl. the byte source (round 5) with the
+            # sum pass billed to the launches that ran one (round 6); rounds 1-4 priced algorithmic bytes (``frac_algorithmic``)
+            "pricing": "executed-bytes/2",
             "kernel": ("ta_mi_update_std" if std_form == len(sink) else "ta_mi_update") + (
                 " (mi_update_kernel; |g| tile sums left by the kernel that produced g)" if k1 == 0 else
                 " (abs_sum_partials_kernel + mi_update_kernel)"),
@@ -472,7 +524,7 @@ def roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken=False
                                     "algorithmic_bytes": int(max(algorithmic)),
                                     "mean_us": round(st_us / len(steady), 2),
                                     "executed_GBps": round(sum(executed[i] for i in steady) / st_us / 1e3, 1)},
-            "k1_pass_skipped_launches": _hip.stats["partials_reused"], "k1_passes": k1,
+            "k1_pass_skipped_launches": len(sink) - k1, "k1_passes": k1,
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4),
             # SURVEY 8(d)'s contract: 24 B per element and nothing else over the steady-state launches
             "frac_at_24B_contract": round(sum(contract[i] for i in steady) / st_us / 1e3 / HBM_PEAK_GBS, 4),
@@ -525,9 +577,60 @@ def committed_pmc_traffic(sink, _hip):
     if priced != len(sink):
         return None
     n_, e_ = sink[0][2], sink[0][3]
-    return {"bytes_per_launch": int(total / len(sink) + (k1 * e_ * n_ if _hip.stats["k1_passes"] > 0 else 0)),
+    ran_k1 = sum(bool(rec[7]) if len(rec) > 7 else _hip.stats["k1_passes"] > 0 for rec in sink) / len(sink)
+    return {"bytes_per_launch": int(total / len(sink) + k1 * e_ * n_ * ran_k1),
             "source": "NOT measured in this run: profiles/pmc_update_kernel.json, the committed rocprofv3 --pmc FETCH_SIZE / "
                       "WRITE_SIZE passes over the shipped kernel at N=125, priced per launch"}
+
+
+def literal_leg(args, _hip):
+    """The reference-literal setup, timed beside the headline: what ``main.py`` does with no environment set
+    (/root/reference/main.py:15,36) -- batches of 32, NCHW, separate eval-mode BatchNorm, plain nn.Module execution, MIOpen's
+    immediate mode (no ``cudnn.benchmark`` find) -- same attack, same surrogate, same synthetic images.  A user who switches
+    packages and nothing else gets THIS rate; the headline's arrangement is the two switches TA_FOLD_BN /
+    TA_CHANNELS_LAST + MIOpen find.  -> ``config.literal``."""
+    import contextlib
+    import transferattack_amd as ta
+    saved = {k: os.environ.get(k) for k in ("TA_FOLD_BN", "TA_CHANNELS_LAST")}
+    saved_benchmark = torch.backends.cudnn.benchmark
+    os.environ["TA_FOLD_BN"], os.environ["TA_CHANNELS_LAST"] = "0", "0"
+    torch.backends.cudnn.benchmark = False
+    batch = 32
+    try:
+        model_name = args.model.split(",") if "," in args.model else args.model
+        with contextlib.redirect_stdout(sys.stderr):
+            attacker = ta.load_attack_class(args.attack)(model_name=model_name)
+        dev = attacker.device
+        batches = [tuple(t.to(dev) for t in synthetic_batch(batch, 7000 + 2 * i, args.image_size, args.classes)) for i in range(2)]
+        attacker(*batches[0])                                    # warm-up: MIOpen's immediate-mode kernels for these shapes
+        torch.cuda.synchronize()
+        _hip.profile_sink, note = [], None
+        try:
+            _hip.timing_begin(args.literal_steps * 64 + 64)
+        except _hip.HipExtensionError as exc:
+            note = str(exc)[:200]
+        t0 = time.perf_counter()
+        for i in range(args.literal_steps):
+            attacker(*batches[i % 2])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sink, _hip.profile_sink = _hip.profile_sink, None
+        dispatch_ms = _hip.timing_end() if note is None else []
+        out = {"images_per_s": round(args.literal_steps * batch / dt, 2), "batch": batch, "steps": args.literal_steps,
+               "ms_per_step": round(dt / args.literal_steps * 1e3, 2),
+               "arrangement": "NCHW, separate BatchNorm, nn.Module execution, MIOpen immediate mode, no environment switches "
+                              "(what main.py runs by default)"}
+        if sink:
+            r = roofline(args, sink, dispatch_ms, note, _hip, byte_source_taken(batches))
+            out.update({"update_frac": r["frac"], "update_frac_at_24B_contract": r["frac_at_24B_contract"],
+                        "update_mean_us": r["mean_us"], "update_kernel": r["kernel"], "k1_passes": r["k1_passes"],
+                        "update_launches": r["launches"]})
+        return out
+    finally:
+        _hip.profile_sink = None
+        torch.backends.cudnn.benchmark = saved_benchmark
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
 def main(argv=None):
@@ -569,7 +672,10 @@ def main(argv=None):
         if args.kernel_times:
             state["records"], state["restore"] = instrument_kernels(_hip, lambda: torch.cuda.Event(enable_timing=True))
 
-    dt, mine = timed_region(step, args, world, before_timed_steps)
+    t_start = time.perf_counter()
+    dt, mine, (waited_s, warmup_s, staged) = timed_region(step, args, world, before_timed_steps, rank,
+                                                          independent="no collective" in layout)
+    startup_s = time.perf_counter() - t_start - dt
     sink, _hip.profile_sink = _hip.profile_sink, None
     timing_note, kernel_records = state["timing_note"], state["records"]
     dispatch_ms = []
@@ -617,7 +723,11 @@ def main(argv=None):
                        "normalize_folded": os.environ.get("TA_FOLD_NORMALIZE", "1") != "0",
                        "attack": args.attack, "surrogate": args.model, "batch": args.batch, "iterations": 10,
                        "parallelism": layout, "gpus_requested": args.gpus, "ranks_observed": observed_world,
-                       "collective_backend": backend, "images_per_s_per_rank": per_rank},
+                       "collective_backend": backend, "images_per_s_per_rank": per_rank,
+                       # before the timed region, on rank 0: its own warm-up steps (MIOpen find on a fresh node) + the other
+                       # ranks' warm-up, which starts when rank 0's ends (staged_warmup)
+                       "startup": {"rank0_warmup_s": round(warmup_s, 1), "until_timed_region_s": round(startup_s, 1),
+                                   "staged": staged}},
             "roofline": roofline(args, sink, dispatch_ms, timing_note, _hip, byte_source_taken(batches)) if sink else None,
         }
         if kernel_records:
@@ -627,6 +737,11 @@ def main(argv=None):
                 result["config"]["update_kernel_sweep"] = kernel_sweep()
             except Exception as exc:  # noqa: BLE001
                 result["config"]["update_kernel_sweep"] = {"error": repr(exc)[:200]}
+        if on_gpu and args.literal_steps > 0 and world == 1:
+            try:
+                result["config"]["literal"] = literal_leg(args, _hip)
+            except Exception as exc:  # noqa: BLE001  -- a second figure: never at the expense of the line
+                result["config"]["literal"] = {"error": repr(exc)[:200]}
         if args.cpu_images > 0 and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args)

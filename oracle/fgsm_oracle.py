@@ -373,11 +373,15 @@ def preprocess_cfg(backbone):
     return 224, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 
 
-def logits_of(backbones, x):
+def logits_of(backbones, x, tap=None):
     """Surrogate forward: single wrapped model, or mean of the M members' logits (EnsembleModel
-    mode='mean', utils.py:94-101)."""
+    mode='mean', utils.py:94-101).  ``tap`` (optional, single model only): called with the gradient
+    that reaches the backbone's input -- PreprocessingModel's output, utils.py:78-79 -- during backward."""
     if not isinstance(backbones, (list, tuple)):
-        return backbones(preprocess(x, *preprocess_cfg(backbones)))
+        y = preprocess(x, *preprocess_cfg(backbones))
+        if tap is not None and y.requires_grad:
+            y.register_hook(tap)
+        return backbones(y)
     outs = [b(preprocess(x, *preprocess_cfg(b))) for b in backbones]
     return torch.mean(torch.stack(outs, dim=0), dim=0)
 
@@ -458,7 +462,11 @@ def run_attack(name, backbones, data, label, trace=None, **overrides):
         return x
 
     def grad_at(x_in, delta, momentum, rec):
-        logits = logits_of(backbones, transform(x_in, momentum, rec))
+        tap = None
+        if trace is not None and not isinstance(backbones, (list, tuple)):
+            # d(loss)/d(backbone input): what Normalize's backward (gy / std, utils.py:76) turns into the gradient below
+            tap = lambda gy: rec.setdefault("grads_y", []).append(gy.detach().clone())     # noqa: E731
+        logits = logits_of(backbones, transform(x_in, momentum, rec), tap)
         lab = label.repeat(copies) if copies > 1 else label
         loss = -ce(logits, lab) if cfg["targeted"] else ce(logits, lab)     # attack.py:110-115
         g = torch.autograd.grad(loss, delta, retain_graph=False, create_graph=False)[0]

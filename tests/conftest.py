@@ -15,6 +15,8 @@ for p in (ROOT, ORACLE_DIR):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "gpu_long: the 1000-image forms of the two slowest ASR jobs (MI355X, ~8 min; -m gpu_long): "
+                                       "kept out of -m gpu so that tier fits the driver's step limit")
     # test infrastructure may build what it checks (a fresh checkout has no .so: they are git-ignored); the product
     # itself never builds or falls back at run time
     import subprocess
@@ -59,11 +61,16 @@ def _gpu_tier(item):
 def pytest_collection_modifyitems(config, items):
     order = {id(it): i for i, it in enumerate(items)}
     items.sort(key=lambda it: ((_gpu_tier(it), order[id(it)]) if "gpu" in it.keywords else (-1, order[id(it)])))
+    if "gpu_long" not in (config.getoption("-m") or ""):          # ... and never as a side effect of -m "not gpu"
+        unasked = pytest.mark.skip(reason="runs only when asked for: -m gpu_long")
+        for item in items:
+            if "gpu_long" in item.keywords:
+                item.add_marker(unasked)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu" in item.keywords or "gpu_long" in item.keywords:
             item.add_marker(skip)
 
 

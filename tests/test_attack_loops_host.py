@@ -34,6 +34,7 @@ def _subset(cases, keep):
 
 
 test_config1_trajectory_replay = A.test_config1_trajectory_replay
+test_config1_loop_replay_default_loop = A.test_config1_loop_replay_default_loop
 
 
 @pytest.mark.parametrize("name,backbone,kw", [("mifgsm", "toy_cnn", dict(epoch=4)), ("ifgsm", "toy_cnn", dict(epoch=3)),
@@ -42,7 +43,8 @@ def test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
     A.test_normalize_folded_loop_equals_hook_loop(monkeypatch, name, backbone, kw)
 
 
-test_normalize_folded_loop_fused_resnet = A.test_normalize_folded_loop_fused_resnet
+def test_normalize_folded_loop_fused_resnet(monkeypatch):
+    A.test_normalize_folded_loop_fused_resnet(monkeypatch, "resnet18")
 
 
 def test_vmi_neighbours_stacked_equal_one_by_one(monkeypatch):

@@ -75,6 +75,9 @@ def test_bench_two_ranks_image_shards(tmp_path):
     assert abs(r["value"] - 2 * 2 * 2 / (r["ms_per_step"] * 2 / 1e3)) <= 1e-2 * r["value"]
     assert r["value"] <= sum(r["config"]["images_per_s_per_rank"]) * 1.001
     assert "image-shard x2" in r["config"]["parallelism"]
+    # rank 0 warmed up first, rank 1 after it (bench.staged_warmup): the time before the timed region holds both warm-ups
+    st = r["config"]["startup"]
+    assert st["staged"] is True and st["until_timed_region_s"] >= st["rank0_warmup_s"] > 0
 
 
 def test_bench_two_ranks_sharded_ensemble(tmp_path):
@@ -85,6 +88,7 @@ def test_bench_two_ranks_sharded_ensemble(tmp_path):
     assert r["n_gpus"] == 2 and r["config"]["ranks_observed"] == 2 and r["config"]["collective_backend"] == "gloo"
     assert "1 image shard(s) x 2 model ranks" in r["config"]["parallelism"]
     assert abs(r["value"] - 2 * 2 / (r["ms_per_step"] * 2 / 1e3)) <= 1e-2 * r["value"]       # one shard: 2 steps x 2 images
+    assert r["config"]["startup"]["staged"] is False          # the members' steps exchange data: no rank can warm up alone
 
 
 def test_bench_single_process_same_code(tmp_path):

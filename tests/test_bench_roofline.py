@@ -47,3 +47,35 @@ def test_roofline_prices_executed_bytes():
     # an inconsistent dispatch clock falls back to the markers and says so
     r3 = bench.roofline(None, sink, [d * 10 for d in dispatch], None, _Hip, byte_source_taken=True)
     assert r3["clock"].startswith("hipEventRecord")
+
+
+def test_roofline_bills_the_sum_pass_to_the_launches_that_ran_one():
+    """records of round 6 carry, per launch, whether the call ran its own sum pass over the gradient (the module path's backward
+    leaves no sums): those launches request 4 B/element more, the others do not -- whatever the process-wide counter says"""
+    n, e = 32, 3 * 224 * 224
+    sink, dispatch = _sink(n, e, 30.0, 26.0)
+    with_k1 = [rec + (True,) for rec in sink]
+    r = bench.roofline(None, with_k1, dispatch, None, _Hip, byte_source_taken=True)
+    assert r["k1_passes"] == 10 and r["k1_pass_skipped_launches"] == 0
+    assert r["steady_state_launch"]["executed_bytes"] == 25 * n * e
+    mixed = [rec + (i % 2 == 0,) for i, rec in enumerate(sink)]
+    r2 = bench.roofline(None, mixed, dispatch, None, _Hip, byte_source_taken=True)
+    assert r2["k1_passes"] == 5 and r["pricing"] == r2["pricing"] == "executed-bytes/2"
+    none = [rec + (False,) for rec in sink]
+    assert bench.roofline(None, none, dispatch, None, _Hip, byte_source_taken=True)["frac"] == \
+        bench.roofline(None, sink, dispatch, None, _Hip, byte_source_taken=True)["frac"]
+
+
+def test_committed_pmc_file_is_the_newest_rounds():
+    """profiles/pmc_update_kernel.json -- which bench.py reads for ``roofline.traffic`` -- must be the file the newest round's
+    PMC run produced (tools/gpu_check.sh pmc writes both): a copy that drifts from its source fails here"""
+    import glob
+    import json
+    rounds = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_update_kernel*.json")))
+    assert rounds, "no per-round PMC summary under profiles/rNN/"
+    newest_dir = os.path.dirname(rounds[-1])
+    newest = sorted(p for p in rounds if os.path.dirname(p) == newest_dir)[-1]
+    top = json.load(open(os.path.join(ROOT, "profiles", "pmc_update_kernel.json")))
+    src = json.load(open(newest))
+    assert top["kernels"] == src["kernels"] and top["fetch_correction"] == src["fetch_correction"], \
+        "profiles/pmc_update_kernel.json differs from %s" % os.path.relpath(newest, ROOT)

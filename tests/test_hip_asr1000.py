@@ -45,7 +45,7 @@ from conftest import GOLDEN_DIR, u8_images
 from transferattack_amd import _hip, backbones
 from transferattack_amd.utils import quantize_images, wrap_model
 
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu          # per test, not per module: the two ``gpu_long`` jobs at the end stay out of ``-m gpu``
 DEV = "cuda"
 
 
@@ -87,8 +87,11 @@ def predictions(net, x, chunk=100):
     return torch.cat(out).numpy()
 
 
-def run_config(config, name, arrangement, g):
+def run_config(config, name, arrangement, g, limit=None):
+    """``limit``: only the first ``limit`` images of the fixture (whole reference batches; the per-batch seeds are the fixture's)"""
     n, batch, seed_base = int(g["n_images"]), int(g["batch"]), int(g["seed_base"])
+    n = n if limit is None else min(n, limit)
+    assert n % batch == 0 or n == int(g["n_images"])
     xu8 = u8_images(n, 224, int(g["seed_images"]))
     x = xu8.float() / 255
     label = torch.from_numpy(g["label"].astype(np.int64))
@@ -183,6 +186,7 @@ def check_rates(config, tag, g, x, label, adv):
     return rows
 
 
+@gpu
 @pytest.mark.parametrize("tag,arrangement", [("reference-literal surrogate", dict()),
                                              ("folded BatchNorm + NHWC + fused glue, as bench.py", dict(fold_bn=True, channels_last=True))])
 def test_asr1000_mifgsm_resnet50(tag, arrangement):
@@ -199,6 +203,7 @@ def test_asr1000_mifgsm_resnet50(tag, arrangement):
     check_rates("configs[1] MI-FGSM / ResNet-50", tag, g, x, label, adv)
 
 
+@gpu
 @pytest.mark.parametrize("tag,arrangement", [("reference-literal surrogate", dict()),
                                              ("folded BatchNorm + NHWC + fused glue, as bench.py", dict(fold_bn=True, channels_last=True))])
 def test_asr1000_dts_resnet50(tag, arrangement):
@@ -211,28 +216,57 @@ def test_asr1000_dts_resnet50(tag, arrangement):
     check_rates("configs[2] DTS / ResNet-50", tag, g, x, label, adv)
 
 
-def test_asr_ens_four_members():
-    """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
-    utils.py:94-101), the 1000-image set (the reference needs ~4 s of CPU time per image here), in the arrangement
-    ``bench.py --attack ens`` runs: BatchNorm folded, ResNet-50 through the fused glue with ReLU pass bits, NHWC for ResNet /
-    ViT only (attack.takes_channels_last), the 299-pixel member behind the resize + Normalize kernel, every member on its own
-    HIP stream.  (The reference-literal arrangement of these members is what test_config5_ensemble_replay pins.)"""
+# The two slowest jobs of this file (3.2 and 7 images/s on one device) run on the FIRST 256 images -- 8 reference batches -- in
+# the ``-m gpu`` tier, whose whole run has to fit the driver's step limit, and on all 1000 behind the second marker
+# ``gpu_long`` (``pytest -m gpu_long``; tools/gpu_check.sh ``asrlong`` / ``tests`` run it).  Same assertions either way; with 256
+# images the bounds are wider by a factor of two, a wrong sign or a stale momentum still moves the rate by tens of points.
+SHORT = 256
+
+
+def _ens_four_members(limit):
     g = fixture("ens")
-    x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(fold_bn=True, channels_last=True), g)
+    x, label, adv, agree, seconds = run_config("configs[4]", "ens", dict(fold_bn=True, channels_last=True), g, limit)
     print("\nconfigs[4]: %d images in %.1f s (%.0f images/s); first-iteration gradient sign agreement with the reference "
           "%.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
     assert agree >= 0.99
     check_rates("configs[4] ensemble MI-FGSM / RN50 + VGG-16 + Inc-v3 + ViT-B/16", "the bench arrangement", g, x, label, adv)
 
 
-def test_asr_vmifgsm_vit():
-    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the 1000-image set (32 reference batches =
-    6720 surrogate evaluations of 32 images: ~6.5 h of reference CPU time for the fixture).  The neighbours come from different
-    generators on the two paths (torch's CPU generator in the reference run, the in-kernel Philox stream here) -- as they would
-    between any two runs of the reference itself, which seeds nothing."""
+def _vmifgsm_vit(limit):
     g = fixture("vmifgsm")
-    x, label, adv, agree, seconds = run_config("configs[3]", "vmifgsm", dict(), g)
+    x, label, adv, agree, seconds = run_config("configs[3]", "vmifgsm", dict(), g, limit)
     print("\nconfigs[3]: %d images in %.1f s (%.1f images/s); first-iteration gradient sign agreement with the reference "
           "%.3f %%" % (len(label), seconds, len(label) / seconds, 100 * agree))
     assert agree >= 0.99
     check_rates("configs[3] VMI-FGSM / ViT-B/16", "reference-literal surrogate", g, x, label, adv)
+
+
+@gpu
+def test_asr_ens_four_members():
+    """BASELINE.json configs[4] on one device: ensemble MI-FGSM over ResNet-50 + VGG-16 + Inception-v3 + ViT-B/16 (logit mean,
+    utils.py:94-101), the first 256 images of the 1000-image set (the reference needs ~4 s of CPU time per image here), in the
+    arrangement ``bench.py --attack ens`` runs: BatchNorm folded, ResNet-50 through the fused glue with ReLU pass bits, NHWC for
+    ResNet / ViT only (attack.takes_channels_last), the 299-pixel member behind the resize + Normalize kernel, every member on
+    its own HIP stream.  (The reference-literal arrangement of these members is what test_config5_ensemble_replay pins.)"""
+    _ens_four_members(SHORT)
+
+
+@gpu
+def test_asr_vmifgsm_vit():
+    """BASELINE.json configs[3] on one device: VMI-FGSM on ViT-B/16, 20 neighbours, the first 256 images of the 1000-image set
+    (the whole fixture: 32 reference batches = 6720 surrogate evaluations of 32 images, ~6.5 h of reference CPU time).  The
+    neighbours come from different generators on the two paths (torch's CPU generator in the reference run, the in-kernel
+    Philox stream here) -- as they would between any two runs of the reference itself, which seeds nothing."""
+    _vmifgsm_vit(SHORT)
+
+
+@pytest.mark.gpu_long
+def test_asr1000_ens_four_members():
+    """test_asr_ens_four_members on all 1000 images (155 s on MI355X)"""
+    _ens_four_members(None)
+
+
+@pytest.mark.gpu_long
+def test_asr1000_vmifgsm_vit():
+    """test_asr_vmifgsm_vit on all 1000 images (330 s on MI355X)"""
+    _vmifgsm_vit(None)

@@ -5,7 +5,11 @@ Tier 1 -- identical gradient source => identical bytes.  The oracle (pinned bit 
 for these very configurations by tests/test_oracle_golden.py: tests/golden/config{2,3,4,5}_*.npz, written by
 oracle/gen_golden.py) runs the configuration on this host's CPU and records every gradient the loop consumes; the
 product's attack class then runs on the GPU -- HIP transforms, surrogate forward/backward, HIP update -- with each
-gradient replaced by the recorded one.  By induction the iterates coincide, so
+gradient replaced by the recorded one.  The attack runs in its DEFAULT loop form: for the plain attacks (MI-FGSM: configs[1])
+that is attack.py::_forward_normalize_folded (ta_normalize_adv_fwd -> backbone -> ta_mi_update_std), which never
+materialises d(loss)/d(delta); there the recorded gradient at the BACKBONE'S INPUT is injected (``Attack.grad_inject``) and the
+update kernel forms gy / std itself -- ``std_form_launches == K`` asserted; the attacks that override a hook (DTS, VMI, the
+ensemble) run the hook loop, where ``get_grad`` is replaced.  By induction the iterates coincide, so
   * the final perturbation and the uint8 images must equal the oracle's BIT FOR BIT (and the reference's golden bytes,
     whenever this host's CPU reproduces them -- oneDNN's summation order depends on the CPU model);
   * the GPU's own fp32 gradient is compared with the reference's at the same point, iteration by iteration (reported;
@@ -29,6 +33,7 @@ pytestmark = pytest.mark.gpu
 EPS, ALPHA = 16 / 255, 1.6 / 255
 DEV = "cuda"
 ENS_MEMBERS = ("resnet50", "vgg16", "inception_v3", "vit_base_patch16_224")
+FOLDED_LOOP = ("fgsm", "ifgsm", "mifgsm")        # attacks whose default loop on a 224-pixel surrogate is _forward_normalize_folded
 
 
 def t(a):
@@ -74,6 +79,8 @@ def replay(monkeypatch, name, model_names, n, golden_arrays, key, oracle_kw=None
     trace = []
     delta_ref = O.run_attack(name, cpu_models if len(cpu_models) > 1 else cpu_models[0], x, label, trace=trace, **oracle_kw)
     ref_grads = [g for rec in trace for g in rec["grads"]]
+    ref_gy = [g for rec in trace for g in rec.get("grads_y", [])]
+    folded_loop = name in FOLDED_LOOP
     u8_ref = O.quantize_u8(x + delta_ref)
     host_matches_golden = np.array_equal(u8_ref, golden_arrays[key])
     lanes = host_sum_lanes()
@@ -94,21 +101,40 @@ def replay(monkeypatch, name, model_names, n, golden_arrays, key, oracle_kw=None
         stats, it = [], [0]
         orig_get_grad = type(atk).get_grad
 
-        def get_grad(self, loss, delta, **kw):
-            gpu = orig_get_grad(self, loss, delta, **kw).cpu()
+        def compare(gpu):
             ref = ref_grads[it[0]]
             diff = (gpu - ref).abs()
             stats.append((float((gpu - ref).norm() / ref.norm()), float((diff <= 1e-5 * ref.abs().max()).float().mean()),
                           float((torch.sign(gpu) != torch.sign(ref)).float().mean())))
             it[0] += 1
-            return ref.to(DEV)
+            return ref
 
-        type(atk).get_grad = get_grad
+        def get_grad(self, loss, delta, **kw):
+            return compare(orig_get_grad(self, loss, delta, **kw).cpu()).to(DEV)
+
+        def inject(iteration, gy):
+            # the default loop of this attack never forms d(loss)/d(delta): it hands gy, the backbone's own input gradient, to
+            # ta_mi_update_std, which divides by std[c] inline.  Replayed: the reference's gy of this iteration, whose
+            # Normalize backward (utils.py:76: gy / std) IS the gradient the reference's get_grad returned -- checked here
+            std = atk.model[0].normalize.std.reshape(1, -1, 1, 1)
+            compare((gy / std).cpu())
+            want = ref_gy[iteration]
+            assert torch.equal(want / std.cpu(), ref_grads[iteration]), "recorded gy / std is not the recorded gradient"
+            return want.to(DEV)
+
+        if folded_loop:
+            assert len(ref_gy) == len(ref_grads), "the oracle recorded no gradient at the backbone's input"
+            atk.grad_inject = inject
+        else:
+            type(atk).get_grad = get_grad
         if draw_seed is not None:
             torch.manual_seed(draw_seed)
+        launches = _hip.stats["std_form_launches"]
         delta = atk(x, label)
         monkeypatch.delenv("TA_ATEN_SUM_LANES", raising=False)
         assert it[0] == len(ref_grads), "the loop asked for %d gradients, the reference for %d" % (it[0], len(ref_grads))
+        if folded_loop:           # it WAS the default loop form (the one bench.py times), one std-form update per iteration
+            assert _hip.stats["std_form_launches"] - launches == len(ref_grads) == atk.epoch
         s = np.array(stats)
         u8 = quantize_images(x, delta)
         d_bad = float((delta.cpu() != delta_ref).float().mean())
@@ -133,9 +159,10 @@ def replay(monkeypatch, name, model_names, n, golden_arrays, key, oracle_kw=None
 
 def test_config2_mifgsm_resnet50_replay(golden, monkeypatch):
     """BASELINE.json configs[1] in miniature: MI-FGSM, ResNet-50, 224 x 224, K = 10, 4 images"""
-    before = _hip.stats["partials_reused"]
+    before = dict(_hip.stats)
     replay(monkeypatch, "mifgsm", ["resnet50"], 4, golden("config2_mifgsm_resnet50_n4"), "adv_u8")
-    assert _hip.stats["partials_reused"] == before           # replayed gradients are fresh tensors: own K1 pass each time
+    assert _hip.stats["partials_reused"] == before["partials_reused"]      # replayed gradients are fresh tensors: a sum-only
+    assert _hip.stats["k1_passes"] - before["k1_passes"] in (10, 20)       # pass (ta_abs_sum_partials_std) each time: K per sum order
 
 
 def test_config3_dts_resnet50_replay(golden, monkeypatch):

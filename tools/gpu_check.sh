@@ -11,35 +11,49 @@ lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket" > $OUT/host.txt
 for step in $STEPS; do
 case $step in
 tests)
-  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider -s --durations=25 > $OUT/pytest_gpu.log 2>&1
+  # the driver's tier (-m gpu, <= 900 s wanted against its 1200 s step limit), timed as the driver times it; then the 1000-image
+  # forms of the two slowest ASR jobs (-m gpu_long)
+  t0=$(date +%s)
+  timeout 1500 python -m pytest tests -m gpu -x -q --timeout 1200 -p no:cacheprovider -s --durations=25 > $OUT/pytest_gpu.log 2>&1
+  echo "pytest -m gpu -x -q wall: $(( $(date +%s) - t0 )) s" | tee -a $OUT/pytest_gpu.log
   grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -30 ;;
+newtests6)
+  # round 6: the default (folded) loop form under replay, the deterministic hook-vs-folded comparison, the 256-image ASR jobs
+  timeout 1200 python -m pytest tests/test_hip_configs.py tests/test_hip_attacks.py tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider --durations=12 \
+      -k "config2 or config1 or fused_resnet or folded_loop or four_members or vmifgsm_vit or deterministic" 2>&1 | grep -v Warning | tee $OUT/newtests6_pytest.txt | tail -40 ;;
+coldranks)
+  # bench.py --gpus 2 on ONE device with fresh MIOpen databases: rank 0 warms up first vs both together (tools/cold_start_ranks.py)
+  timeout 2400 python tools/cold_start_ranks.py --runs ${TA_COLD_RUNS:-one,one:warm,staged,together} 2> $OUT/cold_start_ranks.err | tee $OUT/cold_start_ranks.jsonl ;;
+asrlong)
+  timeout 1200 python -m pytest tests -m gpu_long -q -p no:cacheprovider -s > $OUT/pytest_gpu_long.log 2>&1
+  grep -E "passed|failed|images in" $OUT/pytest_gpu_long.log | tail -6 ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
 bench)
   timeout 900 python bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json ;;
 batches)
-  for b in 32 64 250; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+  for b in 32 64 250; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
 literal)
   # the reference's literal arrangement: batches of 32, NCHW, separate BatchNorm
-  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --fold-bn 0 --channels-last 0 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_literal_b32.json ;;
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --fold-bn 0 --channels-last 0 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_literal_b32.json ;;
 kernels)
   timeout 600 python tools/kernel_bench.py > $OUT/kernel_bench.json 2> $OUT/kernel_bench.err; cat $OUT/kernel_bench.json; tail -3 $OUT/kernel_bench.err ;;
 freq)
   # SSM (20 spectrum views per iteration): the transform is two launches of the fp32-MFMA kernel ta_dct_pair
-  timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ssm_b16.json
+  timeout 600 python bench.py --attack ssm --batch 16 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ssm_b16.json
   timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -8 | tee $OUT/spectrum_microbench.txt ;;
 k2sweep)
   mkdir -p tools/bin; [ -x tools/bin/k2_sweep ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/k2_sweep.hip -o tools/bin/k2_sweep
   timeout 300 tools/bin/k2_sweep > $OUT/k2_sweep.txt 2>&1; cat $OUT/k2_sweep.txt ;;
 configs)
-  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json
-  timeout 600 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32.json
-  timeout 600 python bench.py --attack sia --batch 16 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_sia_b16.json ;;
+  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json
+  timeout 600 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32.json
+  timeout 600 python bench.py --attack sia --batch 16 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_sia_b16.json ;;
 vmi)
-  timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32.json ;;
+  timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --fold-bn 0 --channels-last 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32.json ;;
 gpus1)
   # the self-launch path of bench.py --gpus N on a one-GPU box: N = 1 under torch.distributed.run (RCCL world of 1)
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_torchrun_n1.json
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_torchrun_n1.json
   timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 2>&1 | tail -1 | tee $OUT/bench_gpus2_refused.txt ;;
 spec)
   timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -10 | tee $OUT/spectrum_microbench.txt
@@ -61,13 +75,13 @@ newtests)
   timeout 600 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "folded or dts" 2>&1 | grep -v Warning | tee $OUT/asr1000_fused_pytest.txt | tail -30 ;;
 benchpair)
   # the default line with the surrogate's glue fused (default) and through the plain module path
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue.json
-  TA_FUSED_GLUE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_module_path.json
-  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_b32.json ;;
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue.json
+  TA_FUSED_GLUE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_module_path.json
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_b32.json ;;
 stempair)
   # the default line with the stem's input gradient on csrc/stem.hip (default) and on MIOpen
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_stem.json
-  TA_STEM_KERNEL=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_miopen_stem.json ;;
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_stem.json
+  TA_STEM_KERNEL=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_miopen_stem.json ;;
 fusedtest)
   timeout 600 python -m pytest tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider -k "fused" 2>&1 | grep -v Warning | tee $OUT/fused_pytest.txt | tail -12 ;;
 ktrace)
@@ -85,18 +99,18 @@ steady)
   # what the metric is made of: steady-state kernels of the default bench line.  MIOpen's find-db is warmed by a prior
   # process (its trial kernels stay out of the trace), then the trace is reduced ON THE BOX (tools/steady_trace.py)
   B=${TA_STEADY_BATCH:-125}; X=${TA_STEADY_EXTRA:-}
-  timeout 600 python bench.py --steps 1 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 > /dev/null 2>> $OUT/bench.err
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/steady_b$B -o trace -- python $R/bench.py --steps 4 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 > $R/$OUT/steady_b$B.log 2>&1 )
+  timeout 600 python bench.py --steps 1 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 --literal-steps 0 > /dev/null 2>> $OUT/bench.err
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/steady_b$B -o trace -- python $R/bench.py --steps 4 --warmup 1 --batch $B $X --cpu-images 0 --kernel-sweep 0 --literal-steps 0 > $R/$OUT/steady_b$B.log 2>&1 )
   tail -1 $OUT/steady_b$B.log
   python tools/steady_trace.py $OUT/steady_b$B $OUT/steady_state_b$B.json 30 | tee $OUT/steady_state_b$B.txt
   f=$(find $OUT/steady_b$B -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/steady_state_b${B}_kernel_stats.csv
   find $OUT/steady_b$B -name "*kernel_trace.csv" -delete; find $OUT/steady_b$B -name "*.db" -delete ;;
 sweep)
-  for b in 32 64 250 500; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
+  for b in 32 64 250 500; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
 asr)
   timeout 1500 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr1000_pytest.txt | tail -60 ;;
 rocprof)
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 8 --warmup 2 --cpu-images 0 --kernel-sweep 0 > $R/$OUT/rocprof.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 8 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 > $R/$OUT/rocprof.log 2>&1 )
   tail -1 $OUT/rocprof.log
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && (head -1 "$f"; grep -E "ta::" "$f"; grep -v naive "$f" | head -12 | cut -c1-160)
   find $OUT/prof -name "*kernel_trace.csv" -size +8M -delete; find $OUT/prof -name "*.db" -delete ;;
@@ -107,23 +121,23 @@ newtests4)
 asr4)
   timeout 1200 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "mifgsm_resnet50 or dts" 2>&1 | grep -v Warning | tee $OUT/asr4_pytest.txt | tail -60 ;;
 bench32)
-  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_b32.json
-  TA_U8_SOURCE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_b125_fp32_source.json ;;
+  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_b32.json
+  TA_U8_SOURCE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_b125_fp32_source.json ;;
 ens4)
   # configs[4] on one GPU at the reference's batch and at the per-GPU shard (ensemble MI-FGSM treats images independently)
   for b in 32 125; do
-  timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
+  timeout 900 python bench.py --attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch $b --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b$b.json
   done ;;
 dimclock)
   # where a DIM tile's cycles go: per-phase shader-clock cycles of the two lane-per-column kernels (a tuning build of dim.hip)
   timeout 300 python tools/dim_phase_clock.py 2>&1 | tee $OUT/dim_phase_clock.txt ;;
 benchq)
   # the default line without the CPU leg and the stand-alone sweep; then with the ReLU pass bits off (activations read instead)
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick.json
-  TA_RELU_BITS=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick_no_relu_bits.json ;;
+  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick.json
+  TA_RELU_BITS=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick_no_relu_bits.json ;;
 ensab)
   # configs[4] at the reference's batch: members one after the other / on their own HIP streams, then what the iteration is made of
-  M="--attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --cpu-images 0 --kernel-sweep 0"
+  M="--attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0"
   TA_ENS_STREAMS=0 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_one_stream.json
   TA_ENS_STREAMS=1 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_member_streams.json
   ( cd /tmp && TA_ENS_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ens_trace -o trace -- python $R/bench.py $M --steps 2 --warmup 1 > $R/$OUT/ens_trace.log 2>&1 )
@@ -133,7 +147,7 @@ ensab)
 members)
   # one member at a time (MI-FGSM, batch 32): where configs[4]'s time goes
   for m in vgg16 inception_v3 vit_base_patch16_224 mobilenet_v2; do
-  timeout 600 python bench.py --model $m --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_member_$m.json
+  timeout 600 python bench.py --model $m --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_member_$m.json
   done ;;
 dimpmc)
   for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
@@ -159,7 +173,7 @@ newtests5)
 det)
   # TA_DETERMINISTIC=1: two processes write identical PNGs; what the switch costs on the bench line
   timeout 1500 python -m pytest tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider -k "deterministic_mode" 2>&1 | grep -v Warning | tee $OUT/det_pytest.txt | tail -12
-  TA_DETERMINISTIC=1 timeout 900 python bench.py --steps 4 --warmup 1 --cpu-images 0 --kernel-sweep 0 2>> $OUT/bench.err | tee $OUT/bench_deterministic.json ;;
+  TA_DETERMINISTIC=1 timeout 900 python bench.py --steps 4 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_deterministic.json ;;
 coldstart)
   timeout 1500 python tools/cold_start.py --modes ${TA_COLD_MODES:-immediate,immediate:warm,fast,fast:warm} --keep $OUT/miopen 2> $OUT/cold_start.err | tee $OUT/cold_start.jsonl
   du -sh $OUT/miopen/* 2>/dev/null ;;
@@ -189,7 +203,7 @@ dimab2)
 vmistack)
   # configs[3]: VMI-FGSM / ViT-B/16, k neighbour samples per surrogate evaluation
   for k in ${TA_VMI_KS:-1 5 10}; do
-  TA_VMI_STACK=$k timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32_stack$k.json | cut -c1-400
+  TA_VMI_STACK=$k timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32_stack$k.json | cut -c1-400
   done ;;
 newtests5b)
   timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
@@ -197,7 +211,7 @@ newtests5b)
 trained)
   timeout 900 python -m pytest tests/test_hip_asr_trained.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr_trained_pytest.txt | tail -30 ;;
 dts)
-  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json | cut -c1-1500 ;;
+  timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json | cut -c1-1500 ;;
 retest)
   timeout 600 python -m pytest tests/test_hip_attacks.py tests/test_hip_asr1000.py tests/test_hip_asr_trained.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
       -k "fused_resnet or mifgsm_resnet50 or (trained and mifgsm) or registry_rules" 2>&1 | grep -v Warning | tee $OUT/retest_pytest.txt | tail -40 ;;

@@ -362,11 +362,14 @@ def mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilo
         dev = grad.device
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(dev))
+        k1_before = stats["k1_passes"]
         _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8, std)
         end.record(torch.cuda.current_stream(dev))
         bytes_per_elem = 4 * (3 + (variance is not None) + (momentum_in is not None) + 1 + (momentum_out is not None)
                               + (x_adv is not None))       # r g,(v),(m),d,x  w (m),d,(x_adv): the ALGORITHMIC bytes
-        profile_sink.append((start, end, n, e, bytes_per_elem, data_u8 is not None, std is not None))
+        # (..., byte source offered, std form, did THIS launch run its own sum pass over the gradient)
+        profile_sink.append((start, end, n, e, bytes_per_elem, data_u8 is not None, std is not None,
+                             stats["k1_passes"] > k1_before))
         return
     _mi_update(grad, momentum_in, momentum_out, delta, data, decay, alpha, epsilon, variance, x_adv, n, e, data_u8, std)
 

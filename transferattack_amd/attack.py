@@ -64,12 +64,31 @@ def deterministic_mode():
     this package's own kernels never use floating-point atomics (include/ta_hip.h).  What remains outside: ATen's max-pool
     backward on the plain module path of a CNN surrogate -- the fused ResNet path (folded BatchNorm + NHWC, bench.py's
     arrangement) replaces it by the gather kernel ``ta_maxpool_bwd_relu``; that arrangement is the one
-    ``tests/test_hip_attacks.py::test_deterministic_mode_writes_identical_pngs`` pins.  Returns whether the mode is on."""
+    ``tests/test_hip_attacks.py::test_deterministic_mode_writes_identical_pngs`` pins.  The torch flags are process-wide: they
+    stay as this function set them until an attack is constructed (or this function is called) with the variable unset or 0,
+    which puts back what it found.  ``torch.utils.deterministic.fill_uninitialized_memory`` is switched off with it: that
+    companion of ``use_deterministic_algorithms`` NaN-fills every ``torch.empty`` -- one more pass over each buffer of the hot
+    loops, all of which the HIP kernels overwrite completely.  Returns whether the mode is on."""
+    global _flags_before_deterministic
     if os.environ.get("TA_DETERMINISTIC", "0") != "1":
+        if _flags_before_deterministic is not None:
+            cudnn_det, algos, warn_only, fill = _flags_before_deterministic
+            torch.backends.cudnn.deterministic = cudnn_det
+            torch.use_deterministic_algorithms(algos, warn_only=warn_only)
+            torch.utils.deterministic.fill_uninitialized_memory = fill
+            _flags_before_deterministic = None
         return False
+    if _flags_before_deterministic is None:
+        _flags_before_deterministic = (torch.backends.cudnn.deterministic, torch.are_deterministic_algorithms_enabled(),
+                                       torch.is_deterministic_algorithms_warn_only_enabled(),
+                                       torch.utils.deterministic.fill_uninitialized_memory)
     torch.backends.cudnn.deterministic = True
     torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = False
     return True
+
+
+_flags_before_deterministic = None          # the process-wide torch flags deterministic_mode() found when it first changed them
 
 
 class Attack(object):
@@ -99,6 +118,9 @@ class Attack(object):
         self.normal_source = None
         # test hook of loops that never call get_grad (the folded VMI chain): callable(iteration, gradient)
         self.grad_probe = None
+        # test hook of the folded plain loop: callable(iteration, gy) -> the tensor the update consumes INSTEAD of gy, the
+        # backbone's own input gradient (tests replay the reference's recorded gy through the default loop form)
+        self.grad_inject = None
 
     # ------------------------------------------------------------------------------------------ model
     def load_model(self, model_name):
@@ -172,12 +194,18 @@ class Attack(object):
         """(mean, std) of the surrogate's Normalize if NOTHING else sits between ``data + delta`` (attack.py:88) and the
         backbone, and nobody can observe the tensors in between: the base ``transform`` (identity), ``get_logits`` and
         ``get_grad``; ``self.model`` the plain ``nn.Sequential(PreprocessingModel, backbone)`` of ``wrap_model`` whose Resize is
-        the identity at this image size; no hook on the wrapper, the preprocessing layer or its two sub-modules; no gradient
-        probe.  Then the Normalize is folded into both ends of the iteration (``_forward_normalize_folded``).
-        ``TA_FOLD_NORMALIZE=0`` turns it off."""
+        the identity at this image size; no hook on the wrapper, the preprocessing layer or its two sub-modules, and no
+        process-wide module hook (``torch.nn.modules.module.register_module_*_hook``: it would be called for the modules the
+        folded loop skips).  Then the Normalize is folded into both ends of the iteration (``_forward_normalize_folded``;
+        ``grad_probe`` / ``grad_inject`` are served inside it).  ``TA_FOLD_NORMALIZE=0`` turns it off."""
+        from torch.nn.modules import module as _nn_module
         from .utils import PreprocessingModel, _Normalize, _Resize
         if os.environ.get("TA_FOLD_NORMALIZE", "1") == "0" or self._overrides("transform", "get_logits", "get_grad"):
             return None
+        for registry in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks",
+                         "_global_backward_pre_hooks", "_global_forward_hooks_always_called"):
+            if getattr(_nn_module, registry, None):
+                return None
         model = self.model
         if type(model) is not nn.Sequential or len(model) != 2 or type(model[0]) is not PreprocessingModel:
             return None
@@ -220,6 +248,8 @@ class Attack(object):
             gy = torch.autograd.grad(loss, y, retain_graph=False, create_graph=False)[0]
             if self.grad_probe is not None:             # test hook: the gradient of attack.py:118-122, materialised for it
                 self.grad_probe(it, gy / std.view(1, -1, 1, 1))
+            if self.grad_inject is not None:            # test hook: a recorded gy replaces the device's (a fresh tensor: it
+                gy = self.grad_inject(it, gy).contiguous()      # carries no sums, so the sum-only pass precedes the update)
             momentum = self._fused_update(gy, momentum, delta, data, grad_std=std)
         return delta.detach()
 
