@@ -26,11 +26,19 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 9
+#define TA_ABI_VERSION 10
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
 const char* ta_last_error(void);
+/* Order of the per-image sum of |g| (transferattack/attack.py:128: grad.abs().mean(dim=(1,2,3))).  0 (the default): the
+ * kernels' own fixed order.  8 / 16: ATen's vectorised cascade for a CPU of that SIMD width (AVX2 / AVX-512) -- the
+ * verification mode in which momentum, delta and whole loops carry the reference's bits; K1 then runs as one workgroup per
+ * image, producer-side sums must not be handed in (ws_slots = 0), ta_bsr_bwd adds in ATen's visiting order.  Process-wide,
+ * read by every later call (the Python binding sets it from TA_ATEN_SUM_LANES; the library itself reads no environment).
+ * Returns TA_EINVAL for any other value. */
+int ta_set_sum_order(int lanes);
+int ta_get_sum_order(void);
 /* Launch timing (bench.py's roofline figure): between ta_timing_begin(capacity) and ta_timing_end, each ta_mi_update
  * call (up to `capacity`) carries a pair of HIP events on the dispatch packets of its own kernels -- start on its first
  * kernel (K1 when the |g| sums are not handed over, else the update kernel), stop on the update kernel.  ta_timing_end

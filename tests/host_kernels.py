@@ -48,7 +48,7 @@ def install(monkeypatch, tag=None, env=None):
     monkeypatch.setattr(_hip, "_stream", lambda like=None: None)
 
     def call(name, like, *args):                 # no device / stream on the host: the "launch" runs synchronously
-        _hip._check(getattr(_hip.load(), name)(*args, None), name)
+        _hip._check(getattr(_hip._sync_options(_hip.load()), name)(*args, None), name)
 
     monkeypatch.setattr(_hip, "_call", call)
     monkeypatch.setattr(_hip, "workspace", _hip.Workspace())

@@ -589,20 +589,6 @@ def test_dim_random(size, rate, geoms):
 
 
 # -------------------------------------------------------------------------------------------- SIM / Admix
-def test_dim_row_band_kernels(golden, monkeypatch):
-    """the row-band forms of the DIM pair (TA_DIM_BAND=1: one lane per column, a band of 32 rows x all columns per workgroup,
-    vertical passes over compile-time source rows, row tables fetched with v_readlane) and the tile kernels in the hardware's
-    XCD-contiguous workgroup order (TA_DIM_XCD=1): the same bits as the default kernels -- golden tensors and random geometries"""
-    for env in (dict(TA_DIM_BAND="1"), dict(TA_DIM_XCD="1")):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        test_dim_golden(golden)
-        test_dim_random(224, 1.1, [(224, 0, 0), (224, 22, 22), (245, 0, 1), (245, 1, 0), (237, 3, 5), (230, 16, 0)])
-        test_dim_random(200, 1.15, [(200, 0, 29), (228, 0, 1), (215, 7, 9)])
-        for k in env:
-            monkeypatch.delenv(k)
-
-
 def test_sim_admix_golden(golden):
     g = golden("copies")
     x = dev(g["x"])

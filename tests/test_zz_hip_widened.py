@@ -482,7 +482,7 @@ def test_reference_sum_order(golden, monkeypatch):
             n, e = shape[0], v[0].numel()
             ws = torch.zeros(int(_hip.load().ta_l1_workspace_floats(n, e)), device=DEV)
             vd = v.to(DEV)
-            assert _hip.load().ta_abs_sum_partials(vd.data_ptr(), None, ws.data_ptr(), n, e,
+            assert _hip._sync_options(_hip.load()).ta_abs_sum_partials(vd.data_ptr(), None, ws.data_ptr(), n, e,
                                                    None if DEV == "cpu" else torch.cuda.current_stream().cuda_stream) == 0
             tiles = ws.numel() // (2 * n)
             rows = ws.cpu().numpy()

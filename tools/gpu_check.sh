@@ -178,26 +178,14 @@ coldstart)
   timeout 1500 python tools/cold_start.py --modes ${TA_COLD_MODES:-immediate,immediate:warm,fast,fast:warm} --keep $OUT/miopen 2> $OUT/cold_start.err | tee $OUT/cold_start.jsonl
   du -sh $OUT/miopen/* 2>/dev/null ;;
 dimab)
-  # DIM: row-band kernels (round 5) against the tile kernels, event timing + rocprofv3 durations + HBM counters at N = 160
-  timeout 300 python tools/tim_microbench.py 2>&1 | tee $OUT/dim_band_vs_tiles.txt
+  # DIM pair + TIM: event timing, rocprofv3 durations and HBM counters at N = 160
+  timeout 300 python tools/tim_microbench.py 2>&1 | tee $OUT/dim_tim_microbench.txt
   ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/dimtrace -o trace -- python $R/tools/tim_microbench.py > $R/$OUT/dimtrace.log 2>&1 )
   f=$(find $OUT/dimtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dim_kernel_stats_n160.csv && grep -E "Name|dim_|dwconv" "$f" | cut -c1-200
   find $OUT/dimtrace -name "*kernel_trace.csv" -delete; find $OUT/dimtrace -name "*.db" -delete
-  for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
-  tag=$(echo $c | cut -d' ' -f1)
-  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/dimpmc_$tag -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_$tag.log 2>&1 )
-  python tools/pmc_kernels.py $OUT/dimpmc_$tag | tee -a $OUT/dimpmc_summary.txt
-  done
-  find $OUT -name "*.db" -delete ;;
-dimab2)
-  timeout 300 python tools/tim_microbench.py 2>&1 | tee $OUT/dim_variants.txt
-  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/dimtrace -o trace -- python $R/tools/tim_microbench.py > $R/$OUT/dimtrace.log 2>&1 )
-  f=$(find $OUT/dimtrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dim_kernel_stats_n160.csv
-  find $OUT/dimtrace -name "*kernel_trace.csv" -delete; find $OUT/dimtrace -name "*.db" -delete
-  for v in 1 0; do
-  echo "== tile kernels, TA_DIM_XCD=$v (1 = XCD-contiguous tile order, the default; 0 = the hardware's order)" | tee -a $OUT/dimpmc_summary.txt
-  ( cd /tmp && TA_N=160 TA_DIM_VARIANTS=0 TA_DIM_XCD=$v timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/dimpmc_xcd$v -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_xcd$v.log 2>&1 )
-  python tools/pmc_kernels.py $OUT/dimpmc_xcd$v | tee -a $OUT/dimpmc_summary.txt
+  for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/dimpmc_$c -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_$c.log 2>&1 )
+  python tools/pmc_kernels.py $OUT/dimpmc_$c | tee -a $OUT/dimpmc_summary.txt
   done
   find $OUT -name "*.db" -delete ;;
 vmistack)

@@ -16,27 +16,9 @@ for n in sizes:
     o = torch.empty_like(g[0])
     w = torch.rand(15, 15, device="cuda")
     w = (w / w.sum()).contiguous()
-    def with_env(fn, **env):
-        """the same call under an environment knob of the DIM launchers (read per call)"""
-        def call(i):
-            os.environ.update(env)
-            try:
-                fn(i)
-            finally:
-                for k in env:
-                    os.environ.pop(k)
-        return call
     fwd = lambda i: _hip.dim_fwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
     bwd = lambda i: _hip.dim_bwd(g[i % 3], o, 246, 237, 3, 5)      # noqa: E731
-    if os.environ.get("TA_DIM_VARIANTS", "1") == "0":             # counter runs: one variant per process (env set outside)
-        cases = (("dim_fwd", fwd), ("dim_bwd", bwd))
-    else:
-        cases = (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)),
-                 ("dim_fwd (tiles, hardware order: default)", fwd), ("dim_bwd (tiles, hardware order: default)", bwd),
-                 ("dim_fwd (tiles, XCD-contiguous order, TA_DIM_XCD=1)", with_env(fwd, TA_DIM_XCD="1")),
-                 ("dim_bwd (tiles, XCD-contiguous order, TA_DIM_XCD=1)", with_env(bwd, TA_DIM_XCD="1")),
-                 ("dim_fwd (row bands, TA_DIM_BAND=1)", with_env(fwd, TA_DIM_BAND="1")),
-                 ("dim_bwd (row bands, TA_DIM_BAND=1)", with_env(bwd, TA_DIM_BAND="1")))
+    cases = (("tim 15x15", lambda i: _hip.depthwise_conv2d_same(g[i % 3], o, w)), ("dim_fwd", fwd), ("dim_bwd", bwd))
     for name, call in cases:
         for i in range(6):
             call(i)

@@ -27,6 +27,8 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "ta_abi_version": (_int, []),
     "ta_last_error": (ctypes.c_char_p, []),
+    "ta_set_sum_order": (_int, [_int]),
+    "ta_get_sum_order": (_int, []),
     "ta_timing_begin": (_int, [_int]),
     "ta_timing_end": (_int, [_vp, _int, _vp]),
     "ta_l1_workspace_floats": (_i64, [_i64, _i64]),
@@ -80,7 +82,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HipExtensionError(RuntimeError):
@@ -143,9 +145,27 @@ def _check(rc, what):
         raise HipExtensionError("%s failed (rc=%d): %s" % (what, rc, msg))
 
 
+def sum_order():
+    """0, or the SIMD width (8 / 16) of the CPU whose ATen sum order ``TA_ATEN_SUM_LANES`` asks the kernels to reproduce"""
+    value = os.environ.get("TA_ATEN_SUM_LANES", "0")
+    return int(value) if value in ("8", "16") else 0
+
+
+def _sync_options(lib):
+    """The library reads no environment: the one process-wide setting it has -- the order of the |g| sums -- is pushed through
+    the ABI whenever ``TA_ATEN_SUM_LANES`` differs from what this library object was last told (tests flip it inside one
+    process).  One dict lookup per call when nothing changed."""
+    want = sum_order()
+    if getattr(lib, "_ta_sum_order", 0) != want:
+        if lib.ta_set_sum_order(want) != 0:
+            raise HipExtensionError("ta_set_sum_order(%d) refused" % want)
+        lib._ta_sum_order = want
+    return lib
+
+
 def _call(name, like, *args):
     """lib.<name>(*args, stream) on ``like``'s device and its current torch stream; raises on a non-zero return."""
-    fn = getattr(load(), name)
+    fn = getattr(_sync_options(load()), name)
     dev = like.device
     if dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):                    # the launch needs the tensor's device current in THIS thread
@@ -239,7 +259,7 @@ def _take_partials(grad, variance=None, std=None):
     for exactly that variance tensor; if ``std`` is given, of |grad / std[c]| for exactly that std vector); the attribute
     is consumed either way"""
     entry = grad.__dict__.pop(_ATTR, None)
-    if entry is None or os.environ.get("TA_ATEN_SUM_LANES", "0") not in ("", "0"):
+    if entry is None or sum_order() != 0:
         return None                                   # the reference-order sum is never taken from a producer
     version, ws, slots, stream, var, var_version, std_key = entry
     same_variance = (var is None and variance is None) or (

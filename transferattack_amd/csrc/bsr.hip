@@ -15,7 +15,7 @@
 // grid_sampler compiled with contraction) places them [probe, torch 2.10 CPU: these expressions reproduce
 // F.grid_sample's forward bit for bit] -> the forward equals the reference's.  The backward adds, per source pixel, the
 // products weight * gy of the rotated pixels that reach it: in raster order by default; in ATen's order when
-// TA_ATEN_SUM_LANES = 8 | 16 is set (its vectorised backward walks the flattened strip in chunks of `lanes` pixels and,
+// ta_set_sum_order(8 | 16) is in force (its vectorised backward walks the flattened strip in chunks of `lanes` pixels and,
 // inside a chunk, corner by corner -- nw, ne, sw, se -- then lane by lane), which makes the backward the reference's
 // bit for bit as well.  Forward and backward use the SAME device function for the sampling point.
 //
@@ -306,9 +306,7 @@ extern "C" int ta_bsr_bwd(const float* gy, const int32_t* plan, float* gx, float
     TA_REQUIRE(plan_ints <= kBsrMaxPlanInts, "copies * plan stride exceeds the %d ints staged in LDS", kBsrMaxPlanInts);
     TA_REQUIRE(static_cast<int64_t>(h) * w < (1ll << 29), "plane too large");
     const int row_tiles = static_cast<int>(ceil_div(h, kBsrBwdRows));
-    const char* env = getenv("TA_ATEN_SUM_LANES");               // verification mode, read at every call like update.hip's
-    const int value = env == nullptr ? 0 : atoi(env);
-    const int lanes = (value == 8 || value == 16) ? value : 0;
+    const int lanes = sum_order_lanes();                          // verification mode (ta_set_sum_order): ATen's visiting order
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = static_cast<size_t>(plan_ints) * sizeof(int);
     const int pp = lanes ? 1 : bsr_planes_per_thread(planes, row_tiles, 768, 6);     // 12 planes: no faster than 6 (r2k)

@@ -146,23 +146,11 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
-// XCD-aware tile order (MI355X: 8 XCDs, each with its own L2; the dispatcher hands workgroup b to XCD b % 8).  The tiles of a
-// plane overlap in the cache lines at their left / right edges and in the rows between bands: with the hardware's own order
-// four horizontally adjacent tiles sit on four different XCDs and every shared line is fetched from HBM four times (PMC: 1.96 x
-// the algorithmic bytes in the forward).  Logical tile id = (b % 8) * ceil(n / 8) + b / 8 gives each XCD a CONTIGUOUS run of
-// tiles -- neighbours share an L2.  `swizzle` = 0 keeps the hardware order (the default: see xcd_order below).
-__device__ __forceinline__ int xcd_tile(int b, int n, int swizzle) {
-    if (!swizzle) return b;
-    const int per = (n + 7) >> 3;
-    const int id = (b & 7) * per + (b >> 3);
-    return id;                                           // ids >= n (ragged last chunk) are skipped by the caller
-}
-
 template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int total, int swizzle) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
@@ -174,8 +162,7 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
     const int tiles = tiles_x * tiles_y;
-    const int tid = xcd_tile(static_cast<int>(blockIdx.x), total, swizzle);
-    if (tid >= total) return;                                          // (the grid is padded to a multiple of 8 workgroups)
+    const int tid = static_cast<int>(blockIdx.x);
     const int plane = tid / tiles;                                     // grid < 2^31 (host-checked)
     const int t = tid - plane * tiles;
     const int tyi = t / tiles_x;
@@ -278,123 +265,6 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
         }
     }
     TA_PHASE(0, 5);
-}
-
-// Row-band form of the forward (round 5).  PMC on the lane-per-column kernel (profiles/r04/dim_tim_pmc_n160_r4b.txt): HBM
-// traffic 1.96 x the algorithmic bytes at less than half the bandwidth, 57 % of a wave's life in s_waitcnt.  Both come from
-// the tile shape: a 32 x <= 64-column tile reads row segments of ~230 bytes that start and end inside cache lines, which its
-// left / right neighbours -- on other XCDs, i.e. behind other L2s -- fetch again; and five barrier-separated phases each do
-// seven elements' worth of work per lane.  Here a workgroup owns R output rows x ALL columns of a plane:
-//   * one LANE per column (resize <= 256: a padded-image column in the first half, an output column in the second), so every
-//     row of x is read once, whole and aligned; only the <= 3 rows between two bands are read twice;
-//   * the two VERTICAL passes need no exchange at all: a lane's column stays in its own registers.  The loops run over the
-//     SOURCE rows with compile-time indices (all x loads of the lane are issued up front, 2 * SH registers) and, inside, a
-//     wave-uniform `while` emits the destination rows that became computable -- the row taps (LDS, one broadcast read) decide
-//     WHEN, a uniform select decides WHICH of the two newest source rows is the first operand: no dynamic register index;
-//   * the one HORIZONTAL exchange (H2 reads its two padded columns from other lanes) goes through LDS: one barrier.
-// Same four fused-multiply-add expressions in the same order as the kernels above (ATen's: width first, then height): same bits.
-// wave-uniform row tables without memory: lane l of every wave HOLDS the entry of row l in its registers (a band has fewer
-// than 64 rows) and v_readlane_b32 fetches the entry of the -- wave-uniform -- row the loop is at: a few cycles, where an LDS
-// table cost a round trip per row inside a serial loop (the first version of these kernels, profiles/r05: 2 x slower than
-// the tile kernels for that reason alone)
-__device__ __forceinline__ int lane_get(int v, int row) { return __builtin_amdgcn_readlane(v, row); }
-__device__ __forceinline__ float lane_get(float v, int row) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), row)); }
-
-template <int R, int MH, int SH>      // output rows per band; bounds of the padded-window rows / x rows behind a band
-__global__ __launch_bounds__(kBlock) void dim_fwd_band_kernel(const float* __restrict__ x, float* __restrict__ y, int size,
-                                                              int resize, int rnd, int top, int left, float scale1,
-                                                              float scale2, int bands) {
-    static_assert(MH <= 64 && R <= 64, "one lane per row of the tables");
-    __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];       // the zero-padded, rescaled window: [p][padded column]
-    const int t = static_cast<int>(threadIdx.x), lane = t & 63;
-    const int plane = static_cast<int>(blockIdx.x) / bands;
-    const int band = static_cast<int>(blockIdx.x) - plane * bands;
-    const int oy0 = band * R, th = min(R, size - oy0);
-    const float* xp = x + static_cast<int64_t>(plane) * size * size;
-    float* yp = y + static_cast<int64_t>(plane) * size * size;
-
-    // -- the band's window (wave-uniform values, computed by every lane alike)
-    const int py_lo = make_tap_scaled(oy0, resize, scale2).i0, py_hi = make_tap_scaled(oy0 + th - 1, resize, scale2).i1;
-    const int mh = py_hi - py_lo + 1;                                     // <= MH (host-checked)
-    const int p_a = max(top - py_lo, 0), p_b = min(top + rnd - 1 - py_lo, mh - 1);     // window rows inside the rescaled image
-    const bool any_rows = p_a <= p_b;
-    const int sr_lo = any_rows ? make_tap_scaled(py_lo + p_a - top, size, scale1).i0 : 0;
-    const int sr_hi = any_rows ? make_tap_scaled(py_lo + p_b - top, size, scale1).i1 : 0;     // sr_hi - sr_lo < SH (host-checked)
-    // -- row tables, one row per lane: window row `lane` -> x rows; output row `lane` -> window rows
-    const Tap row1 = make_tap_scaled(min(max(py_lo + lane - top, 0), rnd - 1), size, scale1);
-    const Tap row2 = make_tap_scaled(min(oy0 + lane, size - 1), resize, scale2);
-    const int r1_i0 = row1.i0 - sr_lo, r1_i1 = row1.i1 - sr_lo, r2_i0 = row2.i0 - py_lo, r2_i1 = row2.i1 - py_lo;
-    // -- this lane's columns: padded column t (first resample), output column t (second resample)
-    const int rx = t - left;
-    const bool col_ok = t < resize && rx >= 0 && rx < rnd;
-    Tap tx1{0, 0, 0.f, 0.f}, tx2{0, 0, 0.f, 0.f};
-    if (col_ok) tx1 = make_tap_scaled(rx, size, scale1);
-    if (t < size) tx2 = make_tap_scaled(t, resize, scale2);
-    // -- all loads of the lane, back to back (lanes outside the image read column 0 of a valid row: in bounds, never used)
-    float xa[SH], xb[SH];
-    {
-        const char* base = reinterpret_cast<const char*>(xp);
-        const unsigned c0 = static_cast<unsigned>(tx1.i0) * 4u, c1 = static_cast<unsigned>(tx1.i1) * 4u;
-        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-#pragma unroll
-        for (int j = 0; j < SH; ++j) {
-            const unsigned row = static_cast<unsigned>(min(sr_lo + j, sr_hi)) * row_bytes;
-            xa[j] = *reinterpret_cast<const float*>(base + (row + c0));
-            xb[j] = *reinterpret_cast<const float*>(base + (row + c1));
-        }
-    }
-    // -- H1 + V1 down the lane's padded column: mid[p][t]
-    {
-        float* out = mid + t;
-        int p = 0;
-        for (; p < min(p_a, mh); ++p) out[p * kBlock] = 0.0f;             // zero padding above the image (dim.py:65)
-        float t_prev = 0.0f;
-#pragma unroll
-        for (int j = 0; j < SH; ++j) {
-            const float t_cur = fmaf(tx1.l0, xa[j], tx1.l1 * xb[j]);      // H1: row sr_lo + j of x at this lane's column
-            while (p <= p_b) {
-                if (lane_get(r1_i1, p) > j) break;                        // needs a row of x not reached yet
-                const float a = lane_get(r1_i0, p) == j ? t_cur : t_prev; // i0 is j or j - 1 (taps are monotone, i1 - i0 <= 1)
-                const float v = fmaf(lane_get(row1.l0, p), a, lane_get(row1.l1, p) * t_cur);      // V1
-                out[p * kBlock] = col_ok ? v : 0.0f;                      // zero padding left / right of the image
-                ++p;
-            }
-            t_prev = t_cur;
-        }
-        for (p = max(p_b + 1, p_a); p < mh; ++p) out[p * kBlock] = 0.0f;  // zero padding below
-    }
-    __syncthreads();
-    // -- H2 + V2 down the lane's output column (every lane walks the loop -- the row tables live in all of them -- and only
-    // the lanes that own an output column store)
-    {
-        float ma[MH], mb[MH];                                             // the lane's two window columns, all rows, up front
-#pragma unroll
-        for (int p = 0; p < MH; ++p) {
-            ma[p] = mid[p * kBlock + tx2.i0];                             // (rows >= mh: in bounds, never used)
-            mb[p] = mid[p * kBlock + tx2.i1];
-        }
-        char* base = reinterpret_cast<char*>(yp);
-        unsigned out = static_cast<unsigned>(oy0 * size + min(t, size - 1)) * 4u;
-        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-        const bool owns = t < size;
-        int r = 0;
-        float u_prev = 0.0f;
-#pragma unroll
-        for (int p = 0; p < MH; ++p) {
-            if (p < mh) {                                                 // (uniform)
-                const float u_cur = fmaf(tx2.l0, ma[p], tx2.l1 * mb[p]);  // H2: window row p
-                while (r < th) {
-                    if (lane_get(r2_i1, r) > p) break;
-                    const float a = lane_get(r2_i0, r) == p ? u_cur : u_prev;
-                    const float v = fmaf(lane_get(row2.l0, r), a, lane_get(row2.l1, r) * u_cur);   // V2
-                    if (owns) *reinterpret_cast<float*>(base + out) = v;
-                    out += row_bytes;
-                    ++r;
-                }
-                u_prev = u_cur;
-            }
-        }
-    }
 }
 
 // --------------------------------------------------------------------------------------- backward
@@ -603,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
                                                                float* __restrict__ ws, int size, int resize, int rnd,
                                                                int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int total, int swizzle) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
     TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
@@ -616,8 +486,7 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = tiles_x * tiles_y;
-    const int tid = xcd_tile(static_cast<int>(blockIdx.x), total, swizzle);
-    if (tid >= total) return;                           // (the grid is padded to a multiple of 8 workgroups)
+    const int tid = static_cast<int>(blockIdx.x);
     const int group = tid / tiles;                      // PP consecutive planes share this tile's tables (the geometry
     const int t = tid - group * tiles;                  // is the same for every plane: built once, used PP times)
     const int tyi = t / tiles_x;
@@ -754,162 +623,6 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
 }
 
 
-// Row-band form of the backward (round 5), the counterpart of dim_fwd_band_kernel: a workgroup owns R rows of gx x ALL columns
-// of a plane, one lane per column (of d(rescaled) in stage A, of gx in stage B).  Both stages are still ATen's 2-D gathers in
-// its accumulation order -- acc = fma(wy * wx, g, acc) over the hits, rows outer, columns inner -- but they run over the SOURCE
-// rows with compile-time indices: every source row is read ONCE per lane (stage A: the lane's two output columns of a gy row,
-// all rows' loads issued up front; stage B: the lane's three rescaled columns of a `mid` row from LDS) and kept in a rolling
-// window of 2 (3) rows of registers; a wave-uniform `while` emits the target rows whose LAST hit row has just arrived and a
-// uniform select picks the window row for each hit slot.  One barrier between the stages.  Reads per target element: 2 global
-// + 3 LDS (the tile kernel: 4 global + 9 LDS), whole aligned rows of gy (no horizontal over-fetch).
-// SA = 2, SB = 3 (at most two outputs touch a padded index, at most three rescaled pixels an index of x): the host checks
-// both with the kernels' own tap arithmetic and falls back to the tile kernels otherwise.
-template <int R, int MH, int OH>          // rows of gx per band; bounds of the d(rescaled) rows / gy rows behind a band
-__global__ __launch_bounds__(kBlock) void dim_bwd_band_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                              float* __restrict__ ws, int size, int resize, int rnd, int top,
-                                                              int left, float scale1, float scale2, int bands, int ws_tiles) {
-    constexpr int SA = 2, SB = 3;
-    static_assert(MH <= 64 && R <= 64, "one lane per row of the tables");
-    __shared__ __attribute__((aligned(16))) float mid[MH * kBlock];     // d(rescaled) window: [p][rescaled column]
-    __shared__ float red[kBlock / kWave];
-    const int t = static_cast<int>(threadIdx.x), lane = t & 63;
-    const int plane = static_cast<int>(blockIdx.x) / bands;
-    const int band = static_cast<int>(blockIdx.x) - plane * bands;
-    const int iy0 = band * R, th = min(R, size - iy0);
-    const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
-    char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
-
-    // -- window of d(rescaled) rows behind the band (uniform)
-    const Hit h_first = find_hits(iy0, size, rnd, scale1), h_last = find_hits(iy0 + th - 1, size, rnd, scale1);
-    const int ry_lo = h_first.first, ry_hi = h_last.first + h_last.n - 1;
-    const int mh = ry_hi - ry_lo + 1;                                   // 1 .. MH (host-checked)
-    // -- gy rows behind the window (uniform): first hit of its first row .. last hit of its last row
-    const Hit a_first = find_hits(ry_lo + top, resize, size, scale2), a_last = find_hits(ry_hi + top, resize, size, scale2);
-    const int oy_lo = a_first.first, oy_hi = max(a_last.first + a_last.n - 1, oy_lo);          // oy_hi - oy_lo < OH (host-checked)
-    // -- row tables, one row per lane (lane_get): band row `lane` of gx -> rescaled rows; window row `lane` -> output rows
-    const Hit rowB = find_hits(min(iy0 + lane, size - 1), size, rnd, scale1);
-    const Hit rowA = find_hits(min(ry_lo + lane, ry_hi) + top, resize, size, scale2);
-    const int rowA_first = rowA.first - oy_lo, rowB_first = rowB.first - ry_lo;
-    const int rowA_both = static_cast<int>(rowA.both), rowB_both = static_cast<int>(rowB.both);
-    // -- this lane's columns
-    Hit hxa = find_hits(min(t, rnd - 1) + left, resize, size, scale2);  // stage A: rescaled column t -> output columns
-    if (t >= rnd) hxa.n = 0;
-    Hit hxb = find_hits(min(t, size - 1), size, rnd, scale1);           // stage B: column t of gx -> rescaled columns
-    if (t >= size) { hxb.n = 0; hxb.both = 0u; }
-    const bool any_both_xa = __builtin_amdgcn_readfirstlane(__any(hxa.both != 0u)) != 0;
-    const bool any_both_xb = __builtin_amdgcn_readfirstlane(__any(hxb.both != 0u)) != 0;
-    // -- all loads of the lane, back to back
-    float ga[OH], gb[OH];
-    {
-        const unsigned c0 = static_cast<unsigned>(min(hxa.first, size - 1)) * 4u, c1 = static_cast<unsigned>(min(hxa.first + 1, size - 1)) * 4u;
-        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-#pragma unroll
-        for (int j = 0; j < OH; ++j) {
-            const unsigned row = static_cast<unsigned>(min(oy_lo + j, oy_hi)) * row_bytes;
-            ga[j] = *reinterpret_cast<const float*>(gyp + (row + c0));
-            gb[j] = *reinterpret_cast<const float*>(gyp + (row + c1));
-        }
-    }
-    // -- stage A down the lane's rescaled column: mid[p][t]
-    {
-        float* out = mid + t;
-        int p = 0;
-        float pa = 0.0f, pb = 0.0f;                                     // the previous gy row at this lane's two columns
-#pragma unroll
-        for (int j = 0; j < OH; ++j) {
-            while (p < mh) {
-                const int first_y = lane_get(rowA_first, p), n_y = lane_get(rowA.n, p);          // n_y <= SA
-                if (first_y + n_y - 1 > j) break;                        // its last hit row has not arrived
-                const unsigned both_y = static_cast<unsigned>(lane_get(rowA_both, p));
-                float acc = 0.0f;
-#pragma unroll
-                for (int ky = 0; ky < SA; ++ky)
-                    if (ky < n_y) {
-                        const bool cur = first_y + ky == j;              // the hit row is row j or row j - 1 (uniform)
-                        const float g0 = cur ? ga[j] : pa, g1 = cur ? gb[j] : pb;
-                        const float wy = lane_get(rowA.w[ky], p);
-                        if (!any_both_xa && both_y == 0u) {
-                            acc = hit_accumulate<true>(acc, g0, wy, 0.0f, false, hxa, 0);
-                            acc = hit_accumulate<true>(acc, g1, wy, 0.0f, false, hxa, 1);
-                        } else {
-                            const float wy2 = lane_get(rowA.w2[ky], p);
-                            acc = hit_accumulate<false>(acc, g0, wy, wy2, (both_y >> ky) & 1u, hxa, 0);
-                            acc = hit_accumulate<false>(acc, g1, wy, wy2, (both_y >> ky) & 1u, hxa, 1);
-                        }
-                    }
-                out[p * kBlock] = acc;
-                ++p;
-            }
-            pa = ga[j];
-            pb = gb[j];
-        }
-    }
-    __syncthreads();
-    // -- stage B down the lane's column of gx (every lane walks the loop: the row tables live in all of them)
-    float asum = 0.0f;
-    {
-        int col[SB];
-#pragma unroll
-        for (int k = 0; k < SB; ++k) col[k] = min(max(hxb.first, 0) + k, rnd - 1);            // rescaled columns = LDS columns
-        // the lane's three rescaled columns of window row p, a rolling window of three rows in registers; row p + 1 is read
-        // from LDS while row p is consumed (a depth-1 software pipeline: the loop never waits for the row it needs)
-        float m0[SB], m1[SB] = {0.0f, 0.0f, 0.0f}, m2[SB] = {0.0f, 0.0f, 0.0f}, nxt[SB];
-#pragma unroll
-        for (int k = 0; k < SB; ++k) nxt[k] = mid[col[k]];
-        unsigned out = static_cast<unsigned>(iy0 * size + min(t, size - 1)) * 4u;
-        const unsigned row_bytes = 4u * static_cast<unsigned>(size);
-        const bool owns = t < size;
-        int r = 0;
-#pragma unroll
-        for (int p = 0; p < MH; ++p) {
-            if (p < mh) {                                                // (uniform)
-#pragma unroll
-                for (int k = 0; k < SB; ++k) {
-                    m0[k] = nxt[k];
-                    if (p + 1 < MH) nxt[k] = mid[(p + 1) * kBlock + col[k]];                    // (rows >= mh: in bounds, never used)
-                }
-                while (r < th) {
-                    const int first_y = lane_get(rowB_first, r), n_y = lane_get(rowB.n, r);      // 1 .. SB
-                    if (first_y + n_y - 1 > p) break;
-                    const unsigned both_y = static_cast<unsigned>(lane_get(rowB_both, r));
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int ky = 0; ky < SB; ++ky)
-                        if (ky < n_y) {
-                            const int back = p - (first_y + ky);         // 0, 1 or 2 rows ago (uniform)
-                            const float wy = lane_get(rowB.w[ky], r);
-                            const float wy2 = (!any_both_xb && both_y == 0u) ? 0.0f : lane_get(rowB.w2[ky], r);
-#pragma unroll
-                            for (int kx = 0; kx < SB; ++kx) {
-                                const float g = back == 0 ? m0[kx] : (back == 1 ? m1[kx] : m2[kx]);
-                                if (!any_both_xb && both_y == 0u)
-                                    acc = hit_accumulate<true>(acc, g, wy, 0.0f, false, hxb, kx);
-                                else
-                                    acc = hit_accumulate<false>(acc, g, wy, wy2, (both_y >> ky) & 1u, hxb, kx);
-                            }
-                        }
-                    if (owns) {
-                        *reinterpret_cast<float*>(gxp + out) = acc;
-                        asum += fabsf(acc);
-                    }
-                    out += row_bytes;
-                    ++r;
-                }
-#pragma unroll
-                for (int k = 0; k < SB; ++k) { m2[k] = m1[k]; m1[k] = m0[k]; }
-            }
-        }
-    }
-    const float total = block_sum(asum, red);
-    if (ws != nullptr && t == 0) {
-        // the caller sized ws for ta_dim_bwd_tiles(size, resize) sums per plane (the tile kernels' count): the band's sum goes
-        // to slot `band`, the slots no band owns get an exact zero
-        float* w = ws + static_cast<int64_t>(plane) * ws_tiles;
-        w[band] = total;
-        for (int k = bands + band; k < ws_tiles; k += bands) w[k] = 0.0f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // PreprocessingModel with a Resize (reference: transferattack/utils.py:50-53, 72-79 -- Inception-v3: 224 -> 299, mean = std =
 // 0.5):  y = (bilinear_{in->out}(x) - mean[c]) / std[c]  as ONE kernel each way, with the DIM kernels' taps and rounding
@@ -1036,75 +749,11 @@ static int64_t ta_dim_bwd_tiles_impl(int size, int resize) {
 
 extern "C" int64_t ta_dim_bwd_tiles(int size, int resize) { return ta_dim_bwd_tiles_impl(size, resize); }
 
-// TA_DIM_XCD=1: the XCD-contiguous tile order instead of the hardware's own.  Measured (r5d, N = 160): it removes the
-// over-fetch entirely (FETCH_SIZE forward 184 -> 94 MB, backward 137 -> 91 MB = 1.0 x the algorithmic bytes) and buys NOTHING --
-// forward 54.9 vs 48.8 us, backward 95.5 vs 95.9 us: the redundant lines came from the Infinity Cache, the kernels are not
-// bandwidth-bound.  Off by default; kept as the measurement's switch.
-static int xcd_order() {
-    const char* env = getenv("TA_DIM_XCD");
-    return (env != nullptr && atoi(env) != 0) ? 1 : 0;
-}
-
-// the kernels' make_tap_scaled on the host (fmaf is the exact fused operation here as well)
-static void host_tap(int o, int in_size, float scale, int* i0, int* i1) {
-    float src = fmaf(scale, static_cast<float>(o) + 0.5f, -0.5f);
-    src = src < 0.0f ? 0.0f : src;
-    int a = static_cast<int>(src);
-    a = a > in_size - 1 ? in_size - 1 : a;
-    *i0 = a;
-    *i1 = a + (a < in_size - 1 ? 1 : 0);
-}
-
-// largest window (padded rows, rows of x) behind any R-row band of the forward for this geometry
-static void fwd_band_bounds(int size, int resize, int rnd, int top, int rows, int* mh_max, int* sh_max) {
-    const float scale1 = static_cast<float>(size) / static_cast<float>(rnd), scale2 = static_cast<float>(resize) / static_cast<float>(size);
-    *mh_max = *sh_max = 0;
-    for (int oy0 = 0; oy0 < size; oy0 += rows) {
-        const int th = size - oy0 < rows ? size - oy0 : rows;
-        int lo, hi, unused;
-        host_tap(oy0, resize, scale2, &lo, &unused);
-        host_tap(oy0 + th - 1, resize, scale2, &unused, &hi);
-        const int mh = hi - lo + 1;
-        *mh_max = mh > *mh_max ? mh : *mh_max;
-        const int p_a = top - lo > 0 ? top - lo : 0, p_b = top + rnd - 1 - lo < mh - 1 ? top + rnd - 1 - lo : mh - 1;
-        if (p_a <= p_b) {
-            int s_lo, s_hi;
-            host_tap(lo + p_a - top, size, scale1, &s_lo, &unused);
-            host_tap(lo + p_b - top, size, scale1, &unused, &s_hi);
-            *sh_max = s_hi - s_lo + 1 > *sh_max ? s_hi - s_lo + 1 : *sh_max;
-        }
-    }
-}
-
 extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, int resize, int rnd, int top, int left,
                           void* stream) {
     TA_REQUIRE(x && y && x != y, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // row-band kernel (round 5; opt-in, TA_DIM_BAND=1: measured slower than the tile kernels below): one lane per column, a band
-    // of 32 output rows x every column per workgroup -- the geometries the reference draws at 224 pixels (resize = 246)
-    {
-        const char* env = getenv("TA_DIM_BAND");
-        if (resize <= kBlock && rnd >= size && resize >= size && env != nullptr && atoi(env) != 0) {
-            constexpr int R = 32;
-            int mh_max, sh_max;
-            fwd_band_bounds(size, resize, rnd, top, R, &mh_max, &sh_max);
-            const int bands = static_cast<int>(ceil_div(size, R));
-            const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
-            const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
-            const dim3 grid(static_cast<unsigned>(planes * bands));
-            if (planes * bands < (1ll << 31) && mh_max <= 36 && sh_max <= 37) {      // 224 -> 246: 36 KB of LDS, 4 workgroups per CU
-                hipLaunchKernelGGL((dim_fwd_band_kernel<R, 36, 37>), grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, bands);
-                return check_launch("dim_fwd_band");
-            }
-            if (planes * bands < (1ll << 31) && mh_max <= 40 && sh_max <= 40) {
-                hipLaunchKernelGGL((dim_fwd_band_kernel<R, 40, 40>), grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, bands);
-                return check_launch("dim_fwd_band");
-            }
-        }
-    }
     // lane-per-column kernel: every geometry with resize <= ~2 * size
     if (static_cast<int64_t>(size) * size < (1ll << 30)) {
         const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);        // make_tap's divisions, once
@@ -1118,15 +767,13 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             // every size, r2e / r2f: 13.8 -> 16.0 us at 96 planes, 54 -> 65 us at 480)
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31) - 8, "too many tiles");
-            const int swz = xcd_order();
-            const dim3 grid(static_cast<unsigned>(swz ? ceil_div(lane_blocks, 8) * 8 : lane_blocks));
-            const int total = static_cast<int>(lane_blocks);
+            const dim3 grid(static_cast<unsigned>(lane_blocks));
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, total, swz);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             else
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, total, swz);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -1143,76 +790,11 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
     return check_launch("dim_fwd");
 }
 
-// outputs of a 1-D resample (in_size -> out_size) that touch source index t: [first, last], -1 if none (host form of find_hits)
-static void host_hits(int t, int in_size, int out_size, float scale, int* first, int* last) {
-    *first = -1; *last = -2;
-    const float est = (static_cast<float>(t) - 0.5f) / scale - 0.5f;
-    int c = static_cast<int>(floorf(est)) - 1;
-    c = c < 0 ? 0 : c;
-    for (int o = c; o < out_size && o < c + 8; ++o) {
-        int i0, i1;
-        host_tap(o, in_size, scale, &i0, &i1);
-        if (i0 == t || i1 == t) {
-            if (*first < 0) *first = o;
-            *last = o;
-        } else if (*first >= 0) {
-            break;
-        }
-    }
-}
-
-// largest window (d(rescaled) rows, gy rows) behind any R-row band of the backward for this geometry
-static void bwd_band_bounds(int size, int resize, int rnd, int top, int rows, int* mh_max, int* oh_max) {
-    const float scale1 = static_cast<float>(size) / static_cast<float>(rnd), scale2 = static_cast<float>(resize) / static_cast<float>(size);
-    *mh_max = *oh_max = 0;
-    for (int iy0 = 0; iy0 < size; iy0 += rows) {
-        const int th = size - iy0 < rows ? size - iy0 : rows;
-        int f0, l0, f1, l1;
-        host_hits(iy0, size, rnd, scale1, &f0, &l0);
-        host_hits(iy0 + th - 1, size, rnd, scale1, &f1, &l1);
-        if (f0 < 0 || f1 < 0) { *mh_max = *oh_max = 1 << 20; return; }     // an index nobody touches: not a geometry for this kernel
-        const int mh = l1 - f0 + 1;
-        *mh_max = mh > *mh_max ? mh : *mh_max;
-        int a0, b0, a1, b1;
-        host_hits(f0 + top, resize, size, scale2, &a0, &b0);
-        host_hits(l1 + top, resize, size, scale2, &a1, &b1);
-        if (a0 < 0 || a1 < 0) { *mh_max = *oh_max = 1 << 20; return; }
-        *oh_max = b1 - a0 + 1 > *oh_max ? b1 - a0 + 1 : *oh_max;
-    }
-}
-
 extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes, int size, int resize, int rnd, int top,
                           int left, void* stream) {
     TA_REQUIRE(gy && gx && gy != gx, "null or aliased pointers");
     if (int rc = check_geom(planes, size, resize, rnd, top, left)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // row-band kernel (round 5; opt-in, TA_DIM_BAND=1): the geometries the reference draws at 224 pixels.
-    // ws keeps the tile kernels' layout (ta_dim_bwd_tiles sums per plane: the count depends on (size, resize) only)
-    {
-        const char* env = getenv("TA_DIM_BAND");
-        if (resize <= kBlock && rnd >= size && resize > size && env != nullptr && atoi(env) != 0 &&
-            max_hits(size, rnd) <= 3 && max_hits(resize, size) <= 2) {
-            constexpr int R = 32;
-            int mh_max, oh_max;
-            bwd_band_bounds(size, resize, rnd, top, R, &mh_max, &oh_max);
-            const int bands = static_cast<int>(ceil_div(size, R));
-            const int64_t ws_tiles = ta_dim_bwd_tiles_impl(size, resize);
-            const float scale1 = static_cast<float>(size) / static_cast<float>(rnd);
-            const float scale2 = static_cast<float>(resize) / static_cast<float>(size);
-            const dim3 grid(static_cast<unsigned>(planes * bands));
-            const bool fits = planes * bands < (1ll << 31) && ws_tiles >= bands && ws_tiles < (1 << 30);
-            if (fits && mh_max <= 37 && oh_max <= 35) {                             // 224 -> 246: 37 KB of LDS, 4 workgroups per CU
-                hipLaunchKernelGGL((dim_bwd_band_kernel<R, 37, 35>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, left,
-                                   scale1, scale2, bands, static_cast<int>(ws_tiles));
-                return check_launch("dim_bwd_band");
-            }
-            if (fits && mh_max <= 40 && oh_max <= 40) {
-                hipLaunchKernelGGL((dim_bwd_band_kernel<R, 40, 40>), grid, dim3(kBlock), 0, st, gy, gx, ws, size, resize, rnd, top, left,
-                                   scale1, scale2, bands, static_cast<int>(ws_tiles));
-                return check_launch("dim_bwd_band");
-            }
-        }
-    }
     // lane-per-column gather: resize > size, resize <= 1.5 * size and < 2^28 elements per plane (the choice depends on
     // (size, resize) only, so ta_dim_bwd_tiles tells the caller how many |gx| sums per plane `ws` receives)
     if (resize > size && 2 * resize <= 3 * size && static_cast<int64_t>(size) * size < (1ll << 28)) {
@@ -1228,19 +810,17 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             const int pp = (planes % 3 == 0 && planes / 3 * tiles_x * tiles_y >= 2560) ? 3 : 1;
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31) - 8, "too many tiles");
-            const int swz = xcd_order();
-            const dim3 grid(static_cast<unsigned>(swz ? ceil_div(lane_blocks, 8) * 8 : lane_blocks));
-            const int total = static_cast<int>(lane_blocks);
+            const dim3 grid(static_cast<unsigned>(lane_blocks));
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
             const bool two_a = max_hits(resize, size) <= 2;    // stage A: outputs per padded index (<= 2 whenever resize > size)
 #define TA_DIM_BWD_PP(RPW, SB, SA)                                                                                       \
     do {                                                                                                                 \
         if (pp == 3)                                                                                                     \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total, swz);                \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
         else                                                                                                             \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, total, swz);                \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
     } while (0)
 #define TA_DIM_BWD(RPW, SB) do { if (two_a) TA_DIM_BWD_PP(RPW, SB, 2); else TA_DIM_BWD_PP(RPW, SB, 3); } while (0)
             if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }

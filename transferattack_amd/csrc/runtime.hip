@@ -1,6 +1,7 @@
 // Error reporting, ABI bookkeeping and launch timing for libta_hip.so.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "ta_common.h"
@@ -24,6 +25,10 @@ int check_launch(const char* what) {
     }
     return 0;
 }
+
+// ---- summation order of the |g| sums (ta_set_sum_order): a process-wide setting handed in through the ABI, no environment
+static std::atomic<int> g_sum_order_lanes{0};
+int sum_order_lanes() { return g_sum_order_lanes.load(std::memory_order_relaxed); }
 
 // ---- launch timing: a pool of event pairs handed to the fused update while armed
 static std::mutex g_timing_mutex;
@@ -86,6 +91,14 @@ extern "C" int ta_timing_end(float* ms, int capacity, int* count) {
     }
     return 0;
 }
+
+extern "C" int ta_set_sum_order(int lanes) {
+    TA_REQUIRE(lanes == 0 || lanes == 8 || lanes == 16, "sum order: 0 (kernel order), 8 or 16 (ATen's cascade), got %d", lanes);
+    ta::g_sum_order_lanes.store(lanes, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int ta_get_sum_order(void) { return ta::sum_order_lanes(); }
 
 extern "C" int ta_abi_version(void) { return TA_ABI_VERSION; }
 extern "C" const char* ta_last_error(void) { return ta::g_error; }

@@ -16,6 +16,7 @@ constexpr int kTile = kBlock * kVec * kUnroll;   // 3072 elements per workgroup 
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int sum_order_lanes();                // 0 = the kernels' own order; 8 / 16 = ATen's cascade (ta_set_sum_order, runtime.hip)
 
 // Launch timing (ta_timing_begin / ta_timing_end, runtime.hip): while armed, every fused update claims a pair of HIP
 // events that ride on the dispatch packets of its own kernels (hipExtLaunchKernelGGL), so the elapsed time is the

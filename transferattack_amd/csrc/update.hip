@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void abs_sum_partials_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1 in the REFERENCE's summation order (opt-in, TA_ATEN_SUM_LANES = 8 | 16).
+// K1 in the REFERENCE's summation order (opt-in: ta_set_sum_order(8 | 16); the binding reads TA_ATEN_SUM_LANES).
 // grad.abs().mean(dim=(1,2,3)) on the reference's CPU path is ATen's vectorised cascade sum (SumKernel.cpp; restated
 // in oracle/ta_oracle.c: ta_oracle_aten_row_sum): `lanes` SIMD lanes x 4 interleaved accumulators = 4*lanes columns,
 // each column summed in blocks of 16 steps, 16 block sums into a level-1 sum, and so on for 4 levels, then the levels,
@@ -156,13 +156,8 @@ __global__ __launch_bounds__(kBlock) void aten_order_abs_sum_kernel(const float*
     }
 }
 
-// 0 = off (the kernels' own fixed order); 8 / 16 = ATen's cascade order for that SIMD width.  Read at every call (a
-// getenv per launch is noise), so one process can run both modes.
-static int aten_sum_lanes() {
-    const char* env = getenv("TA_ATEN_SUM_LANES");
-    const int value = env == nullptr ? 0 : atoi(env);
-    return (value == 8 || value == 16) ? value : 0;
-}
+// 0 = off (the kernels' own fixed order); 8 / 16 = ATen's cascade order for that SIMD width: ta_set_sum_order (runtime.hip)
+static int aten_sum_lanes() { return sum_order_lanes(); }
 
 // ------------------------------------------------------------------------------------------------
 // Surrogate pre-processing Normalize (reference: transforms.Normalize inside PreprocessingModel,
@@ -639,7 +634,7 @@ static int launch_partials(const float* g, const float* v, float* ws, int64_t n,
         const int64_t floats = (nb1 + (nb1 >> kAtenLevelPower) + (nb1 >> (2 * kAtenLevelPower)) + 1) * cols;
         // the cascade uses 16-step levels as long as ceil(log2(steps)) / 4 <= 4, i.e. up to 2^19 steps
         TA_REQUIRE(floats <= kAtenMaxLdsFloats && steps <= (1ll << 19),
-                   "TA_ATEN_SUM_LANES: images of %lld elements exceed what the reference-order sum stages in LDS", (long long)e);
+                   "ta_set_sum_order: images of %lld elements exceed what the reference-order sum stages in LDS", (long long)e);
         if (v)
             TA_LAUNCH_TIMED(aten_order_abs_sum_kernel<true>, dim3(static_cast<unsigned>(n)), dim3(kBlock), st, ev_start,
                             no_event, g, v, ws, e, tiles, lanes, stdv, hw);
@@ -845,7 +840,7 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
     // ws_slots > 0 with a variance term: the producer summed |g + v| (ta_normalize_bwd with v) -- the caller's contract
     TA_REQUIRE(!(ws_slots && aten_sum_lanes() != 0),
-               "TA_ATEN_SUM_LANES: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
+               "ta_set_sum_order: the reference-order sum is never taken from a producer (pass ws_slots = 0)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LaunchEvents timed = claim_launch_events();          // null unless ta_timing_begin armed them
     if (ws_slots == 0)
@@ -856,7 +851,6 @@ static int mi_update_impl(const float* g, const float* v, const float* m_in, flo
     const bool vec = vec_ok(e, {g, v, m_in, m_out, delta, x, x_adv});
     // stream past the caches only when one launch moves more than the Infinity Cache can hold
     bool nt = vec && static_cast<double>(n) * static_cast<double>(e) * 24.0 > 256.0 * 1024 * 1024;
-    if (const char* force = getenv("TA_K2_NT")) nt = vec && atoi(force) != 0;       // tuning knob (tools/k2_inloop_probe.py)
     const int key = (v ? 8 : 0) | (m_in ? 4 : 0) | (m_out ? 2 : 0) | (x_adv ? 1 : 0);
     // the byte source: 16-byte aligned floats, 4-byte aligned bytes, whole images of a multiple of 4 elements
     const bool u8 = x_u8 != nullptr && vec && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0;
