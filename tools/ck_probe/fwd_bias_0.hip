@@ -1,0 +1,4 @@
+#include "fwd_instances.h"
+namespace probe {
+void add_fwd_bias_0(std::vector<std::unique_ptr<FwdBias>>& v) { add_fwd<ck::Tuple<G_K>, ck::Tuple<F32>, BiasRelu, ConvFwdDefault, FwdBias>(v); }
+}
