@@ -92,7 +92,7 @@ def run_config(config, name, arrangement, g, limit=None):
     n, batch, seed_base = int(g["n_images"]), int(g["batch"]), int(g["seed_base"])
     n = n if limit is None else min(n, limit)
     assert n % batch == 0 or n == int(g["n_images"])
-    xu8 = u8_images(n, 224, int(g["seed_images"]))
+    xu8 = u8_images(int(g["n_images"]), 224, int(g["seed_images"]))[:n]          # (the generator's stream: the first n of the set)
     x = xu8.float() / 255
     label = torch.from_numpy(g["label"].astype(np.int64))
     nets = [backbones.create(spec.split(":")[0], seed=int(spec.split(":")[1]), verbose=False) for spec in str(g["surrogate"]).split(",")]
@@ -133,7 +133,7 @@ def run_config(config, name, arrangement, g, limit=None):
     got = first[0][:k].cpu().numpy()
     ref_pos = np.unpackbits(g["sign_bits"])[:got.size].reshape(got.shape).astype(bool)
     agree = float(((got > 0) == ref_pos).mean())
-    return x, label.numpy(), adv, agree, seconds
+    return x[:n], label.numpy()[:n], adv, agree, seconds
 
 
 P_MIN = 2.2e-4          # two-sided tail of |z| = 3.7 (round 4 ran with |z| = 4; largest z observed over rounds 3-4: 2.93; ~1 % false alarms per 48-comparison tier)

@@ -24,6 +24,12 @@ newtests6)
 coldranks)
   # bench.py --gpus 2 on ONE device with fresh MIOpen databases: rank 0 warms up first vs both together (tools/cold_start_ranks.py)
   timeout 2400 python tools/cold_start_ranks.py --runs ${TA_COLD_RUNS:-one,one:warm,staged,together} 2> $OUT/cold_start_ranks.err | tee $OUT/cold_start_ranks.jsonl ;;
+ckprobe)
+  # review r5 item 4: MIOpen convolution + glue kernel vs composable_kernel instances with the glue as epilogue (tools/ck_probe)
+  [ -f tools/bin/libck_probe.so ] || bash tools/ck_probe/build.sh > $OUT/ck_probe_build.log 2>&1
+  timeout 1500 python tools/ck_conv_probe.py --json $OUT/ck_conv_probe.json 2> $OUT/ck_conv_probe.err | tee $OUT/ck_conv_probe.jsonl | cut -c1-600 ;;
+stem)
+  timeout 300 python tools/stem_microbench.py 2>&1 | tee $OUT/stem_microbench.txt ;;
 asrlong)
   timeout 1200 python -m pytest tests -m gpu_long -q -p no:cacheprovider -s > $OUT/pytest_gpu_long.log 2>&1
   grep -E "passed|failed|images in" $OUT/pytest_gpu_long.log | tail -6 ;;
@@ -55,35 +61,10 @@ gpus1)
   # the self-launch path of bench.py --gpus N on a one-GPU box: N = 1 under torch.distributed.run (RCCL world of 1)
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_torchrun_n1.json
   timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 2>&1 | tail -1 | tee $OUT/bench_gpus2_refused.txt ;;
-spec)
-  timeout 300 python tools/spectrum_microbench.py 2>&1 | tail -10 | tee $OUT/spectrum_microbench.txt
-  timeout 300 python -m pytest tests/test_zz_hip_widened.py tests/test_hip_kernels.py -q -m gpu -k "spectrum or dim or ssm or fgsra" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/spec_pytest.txt ;;
-bsr)
-  timeout 120 python tools/bsr_microbench.py 2> $OUT/bsr_microbench.err | tee $OUT/bsr_microbench.json
-  timeout 200 python -m pytest tests/test_zz_hip_widened.py -q -m gpu -k "bsr" -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/bsr_pytest.txt ;;
-late)
-  # the GPU tests written after round 3's GPU minutes were spent: run these first
-  timeout 900 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "ens or vmifgsm" 2>&1 | grep -v Warning | tail -40 | tee $OUT/late_pytest.txt ;;
 dispatch)
   timeout 120 python tools/update_dispatch_clock.py 2> $OUT/update_dispatch_clock.err | tee $OUT/update_dispatch_clock.json ;;
 probe)
   timeout 900 python tools/backbone_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err; cat $OUT/probe.jsonl ;;
-newtests)
-  # the GPU tests of what changed last (fused surrogate glue, folded VMI chain, DIM tables, ASR with the bench arrangement)
-  timeout 900 python -m pytest tests/test_hip_configs.py tests/test_hip_kernels.py tests/test_hip_attacks.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
-      -k "fused or vmi or vni or dim or partials or streaming or config4" 2>&1 | grep -v Warning | tee $OUT/newtests_pytest.txt | tail -25
-  timeout 600 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "folded or dts" 2>&1 | grep -v Warning | tee $OUT/asr1000_fused_pytest.txt | tail -30 ;;
-benchpair)
-  # the default line with the surrogate's glue fused (default) and through the plain module path
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue.json
-  TA_FUSED_GLUE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_module_path.json
-  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_b32.json ;;
-stempair)
-  # the default line with the stem's input gradient on csrc/stem.hip (default) and on MIOpen
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_stem.json
-  TA_STEM_KERNEL=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_fused_glue_miopen_stem.json ;;
-fusedtest)
-  timeout 600 python -m pytest tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider -k "fused" 2>&1 | grep -v Warning | tee $OUT/fused_pytest.txt | tail -12 ;;
 ktrace)
   # rocprofv3's own durations of every kernel of the stand-alone bench (event timing adds the marker overhead)
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace -o trace -- python $R/tools/kernel_bench.py > $R/$OUT/ktrace.log 2>&1 )
@@ -105,24 +86,11 @@ steady)
   python tools/steady_trace.py $OUT/steady_b$B $OUT/steady_state_b$B.json 30 | tee $OUT/steady_state_b$B.txt
   f=$(find $OUT/steady_b$B -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/steady_state_b${B}_kernel_stats.csv
   find $OUT/steady_b$B -name "*kernel_trace.csv" -delete; find $OUT/steady_b$B -name "*.db" -delete ;;
-sweep)
-  for b in 32 64 250 500; do timeout 600 python bench.py --steps 3 --warmup 1 --batch $b --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee -a $OUT/bench_batches.json; done ;;
-asr)
-  timeout 1500 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr1000_pytest.txt | tail -60 ;;
 rocprof)
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 8 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 > $R/$OUT/rocprof.log 2>&1 )
   tail -1 $OUT/rocprof.log
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && (head -1 "$f"; grep -E "ta::" "$f"; grep -v naive "$f" | head -12 | cut -c1-160)
   find $OUT/prof -name "*kernel_trace.csv" -size +8M -delete; find $OUT/prof -name "*.db" -delete ;;
-newtests4)
-  # round 4: byte source of the fused update, loop-level goldens (L2 / tensor / negative step, random starts), partials verify mode
-  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_loops_golden.py tests/test_zz_hip_widened.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
-      -k "test_hip_kernels or loops_golden or registry_rules or shard_size or members_on_streams" 2>&1 | grep -v Warning | tee $OUT/newtests4_pytest.txt | tail -25 ;;
-asr4)
-  timeout 1200 python -m pytest tests/test_hip_asr1000.py -q -m gpu -s -p no:cacheprovider -k "mifgsm_resnet50 or dts" 2>&1 | grep -v Warning | tee $OUT/asr4_pytest.txt | tail -60 ;;
-bench32)
-  timeout 600 python bench.py --steps 6 --warmup 2 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_b32.json
-  TA_U8_SOURCE=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_b125_fp32_source.json ;;
 ens4)
   # configs[4] on one GPU at the reference's batch and at the per-GPU shard (ensemble MI-FGSM treats images independently)
   for b in 32 125; do
@@ -131,31 +99,6 @@ ens4)
 dimclock)
   # where a DIM tile's cycles go: per-phase shader-clock cycles of the two lane-per-column kernels (a tuning build of dim.hip)
   timeout 300 python tools/dim_phase_clock.py 2>&1 | tee $OUT/dim_phase_clock.txt ;;
-benchq)
-  # the default line without the CPU leg and the stand-alone sweep; then with the ReLU pass bits off (activations read instead)
-  timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick.json
-  TA_RELU_BITS=0 timeout 600 python bench.py --steps 6 --warmup 2 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tee $OUT/bench_default_quick_no_relu_bits.json ;;
-ensab)
-  # configs[4] at the reference's batch: members one after the other / on their own HIP streams, then what the iteration is made of
-  M="--attack ens --model resnet50,vgg16,inception_v3,vit_base_patch16_224 --batch 32 --cpu-images 0 --kernel-sweep 0 --literal-steps 0"
-  TA_ENS_STREAMS=0 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_one_stream.json
-  TA_ENS_STREAMS=1 timeout 900 python bench.py $M --steps 2 --warmup 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_ens4_b32_member_streams.json
-  ( cd /tmp && TA_ENS_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ens_trace -o trace -- python $R/bench.py $M --steps 2 --warmup 1 > $R/$OUT/ens_trace.log 2>&1 )
-  python tools/steady_trace.py $OUT/ens_trace $OUT/ens4_b32_steady_state.json 40 | tee $OUT/ens4_b32_steady_state.txt | head -50
-  f=$(find $OUT/ens_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/ens4_b32_kernel_stats.csv
-  find $OUT/ens_trace -name "*kernel_trace.csv" -delete; find $OUT/ens_trace -name "*.db" -delete ;;
-members)
-  # one member at a time (MI-FGSM, batch 32): where configs[4]'s time goes
-  for m in vgg16 inception_v3 vit_base_patch16_224 mobilenet_v2; do
-  timeout 600 python bench.py --model $m --batch 32 --steps 2 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_member_$m.json
-  done ;;
-dimpmc)
-  for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES"; do
-  tag=$(echo $c | cut -d' ' -f1)
-  ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/dimpmc_$tag -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/dimpmc_$tag.log 2>&1 )
-  python tools/pmc_kernels.py $OUT/dimpmc_$tag | tee -a $OUT/dimpmc_summary.txt
-  done
-  find $OUT -name "*.db" -delete ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$OUT/pmc_$c -o pmc -- python $R/tools/update_microbench.py > $R/$OUT/pmc_$c.log 2>&1 )
@@ -166,10 +109,6 @@ timpmc)
   ( cd /tmp && TA_N=160 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/$OUT/timpmc -o pmc -- python $R/tools/tim_microbench.py > $R/$OUT/timpmc.log 2>&1 )
   python tools/pmc_kernels.py $OUT/timpmc | tee $OUT/timpmc_summary.txt
   find $OUT -name "*.db" -delete ;;
-newtests5)
-  # round 5: the Normalize folded into both ends of the plain loop (ta_normalize_adv_fwd / ta_mi_update_std / stem sums)
-  timeout 900 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider \
-      -k "test_hip_kernels or normalize_folded or stem_input_grad" 2>&1 | grep -v Warning | tee $OUT/newtests5_pytest.txt | tail -25 ;;
 det)
   # TA_DETERMINISTIC=1: two processes write identical PNGs; what the switch costs on the bench line
   timeout 1500 python -m pytest tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider -k "deterministic_mode" 2>&1 | grep -v Warning | tee $OUT/det_pytest.txt | tail -12
@@ -193,18 +132,10 @@ vmistack)
   for k in ${TA_VMI_KS:-1 5 10}; do
   TA_VMI_STACK=$k timeout 900 python bench.py --attack vmifgsm --model vit_base_patch16_224 --batch 32 --steps 1 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --fold-bn 0 --channels-last 0 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_vmi_vit_b32_stack$k.json | cut -c1-400
   done ;;
-newtests5b)
-  timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_hip_attacks.py -q -m gpu -s -p no:cacheprovider \
-      -k "test_hip_kernels or normalize_folded or conditioned or stacked or variants_run" 2>&1 | grep -v Warning | tee $OUT/newtests5b_pytest.txt | tail -40 ;;
 trained)
   timeout 900 python -m pytest tests/test_hip_asr_trained.py -q -m gpu -s -p no:cacheprovider 2>&1 | grep -v Warning | tee $OUT/asr_trained_pytest.txt | tail -30 ;;
 dts)
   timeout 600 python bench.py --attack dts --batch 32 --steps 3 --warmup 1 --cpu-images 0 --kernel-sweep 0 --literal-steps 0 --kernel-times 1 2>> $OUT/bench.err | tail -1 | tee $OUT/bench_dts_b32.json | cut -c1-1500 ;;
-retest)
-  timeout 600 python -m pytest tests/test_hip_attacks.py tests/test_hip_asr1000.py tests/test_hip_asr_trained.py tests/test_zz_hip_widened.py -q -m gpu -s -p no:cacheprovider \
-      -k "fused_resnet or mifgsm_resnet50 or (trained and mifgsm) or registry_rules" 2>&1 | grep -v Warning | tee $OUT/retest_pytest.txt | tail -40 ;;
-detcold)
-  TA_DETERMINISTIC=1 timeout 900 python tools/cold_start.py --modes immediate,immediate:warm --root /tmp/ta_cold_det 2> $OUT/cold_start_det.err | tee $OUT/cold_start_deterministic.jsonl ;;
 esac
 done
 du -sh $OUT

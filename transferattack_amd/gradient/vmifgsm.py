@@ -16,6 +16,8 @@ current gradient's Normalize backward adds the |grad + variance| tile sums, and 
 after the neighbours (the variance is sampled around the old delta either way, vmifgsm.py:89-95), so the update makes no
 pass of its own over the gradient.  Rounding points are those of the separate kernels: same bits.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -92,14 +94,17 @@ class VMIFGSM(Attack):
         iteration are independent (vmifgsm.py:46-58 loops over them only because autograd.grad is called per sample): stacking
         k of them runs the surrogate on k * N images -- fewer, larger launches and 1 / k of the host-side dispatch work per
         image; slices are accumulated in neighbour order, so the variance keeps its rounding sequence.  ``TA_VMI_STACK=k`` sets
-        it (1 = one evaluation per neighbour, the reference's shape); default: the largest divisor of num_neighbor with
-        k * N <= 160 images (measured on ViT-B/16)."""
-        import os
+        it for any surrogate (1 = one evaluation per neighbour, the reference's shape).  Default: stacking only where it was
+        measured -- a transformer surrogate (configs[3]: ViT-B/16, +15 %, profiles/r05/bench_vmi_vit_b32_stack*.json), the largest
+        divisor of num_neighbor with k * N <= 160 images; every other surrogate keeps the reference's one-by-one shape (its
+        libraries may pick other algorithms for a k * N batch, and the activations of k * N images must fit)."""
         want = os.environ.get("TA_VMI_STACK", "")
         if want.isdigit() and int(want) >= 1:
             k = min(int(want), self.num_neighbor)
-        else:
+        elif "VisionTransformer" in type(self.model[1]).__name__:
             k = max(1, min(self.num_neighbor, 160 // max(n, 1)))
+        else:
+            k = 1
         while self.num_neighbor % k:
             k -= 1
         return k
