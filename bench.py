@@ -73,6 +73,9 @@ def parse(argv=None):
     p.add_argument("--fold-bn", type=int, default=1,
                    help="fold the surrogate's eval-mode BatchNorm into its convolutions (algebraically exact)")
     p.add_argument("--channels-last", type=int, default=1, help="run the surrogate in NHWC memory format")
+    p.add_argument("--ck-epilogue", type=int, default=1,
+                   help="fused ResNet path: convolution + glue pass as ONE composable_kernel convolution with the pass as epilogue "
+                        "(libta_ck.so) wherever that measures faster than MIOpen's convolution + the glue kernel (TA_CK_EPILOGUE)")
     p.add_argument("--cpu-images", type=int, default=32, help="images of the CPU-baseline sample (0 = skip); 32 = the reference's batch")
     p.add_argument("--kernel-sweep", type=int, default=1, help="also time the update kernel stand-alone")
     p.add_argument("--literal-steps", type=int, default=3,
@@ -591,9 +594,9 @@ def literal_leg(args, _hip):
     TA_CHANNELS_LAST + MIOpen find.  -> ``config.literal``."""
     import contextlib
     import transferattack_amd as ta
-    saved = {k: os.environ.get(k) for k in ("TA_FOLD_BN", "TA_CHANNELS_LAST")}
+    saved = {k: os.environ.get(k) for k in ("TA_FOLD_BN", "TA_CHANNELS_LAST", "TA_CK_EPILOGUE")}
     saved_benchmark = torch.backends.cudnn.benchmark
-    os.environ["TA_FOLD_BN"], os.environ["TA_CHANNELS_LAST"] = "0", "0"
+    os.environ["TA_FOLD_BN"], os.environ["TA_CHANNELS_LAST"], os.environ["TA_CK_EPILOGUE"] = "0", "0", "0"
     torch.backends.cudnn.benchmark = False
     batch = 32
     try:
@@ -644,7 +647,8 @@ def main(argv=None):
 
     os.environ["TA_FOLD_BN"] = "1" if args.fold_bn else "0"
     os.environ["TA_CHANNELS_LAST"] = "1" if args.channels_last else "0"
-    from transferattack_amd import _hip
+    os.environ["TA_CK_EPILOGUE"] = "1" if args.ck_epilogue and args.fold_bn and args.channels_last and on_gpu else "0"
+    from transferattack_amd import _ck, _hip
     _hip.load()
     torch.backends.cudnn.benchmark = True                     # MIOpen picks its fastest conv algorithms
     attacker, shard_rank, shard_world, layout = build_attacker(args, world)
@@ -717,6 +721,8 @@ def main(argv=None):
                                    "3x%dx%d, batches of %d, %s"
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
                                       args.image_size, args.image_size, args.batch, layout),
+                       # glue passes as epilogues of composable_kernel convolutions (libta_ck.so), site by site where faster
+                       "ck_epilogue": {"on": _ck.enabled(), "sites_tuned": _ck.stats["tuned_sites"], "sites_fused": _ck.stats["sites_on_ck"]},
                        "byte_source": os.environ.get("TA_U8_SOURCE", "1") != "0",
                        # the surrogate's Normalize folded into the two HIP kernels either side of the backbone
                        # (attack.py::_forward_normalize_folded): no x + delta store, no gx = gy / std store

@@ -188,12 +188,19 @@ def check_rates(config, tag, g, x, label, adv):
 
 @gpu
 @pytest.mark.parametrize("tag,arrangement", [("reference-literal surrogate", dict()),
-                                             ("folded BatchNorm + NHWC + fused glue, as bench.py", dict(fold_bn=True, channels_last=True))])
-def test_asr1000_mifgsm_resnet50(tag, arrangement):
-    """BASELINE.json configs[1]: MI-FGSM, ResNet-50, eps 16/255, alpha 1.6/255, K = 10, the 1000-image set"""
+                                             ("folded BatchNorm + NHWC + fused glue + CK epilogues, as bench.py", dict(fold_bn=True, channels_last=True))])
+def test_asr1000_mifgsm_resnet50(tag, arrangement, monkeypatch):
+    """BASELINE.json configs[1]: MI-FGSM, ResNet-50, eps 16/255, alpha 1.6/255, K = 10, the 1000-image set; the second case in the
+    arrangement bench.py times, glue passes in the convolutions' epilogues (libta_ck.so) included"""
+    from transferattack_amd import _ck
     g = fixture("mifgsm")
     before = dict(_hip.stats)
+    ck_before = _ck.stats["fused_launches"]
+    monkeypatch.setenv("TA_CK_EPILOGUE", "1" if arrangement else "0")
     x, label, adv, agree, seconds = run_config("configs[1]", "mifgsm", arrangement, g)
+    if arrangement:
+        assert _ck.stats["fused_launches"] > ck_before, "no convolution ran with its glue as epilogue"
+        print("convolution sites tuned %d, on composable_kernel with the glue as epilogue %d" % (_ck.stats["tuned_sites"], _ck.stats["sites_on_ck"]))
     print("\nconfigs[1] [%s]: %d images in %.1f s (%.0f images/s incl. upload, quantise, download); first-iteration "
           "gradient sign agreement with the reference %.3f %%" % (tag, len(label), seconds, len(label) / seconds, 100 * agree))
     assert _hip.stats["std_form_launches"] > before["std_form_launches"], "the loop did not fold the Normalize into its ends"

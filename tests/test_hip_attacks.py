@@ -400,7 +400,8 @@ def conditioned_gradient(build, x, label, fold_bn, channels_last, fold_normalize
 
 CONDITIONED_ARRANGEMENTS = [("reference-literal (NCHW, separate BatchNorm, hook loop)", False, False, False),
                             ("reference-literal, Normalize folded into the loop's ends", False, False, True),
-                            ("bench arrangement (folded BatchNorm, NHWC, fused glue, stem kernel, folded Normalize)", True, True, True)]
+                            ("bench arrangement (folded BatchNorm, NHWC, fused glue, stem kernel, folded Normalize)", True, True, True),
+                            ("bench arrangement with the glue in the convolutions' epilogues (CK)", True, True, True)]
 
 
 @pytest.mark.parametrize("tag,fold_bn,channels_last,fold_normalize", CONDITIONED_ARRANGEMENTS)
@@ -411,6 +412,7 @@ def test_gradient_within_1e5_on_conditioned_resnet50(golden, monkeypatch, tag, f
     this bound on ANY pair of fp32 implementations (test_gradient_accuracy_vs_fp64 prints its numbers): this fixture removes
     the ReLU / max-pool discontinuities and the amplification that hide an implementation's own error behind them."""
     x, label, g, mask, build = conditioned_fixture(golden)
+    monkeypatch.setenv("TA_CK_EPILOGUE", "1" if "(CK)" in tag else "0")
     g_ref = t(g["grad_reference_cpu_fp32"])
     scale = float(g_ref.abs().max())
     got = conditioned_gradient(build, x, label, fold_bn, channels_last, fold_normalize, monkeypatch)

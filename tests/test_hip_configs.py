@@ -295,10 +295,13 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
     monkeypatch.setenv("TA_CHANNELS_LAST", nhwc)
     atk = ta.load_attack_class("mifgsm")(model_name=name)
     got = {}
-    for tag, flag, stem in (("module", "0", "1"), ("module again", "0", "1"), ("fused", "1", "1"), ("fused again", "1", "1"),
-                            ("fused, MIOpen stem", "1", "0")):
+    from transferattack_amd import _ck
+    ck_before = _ck.stats["fused_launches"]
+    for tag, flag, stem, ck in (("module", "0", "1", "0"), ("module again", "0", "1", "0"), ("fused", "1", "1", "0"),
+                                ("fused again", "1", "1", "0"), ("fused, MIOpen stem", "1", "0", "0"), ("fused, CK epilogues", "1", "1", "1")):
         monkeypatch.setenv("TA_FUSED_GLUE", flag)
         monkeypatch.setenv("TA_STEM_KERNEL", stem)
+        monkeypatch.setenv("TA_CK_EPILOGUE", ck)
         xd = x.to(DEV).requires_grad_(True)
         logits = atk.model(xd)
         grad = torch.autograd.grad(torch.nn.functional.cross_entropy(logits, label), xd)[0]
@@ -317,6 +320,17 @@ def test_fused_glue_is_the_same_surrogate(monkeypatch, name, nhwc, batch):
     assert rel(got["fused"][0], got["module"][0]) <= 1e-5
     assert e_fus[0] <= max(4 * e_mod[0], 1e-5) and e_fus[1] <= max(4 * e_mod[1], 1e-2)
     assert flips <= 0.01
+    # the same surrogate with the glue passes in the convolutions' epilogues (libta_ck.so; NHWC only): same claims
+    e_ck = (rel(got["fused, CK epilogues"][0], logits64), rel(got["fused, CK epilogues"][1], grad64))
+    flips_ck = float((torch.sign(got["fused, CK epilogues"][1]) != torch.sign(got["module"][1])).float().mean())
+    print("%s nhwc=%s, CK epilogues: rel-L2 error vs fp64 (logits, input-gradient) %.2e %.2e; vs module path: logits rel %.1e, sign "
+          "flips %.3f%%; fused launches %d, sites on CK %d of %d tuned" % (name, nhwc, e_ck[0], e_ck[1], rel(got["fused, CK epilogues"][0], got["module"][0]),
+                                                                           100 * flips_ck, _ck.stats["fused_launches"] - ck_before,
+                                                                           _ck.stats["sites_on_ck"], _ck.stats["tuned_sites"]))
+    assert rel(got["fused, CK epilogues"][0], got["module"][0]) <= 1e-5
+    assert e_ck[0] <= max(4 * e_mod[0], 1e-5) and e_ck[1] <= max(4 * e_mod[1], 1e-2) and flips_ck <= 0.01
+    if nhwc == "1":
+        assert _ck.stats["fused_launches"] > ck_before, "TA_CK_EPILOGUE=1 launched no fused convolution"
 
 
 @pytest.mark.parametrize("n,oh,ow", [(4, 112, 112), (1, 9, 37), (2, 150, 150)])

@@ -170,6 +170,25 @@ def test_abi_symbols_exported():
     assert lib.ta_update_tiles(150528) == 49 and lib.ta_conv_tiles(15, 224, 224) == 7 and lib.ta_conv_tiles(9, 224, 224) == 14 and lib.ta_dim_bwd_tiles(224, 246) == 28
 
 
+def test_ck_abi_symbols_exported():
+    """libta_ck.so (convolutions with the glue pass as epilogue) loads without a GPU, exports every symbol include/ta_ck.h declares,
+    and knows its tile configurations: fused forms exist for every filter with bias + ReLU, for 1x1 / stride 1 filters otherwise"""
+    import os
+    import re
+    from transferattack_amd import _ck
+    lib = _ck.load()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ta_ck.h")).read()
+    declared = set(re.findall(r"\b(ta_ck_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_ck.SIGNATURES), declared ^ set(_ck.SIGNATURES)
+    assert lib.ta_ck_abi_version() == _ck.ABI_VERSION == 1
+    assert lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 3, 1, 1) >= 8 and lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 1, 1, 0) >= 8
+    for kind in (_ck.FWD_BIAS_ADD_RELU, _ck.FWD_BIAS_ADD_BIAS_RELU, _ck.BWD_MASK, _ck.BWD_ADD_MASK):
+        assert lib.ta_ck_instances(kind, 1, 1, 0) >= 6 and lib.ta_ck_instances(kind, 3, 1, 1) == 0
+    assert b"Xdl_CShuffle" in lib.ta_ck_instance_name(_ck.BWD_ADD_MASK, 1, 1, 0, 0)
+    assert lib.ta_ck_conv(_ck.FWD_BIAS_RELU, 0, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, None) == -1       # TA_CK_EINVAL
+    assert b"null" in lib.ta_ck_last_error()
+
+
 # ------------------------------------------------------------------ SURVEY 8(f) rank 3: wider gradient family
 MORE = [("pifgsm", {}), ("emifgsm", {}), ("iefgsm", {}), ("gnp", {}), ("gra", dict(num_neighbor=5)),
         ("pgn", dict(num_neighbor=4)), ("gifgsm", {}), ("dta", dict(K=3)), ("pcifgsm", {}), ("smifgrm", dict(num_neighbor=4))]

@@ -43,6 +43,12 @@ def main():
     if "--factor" in sys.argv:                      # a calibration taken elsewhere (say where): this run's copy launches are not
         factor = float(sys.argv[sys.argv.index("--factor") + 1])       # all of one size (e.g. host-to-device staging copies)
         print("fetch correction x%.4f given on the command line" % factor)
+    elif any("abs_sum_partials_kernel<4, false, false, false>" in k for k in per):
+        # the calibration of choice: K1 is a pure, fully coalesced read of exactly 4 B/element at this very N (the device copies of
+        # a run mix shapes -- staging copies, index tensors -- and gave x7.9 in r6b where this kernel gives x1.999)
+        k1 = next(k for k in per if "abs_sum_partials_kernel<4, false, false, false>" in k)
+        factor = 4.0 / per[k1]["FETCH_SIZE"]
+        print("calibration on %s: reported fetch %.3f B/elem for a pure read of 4 B/elem -> correction x%.3f" % (k1[-60:], per[k1]["FETCH_SIZE"], factor))
     elif copy:
         c = per[copy[0]]
         if c.get("FETCH_SIZE"):
@@ -54,7 +60,9 @@ def main():
         doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/update_microbench.py, "
                          "N = %d; summary by tools/pmc_summary.py" % n,
                "fetch_correction": round(factor, 4),
-               "fetch_correction_source": "command line (--factor)" if "--factor" in sys.argv else "the known-size device copy of the same run",
+               "fetch_correction_source": "command line (--factor)" if "--factor" in sys.argv else (
+                   "this run's abs_sum_partials_kernel launches: a pure read of exactly 4 B/element" if any(
+                       "abs_sum_partials_kernel<4, false, false, false>" in k for k in per) else "the known-size device copy of the same run"),
                "kernels": {}}
         for name, c in per.items():
             if "ta::" not in name and "ta2" not in name:

@@ -1,0 +1,147 @@
+"""ctypes binding of libta_ck.so (include/ta_ck.h): convolutions of a ResNet surrogate with the glue pass that follows them as
+the convolution's epilogue -- composable_kernel instances, the library kernels MIOpen itself dispatches for these layers.
+
+Opt-in (``TA_CK_EPILOGUE=1``; ``bench.py`` switches it on and says so) and used by ``backbones/fused.py`` only.  Per
+(epilogue, shape) the first call times the two-kernel form it would replace -- MIOpen's convolution + the glue kernel of
+libta_hip.so -- against every tile configuration of the fused form and keeps the faster (``choose``): a layer for which MIOpen's
+assembly kernels win stays on them (the 3 x 3 backward-data layers do, profiles/r06/ck_conv_probe_b125_r6b.json).  Like MIOpen's
+find mode this makes the choice of kernel, hence the last bits of an activation, a property of the process: under
+``TA_DETERMINISTIC=1`` the path is off.  No fallback inside: a missing library raises when the path is asked for.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _hip
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("TA_CK_LIB", os.path.join(_HERE, "lib", "libta_ck.so"))
+ABI_VERSION = 1
+
+FWD_BIAS_RELU, FWD_BIAS_ADD_RELU, FWD_BIAS_ADD_BIAS_RELU, BWD_MASK, BWD_ADD_MASK = 1, 2, 3, 4, 5
+UNSUPPORTED = 1
+
+_int, _vp = ctypes.c_int, ctypes.c_void_p
+SIGNATURES = {
+    "ta_ck_abi_version": (_int, []),
+    "ta_ck_last_error": (ctypes.c_char_p, []),
+    "ta_ck_instances": (_int, [_int, _int, _int, _int]),
+    "ta_ck_instance_name": (ctypes.c_char_p, [_int, _int, _int, _int, _int]),
+    "ta_ck_conv": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+}
+
+_lib = None
+stats = {"fused_launches": 0, "tuned_sites": 0, "sites_on_ck": 0}
+plans = {}                       # site key -> configuration index, or None = the two-kernel form is faster there
+
+
+def enabled():
+    return os.environ.get("TA_CK_EPILOGUE", "0") == "1" and os.environ.get("TA_DETERMINISTIC", "0") != "1"
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise _hip.HipExtensionError("TA_CK_EPILOGUE=1 but %s is missing: build it with `make -C transferattack_amd/csrc` "
+                                     "(python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise _hip.HipExtensionError("cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise _hip.HipExtensionError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype, fn.argtypes = restype, argtypes
+    if lib.ta_ck_abi_version() != ABI_VERSION:
+        raise _hip.HipExtensionError("libta_ck.so ABI %d, binding %d" % (lib.ta_ck_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def nhwc(t):
+    """is ``t`` ([n, c, h, w]) dense NHWC memory?"""
+    return t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def weight_kyxc(conv):
+    """the convolution's weight as dense [k, y, x, c] memory, cached on the module (frozen weights: built once)"""
+    w = conv.weight
+    cached = getattr(conv, "_ta_ck_weight", None)
+    if cached is None or cached[0] != w._version or cached[1].device != w.device:
+        cached = (w._version, w.detach().permute(0, 2, 3, 1).contiguous())
+        conv._ta_ck_weight = cached
+    return cached[1]
+
+
+def geometry(x_shape, conv):
+    """(n, c, h, w, k, ksize, stride, pad) of ``conv`` on an input of ``x_shape``, or None if the entry points do not take it"""
+    k, c, ky, kx = conv.weight.shape
+    st, pd, dl = tuple(conv.stride), tuple(conv.padding), tuple(conv.dilation)
+    if ky != kx or st[0] != st[1] or pd[0] != pd[1] or dl != (1, 1) or conv.groups != 1 or isinstance(conv.padding, str):
+        return None
+    n, cin, h, w = x_shape
+    if cin != c:
+        return None
+    return (int(n), int(c), int(h), int(w), int(k), int(ky), int(st[0]), int(pd[0]))
+
+
+def out_hw(geom):
+    n, c, h, w, k, ks, st, pd = geom
+    return (h + 2 * pd - ks) // st + 1, (w + 2 * pd - ks) // st + 1
+
+
+def conv(kind, index, a, w, d0, d1, d2, e, geom):
+    """one launch on ``a``'s device and current stream; -> 0 launched / UNSUPPORTED; raises otherwise"""
+    p = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+    dev = a.device
+    with torch.cuda.device(dev):
+        rc = load().ta_ck_conv(kind, index, p(a), p(w), p(d0), p(d1), p(d2), p(e), *geom, torch.cuda.current_stream(dev).cuda_stream)
+    if rc not in (0, UNSUPPORTED):
+        raise _hip.HipExtensionError("ta_ck_conv failed (rc=%d): %s" % (rc, load().ta_ck_last_error().decode("utf-8", "replace")))
+    if rc == 0:
+        stats["fused_launches"] += 1
+    return rc
+
+
+def _time(fn, reps=3):
+    fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / reps
+
+
+def choose(key, kind, geom, run_fused, run_two_kernels):
+    """-> the configuration index of the fused form for this site, or None where the two-kernel form is at least as fast.
+    Decided once per key by timing both on the caller's own tensors (``run_fused(index)`` -> rc, ``run_two_kernels()``: both
+    leave their inputs untouched); a fused form must win by 3 % to be taken."""
+    if key in plans:
+        return plans[key]
+    n_cfg = load().ta_ck_instances(kind, geom[5], geom[6], geom[7])
+    best, best_ms = None, float("inf")
+    if n_cfg > 0:
+        torch.cuda.synchronize()
+        base_ms = _time(run_two_kernels)
+        for idx in range(n_cfg):
+            if run_fused(idx) != 0:
+                continue
+            ms = _time(lambda: run_fused(idx))
+            if ms < best_ms:
+                best, best_ms = idx, ms
+        if best is not None and best_ms > 0.97 * base_ms:
+            best = None
+        if os.environ.get("TA_CK_DEBUG"):
+            print("ck site %s: two kernels %.1f us, fused %s" % (key, base_ms * 1e3, "none faster" if best is None else "%.1f us (%s)" % (
+                best_ms * 1e3, load().ta_ck_instance_name(kind, geom[5], geom[6], geom[7], best).decode())), flush=True)
+    plans[key] = best
+    stats["tuned_sites"] += 1
+    stats["sites_on_ck"] += best is not None
+    return best

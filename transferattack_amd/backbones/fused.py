@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
 
-from .. import _hip
+from .. import _ck, _hip
 
 
 def _conv(x, conv):
@@ -36,6 +36,84 @@ def _conv_input_grad(g, x_like, conv):
     """d/d(input) of ``conv`` for output gradient ``g``; ``x_like`` is the convolution's input (shape / memory format only)"""
     return torch.ops.aten.convolution_backward(g, x_like, conv.weight, None, list(conv.stride), list(conv.padding),
                                                list(conv.dilation), False, [0, 0], conv.groups, [True, False, False])[0]
+
+
+# ---- convolution sites.  Each is "MIOpen convolution + one glue kernel" (the two-kernel form), or -- with TA_CK_EPILOGUE=1, NHWC
+# operands and a shape for which it measured faster (``_ck.choose``) -- ONE composable_kernel convolution with the glue as its
+# epilogue (libta_ck.so, include/ta_ck.h).  Same rounding points either way; the fused form leaves no pass bits (CK's epilogue
+# operands are element tensors), so a backward site behind it reads the activation itself.
+def _ck_ready(*tensors):
+    return _ck.enabled() and all(t is None or _ck.nhwc(t) for t in tensors)
+
+
+def _empty_nhwc(like, n, c, h, w):
+    return torch.empty((n, c, h, w), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+
+def _site_bias_relu(x, conv, new_bits):
+    """-> (clamp_min(conv(x) + bias, 0), pass bits | None)"""
+    def two_kernels():
+        y = _conv(x, conv)
+        m = new_bits(y)
+        _hip.bias_act_(y, conv.bias, mask=m)
+        return y, m
+    geom = _ck.geometry(x.shape, conv) if _ck_ready(x) else None
+    if geom is None:
+        return two_kernels()
+    w = _ck.weight_kyxc(conv)
+    ho, wo = _ck.out_hw(geom)
+    y = _empty_nhwc(x, geom[0], geom[4], ho, wo)
+    fused = lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom)      # noqa: E731
+    idx = _ck.choose(("bias_relu", geom), _ck.FWD_BIAS_RELU, geom, fused, two_kernels)
+    if idx is None:
+        return two_kernels()
+    fused(idx)
+    return y, None
+
+
+def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
+    """-> (clamp_min((conv(x) + bias) + (other [+ bias_other]), 0), pass bits | None): a block's last convolution, its shortcut, its ReLU"""
+    def two_kernels():
+        y = _conv(x, conv)
+        m = new_bits(y)
+        _hip.bias_add_relu_(y, conv.bias, other, bias_other, mask=m)
+        return y, m
+    geom = _ck.geometry(x.shape, conv) if _ck_ready(x, other) else None
+    if geom is None:
+        return two_kernels()
+    kind = _ck.FWD_BIAS_ADD_RELU if bias_other is None else _ck.FWD_BIAS_ADD_BIAS_RELU
+    w = _ck.weight_kyxc(conv)
+    ho, wo = _ck.out_hw(geom)
+    if tuple(other.shape) != (geom[0], geom[4], ho, wo):
+        return two_kernels()
+    y = _empty_nhwc(x, geom[0], geom[4], ho, wo)
+    fused = lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)      # noqa: E731
+    idx = _ck.choose(("bias_add_relu", bias_other is not None, geom), kind, geom, fused, two_kernels)
+    if idx is None:
+        return two_kernels()
+    fused(idx)
+    return y, None
+
+
+def _site_input_grad_mask(g, conv, act, bits, other=None):
+    """-> threshold_backward(conv's input gradient of ``g`` [+ other], act, 0): the ReLU in front of ``conv`` (``other``: the second
+    branch of a residual junction).  ``bits``: act's pass bits where the forward left them."""
+    def two_kernels():
+        gx = _like(_conv_input_grad(g, act, conv), act)
+        return _hip.relu_mask(gx, act, gx, gb=other, mask=bits)
+    geom = _ck.geometry(act.shape, conv) if _ck_ready(g, act, other) else None
+    if geom is None:
+        return two_kernels()
+    kind = _ck.BWD_MASK if other is None else _ck.BWD_ADD_MASK
+    w = _ck.weight_kyxc(conv)
+    gx = torch.empty_like(act)
+    d0, d1 = (act, None) if other is None else (other, act)
+    fused = lambda idx: _ck.conv(kind, idx, g, w, d0, d1, None, gx, geom)      # noqa: E731
+    idx = _ck.choose(("input_grad_mask", other is not None, bits is not None, geom), kind, geom, fused, two_kernels)
+    if idx is None:
+        return two_kernels()
+    fused(idx)
+    return gx
 
 
 def observed(module):
@@ -128,22 +206,16 @@ class _ResNetFn(torch.autograd.Function):
         saved, masks, cur = [], [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
-                a = _conv(cur, blk.conv1)
-                ma = new_bits(a)
-                _hip.bias_act_(a, blk.conv1.bias, mask=ma)
+                a, ma = _site_bias_relu(cur, blk.conv1, new_bits)
                 if bottleneck:
-                    b = _conv(a, blk.conv2)
-                    mb = new_bits(b)
-                    _hip.bias_act_(b, blk.conv2.bias, mask=mb)
+                    b, mb = _site_bias_relu(a, blk.conv2, new_bits)
                     last_in, last = b, blk.conv3
                 else:
                     b, mb, last_in, last = None, None, a, blk.conv2
-                y = _conv(last_in, last)
-                my = new_bits(y)
                 if blk.downsample is None:
-                    _hip.bias_add_relu_(y, last.bias, cur, mask=my)
+                    y, my = _site_bias_add_relu(last_in, last, cur, None, new_bits)
                 else:
-                    _hip.bias_add_relu_(y, last.bias, _conv(cur, blk.downsample[0]), blk.downsample[0].bias, mask=my)
+                    y, my = _site_bias_add_relu(last_in, last, _conv(cur, blk.downsample[0]), blk.downsample[0].bias, new_bits)
                 saved.append((a, b, y))
                 masks.append((ma, mb, my))
                 cur = y
@@ -156,10 +228,8 @@ class _ResNetFn(torch.autograd.Function):
         flat = [x, stem, pooled, idx]
         for a, b, y in saved:
             flat += [a, b, y] if bottleneck else [a, y]
-        ctx.have_bits = bits and all(m is not None for trio in masks for m in (trio if bottleneck else (trio[0], trio[2])))
-        if ctx.have_bits:
-            for ma, mb, my in masks:
-                flat += [ma, mb, my] if bottleneck else [ma, my]
+        for ma, mb, my in masks:          # pass bits per activation, None where there are none (TA_RELU_BITS=0, an odd size, a fused site)
+            flat += [ma, mb, my] if bottleneck else [ma, my]
         ctx.save_for_backward(*flat)
         return logits
 
@@ -173,36 +243,32 @@ class _ResNetFn(torch.autograd.Function):
         blocks = [blk for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for blk in layer]
         end = 4 + per * len(blocks)
         saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(4, end, per)]
-        if ctx.have_bits:
-            masks = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(end, end + per * len(blocks), per)]
-        else:
-            masks = [(None, None, None)] * len(blocks)
+        masks = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(end, end + per * len(blocks), per)]
         last_y = saved[-1][2]
         n, c, h, w = last_y.shape
         g_feat = g_logits.mm(net.fc.weight)                                    # [N, C]
         # mean over H*W backward: expand(grad) / (H*W), as autograd's mean_backward
         g = _like(g_feat.view(n, c, 1, 1).expand(n, c, h, w) / (h * w), last_y)
-        # g: gradient wrt the block output BEFORE that output's ReLU threshold has been applied; ``pending`` is a second
-        # addend of the same gradient (the two branches of a junction), folded into the threshold pass
-        pending = None
+        # gm: the gradient wrt a block's output AFTER that output's ReLU threshold.  For the last block it comes from the head; for
+        # block i - 1 it is formed where block i's two branches meet -- threshold(conv1's input gradient + the shortcut's gradient):
+        # one glue pass behind MIOpen's convolution, or that convolution's own epilogue (_site_input_grad_mask)
+        gm = _hip.relu_mask(g, last_y, g, mask=masks[-1][2])
+        g, pending = None, None
         for i in range(len(blocks) - 1, -1, -1):
             blk = blocks[i]
             a, b, y = saved[i]
             ma, mb, my = masks[i]
             x_in = saved[i - 1][2] if i > 0 else pooled
-            # threshold of the block's output ReLU on the sum of the junction's two branches, in place on ``g`` (a fresh
-            # convolution output nobody else holds; ``pending`` -- possibly the previous ``gm`` -- is only read)
-            gm = _hip.relu_mask(g, y, g, gb=pending, mask=my)
             if bottleneck:
-                gb_ = _like(_conv_input_grad(gm, b, blk.conv3), b)
-                _hip.relu_mask(gb_, b, gb_, mask=mb)
-                ga_ = _like(_conv_input_grad(gb_, a, blk.conv2), a)
+                gb_ = _site_input_grad_mask(gm, blk.conv3, b, mb)
+                ga_ = _site_input_grad_mask(gb_, blk.conv2, a, ma)
             else:
-                ga_ = _like(_conv_input_grad(gm, a, blk.conv2), a)
-            _hip.relu_mask(ga_, a, ga_, mask=ma)
-            g_main = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in)
+                ga_ = _site_input_grad_mask(gm, blk.conv2, a, ma)
             g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
-            g, pending = g_main, g_skip                                        # summed inside the next threshold pass
+            if i > 0:
+                gm = _site_input_grad_mask(ga_, blk.conv1, x_in, masks[i - 1][2], other=g_skip)
+            else:                                                              # the pooled map has no ReLU of its own: the junction
+                g, pending = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in), g_skip      # is summed by the max-pool backward
         # the stem's ReLU sits before the max-pool: junction add + max-pool backward + threshold
         mp = net.maxpool
         k, st, pd = _pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding)

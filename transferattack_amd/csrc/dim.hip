@@ -146,6 +146,20 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
+// N 16-byte cells per lane from global memory into LDS with every load issued before the first store -- as straight-line code
+// over scalars (a recursion the compiler inlines): the array form of this loop stayed in scratch memory (r6b: 64 B of private
+// memory per lane, WRITE_SIZE 2.3 x the output, kernels 2 x slower).  cell(u, v) loads cell u into v and returns its LDS offset
+// in floats, or -1 for a cell outside the window.
+template <int U, int N, typename Cell>
+__device__ __forceinline__ void stage_cells(float* lds, const Cell& cell) {
+    if constexpr (U < N) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int at = cell(U, v);
+        stage_cells<U + 1, N>(lds, cell);
+        if (at >= 0) *reinterpret_cast<float4*>(lds + at) = v;
+    }
+}
+
 constexpr int kDimStageStride = 72;     // floats per staged row of x / gy: <= 64 window columns at a source stride <= 1, + 2 taps / slots + 3 of alignment
 
 template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
@@ -212,19 +226,13 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     if (staged) {
         // -- H0: x[sr_lo .. sr_lo + sh - 1][xc_lo .. xc_hi] -> LDS (in `mid`'s storage), 16 bytes per access
         float* X = mid;
-        float4 cell[kXVec];
-        int at[kXVec];
-#pragma unroll
-        for (int u = 0; u < kXVec; ++u) {
+        stage_cells<0, kXVec>(X, [&](int u, float4& v) {
             const int idx = u * kBlock + static_cast<int>(threadIdx.x);
             const int r = idx / X4, c4 = idx - r * X4;
-            const bool ok = r < sh && xc_lo + 4 * c4 <= xc_hi;            // (size % 4 == 0: a cell that starts inside a row ends inside it)
-            at[u] = ok ? r * kDimStageStride + 4 * c4 : -1;
-            if (ok) cell[u] = *reinterpret_cast<const float4*>(xp + static_cast<unsigned>((sr_lo + r) * size + xc_lo + 4 * c4));
-        }
-#pragma unroll
-        for (int u = 0; u < kXVec; ++u)
-            if (at[u] >= 0) *reinterpret_cast<float4*>(X + at[u]) = cell[u];
+            if (!(r < sh && xc_lo + 4 * c4 <= xc_hi)) return -1;         // (size % 4 == 0: a cell that starts inside a row ends inside it)
+            v = *reinterpret_cast<const float4*>(xp + static_cast<unsigned>((sr_lo + r) * size + xc_lo + 4 * c4));
+            return r * kDimStageStride + 4 * c4;
+        });
         __syncthreads();
         TA_PHASE(0, 6);
         // -- H1 from LDS: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1])
@@ -580,19 +588,13 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
     if (staged) {
         // -- stage A0: gy[gr_lo .. gr_hi][gc_lo .. gc_hi] -> G, 16 bytes per access; every load of the lane before its first store
-        float4 cell[kDimGyVec];
-        int at[kDimGyVec];
-#pragma unroll
-        for (int u = 0; u < kDimGyVec; ++u) {
+        stage_cells<0, kDimGyVec>(G, [&](int u, float4& v) {
             const int idx = u * kBlock + static_cast<int>(threadIdx.x);
             const int r = idx / G4, c4 = idx - r * G4;
-            const bool ok = r < gh && gc_lo + 4 * c4 <= gc_hi;           // (size % 4 == 0: a cell that starts inside a row ends inside it)
-            at[u] = ok ? r * kDimGyStride + 4 * c4 : -1;
-            if (ok) cell[u] = *reinterpret_cast<const float4*>(gyp + 4u * static_cast<unsigned>((gr_lo + r) * size + gc_lo + 4 * c4));
-        }
-#pragma unroll
-        for (int u = 0; u < kDimGyVec; ++u)
-            if (at[u] >= 0) *reinterpret_cast<float4*>(G + at[u]) = cell[u];
+            if (!(r < gh && gc_lo + 4 * c4 <= gc_hi)) return -1;         // (size % 4 == 0: a cell that starts inside a row ends inside it)
+            v = *reinterpret_cast<const float4*>(gyp + 4u * static_cast<unsigned>((gr_lo + r) * size + gc_lo + 4 * c4));
+            return r * kDimGyStride + 4 * c4;
+        });
         __syncthreads();
         TA_PHASE(1, 5);
         // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c], gathered from G

@@ -27,7 +27,6 @@ constexpr int kStemWinRows = kStemRows + 3;     // dy rows behind them
 constexpr int kStemWinCols = kStemCols + 3;
 constexpr int kStemLd = 68;                     // dwords per staged dy pixel (64 channels + 4: bank spread)
 constexpr int kStemK = 64;                      // output channels of the convolution = K per tap
-constexpr int kStemRunLd = 68;                  // floats per staged run of dx (64 + 4: the 4 lane quarters land on other banks)
 
 typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,8 +63,7 @@ __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float*
                                                                     const float* __restrict__ stdv, float* __restrict__ ws) {
     // 66 640 B of LDS: more than the 64 KB of every pre-gfx950 part -- this library targets MI355X (gfx950, 160 KB per CU)
     // only, as does philox.h's v_mad_u64_u32 path; the Makefile builds nothing else
-    static_assert(sizeof(float) * (kStemWinRows * kStemWinCols * kStemLd + kStemRows * 6 * kStemRunLd) <= 80 * 1024,
-                  "two workgroups per CU need <= 80 KB of gfx950's 160 KB each");
+    static_assert(sizeof(float) * kStemWinRows * kStemWinCols * kStemLd <= 160 * 1024, "dy window exceeds gfx950's LDS");
     __shared__ __attribute__((aligned(16))) float win[kStemWinRows * kStemWinCols * kStemLd];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,38 +108,24 @@ __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float*
         }
     }
 
-    // -- D[4 * kk + r][col]: position j0 + mt*16 + 4*kk + r of row i0 + wave, column col = (py, px, c).  In dx (NCHW) the wave's
-    // 32 positions x 4 phases x 3 channels are six contiguous runs of 64 floats -- (channel, output row 2i + py), the two px
-    // interleaved -- but a lane holds one COLUMN of D, i.e. every other element of one run: stored from the accumulators, each
-    // instruction scattered 4-byte stores at an 8-byte stride over 12 rows (round 3-5).  Round 6: the wave's accumulators are
-    // transposed through LDS (6.5 KB beside the window) and every run leaves as one 256-byte store of the wave.
-    __shared__ __attribute__((aligned(16))) float runs[kStemRows][6][kStemRunLd];
+    // -- D[4 * kk + r][col]: position j0 + mt*16 + 4*kk + r of row i0 + wave, column col = (py, px, c)
     const int col = lane & 15, i = i0 + wave;
     float part = 0.0f;
-    if (col < 12) {
+    if (col < 12 && i < oh) {
         const int c = col % 3, px = (col / 3) & 1, py = col / 6;
+        const int h = 2 * oh, wd = 2 * ow;
+        float* row = dx + ((static_cast<int64_t>(n) * 3 + c) * h + (2 * i + py)) * wd + px;
         const float sd = SUMS ? stdv[c] : 1.0f;
-        float* run = &runs[wave][c * 2 + py][px];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int jj = mt * 16 + 4 * kk + r;
-                run[2 * jj] = acc[mt][r];
-                if (SUMS && i < oh && j0 + jj < ow) part += fabsf(acc[mt][r] / sd);       // same elements, same order as before
+                const int j = j0 + mt * 16 + 4 * kk + r;
+                if (j < ow) {
+                    row[2 * j] = acc[mt][r];
+                    if (SUMS) part += fabsf(acc[mt][r] / sd);
+                }
             }
-    }
-    __syncthreads();
-    if (i < oh) {
-        const int h = 2 * oh, wd = 2 * ow;
-        const int xcol = 2 * j0 + lane;
-        if (xcol < wd) {
-#pragma unroll
-            for (int seg = 0; seg < 6; ++seg) {
-                const int c = seg >> 1, py = seg & 1;
-                dx[((static_cast<int64_t>(n) * 3 + c) * h + (2 * i + py)) * wd + xcol] = runs[wave][seg][lane];
-            }
-        }
     }
     if (SUMS) {
         __shared__ float red[kBlock / kWave];
