@@ -13,8 +13,9 @@ backward + fused HIP update).  Host-side arrangement of the surrogate (all repor
 switchable): eval-mode BatchNorm folded into the convolutions, NHWC memory format (profiles/r01/backbone_probe.jsonl:
 +46% over plain NCHW at this batch), and -- with both -- the fused execution of backbones/fused.py (same MIOpen
 convolutions, the memory-bound passes between them fused, the stem's input gradient on the fp32-MFMA kernel:
-TA_FUSED_GLUE / TA_STEM_KERNEL = 0 switch them off); ``--batch 32 --fold-bn 0 --channels-last 0`` is the reference's
-literal setup.
+TA_FUSED_GLUE / TA_STEM_KERNEL = 0 switch them off) and, site by site where it measures faster, convolution + glue pass as ONE
+composable_kernel convolution with the pass as epilogue (libta_ck.so, ``--ck-epilogue 0`` switches it off);
+``--batch 32 --fold-bn 0 --channels-last 0`` is the reference's literal setup, which every line also reports as ``config.literal``.
 Inputs are resident in HBM before the timed region; the surrogate is the ResNet-50 architecture with seeded
 random weights (no checkpoints offline); arithmetic is fp32 throughout, as in the reference.
 

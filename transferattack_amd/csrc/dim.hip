@@ -146,39 +146,18 @@ __device__ __forceinline__ Tap make_tap_scaled(int o, int in_size, float scale) 
     return Tap{i0, i1, 1.0f - l1, l1};
 }
 
-// N 16-byte cells per lane from global memory into LDS with every load issued before the first store -- as straight-line code
-// over scalars (a recursion the compiler inlines): the array form of this loop stayed in scratch memory (r6b: 64 B of private
-// memory per lane, WRITE_SIZE 2.3 x the output, kernels 2 x slower).  cell(u, v) loads cell u into v and returns its LDS offset
-// in floats, or -1 for a cell outside the window.
-template <int U, int N, typename Cell>
-__device__ __forceinline__ void stage_cells(float* lds, const Cell& cell) {
-    if constexpr (U < N) {
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const int at = cell(U, v);
-        stage_cells<U + 1, N>(lds, cell);
-        if (at >= 0) *reinterpret_cast<float4*>(lds + at) = v;
-    }
-}
-
-constexpr int kDimStageStride = 72;     // floats per staged row of x / gy: <= 64 window columns at a source stride <= 1, + 2 taps / slots + 3 of alignment
-
 template <int RPW>                      // rows per wave of the LDS rectangles: ROWS = 4 * RPW
 __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                int size, int resize, int rnd, int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int vec) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
-    constexpr int X4 = kDimStageStride / 4;                              // 16-byte cells per staged row of x
-    constexpr int kXVec = (ROWS * X4 + kBlock - 1) / kBlock;            // cells per lane
     TA_PHASE_BEGIN();
     __shared__ __attribute__((aligned(16))) Tap ty2[kDimLaneRows];     // output row  -> padded rows
     __shared__ __attribute__((aligned(16))) Tap ty1[ROWS];             // window row  -> x rows (valid rows only)
     __shared__ int corner[2];                                          // px_lo, px_hi
     __shared__ __attribute__((aligned(16))) float T[ROWS * 64];        // H1 result; re-used as `u` by H2 / V2
-    // the zero-padded, rescaled window [ROWS][64]; before V1 writes it, the staged rows of x [ROWS][kDimStageStride] (round 6:
-    // H1's gather -- two 4-byte loads per lane and row at a lane-to-lane stride of size / rnd <= 1 element, 2-3 cache lines per
-    // wave instruction -- reads LDS instead; the rows come in as whole 16-byte aligned segments, <= kXVec loads per lane)
-    __shared__ __attribute__((aligned(16))) float mid[ROWS * kDimStageStride];
+    __shared__ __attribute__((aligned(16))) float mid[ROWS * 64];      // the zero-padded, rescaled window
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row logic runs on the SALU
@@ -218,39 +197,8 @@ __global__ __launch_bounds__(kBlock) void dim_fwd_lanes_kernel(const float* __re
     const int sr_lo = any_rows ? ty1[p_a].i0 : 0;
     const int sh = any_rows ? ty1[p_b].i1 - sr_lo + 1 : 0;             // <= ROWS
 
-    // columns of x behind the window: the taps of its first / last column inside the rescaled image (monotone in between)
-    const int la = max(left - px_lo, 0), lb = min(mw - 1, rnd - 1 + left - px_lo);
-    const int xc_lo = la <= lb ? (make_tap_scaled(px_lo + la - left, size, scale1).i0 & ~3) : 0;
-    const int xc_hi = la <= lb ? make_tap_scaled(px_lo + lb - left, size, scale1).i1 : -1;
-    const bool staged = vec != 0 && any_rows && xc_hi - xc_lo < kDimStageStride;      // workgroup-uniform
-    if (staged) {
-        // -- H0: x[sr_lo .. sr_lo + sh - 1][xc_lo .. xc_hi] -> LDS (in `mid`'s storage), 16 bytes per access
-        float* X = mid;
-        stage_cells<0, kXVec>(X, [&](int u, float4& v) {
-            const int idx = u * kBlock + static_cast<int>(threadIdx.x);
-            const int r = idx / X4, c4 = idx - r * X4;
-            if (!(r < sh && xc_lo + 4 * c4 <= xc_hi)) return -1;         // (size % 4 == 0: a cell that starts inside a row ends inside it)
-            v = *reinterpret_cast<const float4*>(xp + static_cast<unsigned>((sr_lo + r) * size + xc_lo + 4 * c4));
-            return r * kDimStageStride + 4 * c4;
-        });
-        __syncthreads();
-        TA_PHASE(0, 6);
-        // -- H1 from LDS: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1])
-        const int w0 = min(wave, max(sh - 1, 0));
-        const int last = max(sh - 1 - w0, 0);
-        const int c0 = col_ok ? tx1.i0 - xc_lo : 0, c1 = col_ok ? tx1.i1 - xc_lo : 0;
-        float a[RPW], b[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const float* row = X + (w0 + min(4 * i, last & ~3)) * kDimStageStride;
-            a[i] = row[c0];
-            b[i] = row[c1];
-        }
-        float* out = T + wave * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) out[i * 256] = fmaf(tx1.l0, a[i], tx1.l1 * b[i]);
-    } else {
     // -- H1: T[r][c] = fma(lx0, x[r][i0], lx1 * x[r][i1]); all loads of the lane first, 32-bit element offsets
+    {
         float a[RPW], b[RPW];
         // 32-bit BYTE offsets from the wave-uniform plane pointer (4 * size * size < 2^32, host-checked): the loads
         // take the scalar-base + 32-bit-offset form, no 64-bit address arithmetic per access
@@ -517,15 +465,6 @@ __device__ __forceinline__ float hit_accumulate(float acc, float g, float wy, fl
     return acc;
 }
 
-// Staging of the gy window (round 6).  The phase clock (profiles/r05/dim_phase_clock_r5h.txt) puts 75-79 % of a backward
-// workgroup's life in stage A's global gather: per window row a lane loads SA x SA single floats whose columns advance by
-// size / resize ~ 0.91 element from lane to lane, so every wave instruction is 64 four-byte requests over 2-3 cache lines, ~40 of
-// them per lane and tile.  With `vec` (size % 4 == 0, 16-byte aligned gy) the rows of gy behind the window are first copied
-// into LDS as whole 16-byte aligned segments -- <= kDimGyVec global_load_dwordx4 per lane, all issued back to back -- and stage A
-// gathers from there (ds_read_b32, conflict-free: consecutive lanes read consecutive or equal addresses).  Same values, same
-// accumulation order: the bits do not change.
-constexpr int kDimGyStride = kDimStageStride;
-
 template <int RPW, int SB, int PP, int SA>      // SB: hit slots of stage B (3 when no index of x is touched by 4 rescaled pixels);
                                         // SA: hit slots of stage A (2 when no padded index is touched by 3 outputs: always so when the
                                         // second resample shrinks, resize > size -- 4 instead of 9 gathers per window pixel);
@@ -534,13 +473,9 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
                                                                float* __restrict__ ws, int size, int resize, int rnd,
                                                                int top, int left,
                                                                float scale1, float scale2, int tw, int tiles_x,
-                                                               int tiles_y, int vec) {
+                                                               int tiles_y) {
     constexpr int ROWS = 4 * RPW;
-    constexpr int GROWS = ROWS + 2;                                      // gy rows behind ROWS window rows (resize > size)
-    constexpr int G4 = kDimGyStride / 4;                                 // 16-byte cells per staged row
-    constexpr int kDimGyVec = (GROWS * G4 + kBlock - 1) / kBlock;        // cells per lane
     TA_PHASE_BEGIN();
-    __shared__ __attribute__((aligned(16))) float G[GROWS * kDimGyStride];   // the gy window, row gr_lo + r at r * kDimGyStride
     __shared__ __attribute__((aligned(16))) Hit colB[64];               // tile column ix   -> rescaled columns
     __shared__ __attribute__((aligned(16))) Hit rowB[kDimLaneRows];     // tile row iy      -> rescaled rows
     __shared__ __attribute__((aligned(16))) Hit colA[64];               // window column px -> output columns
@@ -575,68 +510,13 @@ __global__ __launch_bounds__(kBlock) void dim_bwd_lanes_kernel(const float* __re
     __syncthreads();
     TA_PHASE(1, 1);
 
-    // the rows / columns of gy behind the window (the hit runs are monotone in the window index)
-    const int gr_lo = rowA[0].first, gr_hi = min(rowA[mh - 1].first + SA - 1, size - 1);
-    const int gc_lo = colA[0].first & ~3, gc_hi = min(colA[mw - 1].first + SA - 1, size - 1);
-    const int gh = gr_hi - gr_lo + 1;
-    const bool staged = vec != 0 && gh <= GROWS && gc_hi - gc_lo < kDimGyStride;     // wave-uniform (workgroup-uniform)
-
 #pragma unroll 1
     for (int q = 0; q < PP; ++q) {
     const int plane = group * PP + q;
     const char* gyp = reinterpret_cast<const char*>(gy + static_cast<int64_t>(plane) * size * size);
     char* gxp = reinterpret_cast<char*>(gx + static_cast<int64_t>(plane) * size * size);
-    if (staged) {
-        // -- stage A0: gy[gr_lo .. gr_hi][gc_lo .. gc_hi] -> G, 16 bytes per access; every load of the lane before its first store
-        stage_cells<0, kDimGyVec>(G, [&](int u, float4& v) {
-            const int idx = u * kBlock + static_cast<int>(threadIdx.x);
-            const int r = idx / G4, c4 = idx - r * G4;
-            if (!(r < gh && gc_lo + 4 * c4 <= gc_hi)) return -1;         // (size % 4 == 0: a cell that starts inside a row ends inside it)
-            v = *reinterpret_cast<const float4*>(gyp + 4u * static_cast<unsigned>((gr_lo + r) * size + gc_lo + 4 * c4));
-            return r * kDimGyStride + 4 * c4;
-        });
-        __syncthreads();
-        TA_PHASE(1, 5);
-        // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c], gathered from G
-        Hit hx = colA[lane < mw ? lane : 0];
-        if (lane >= mw) hx.n = 0;
-        const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
-        int col[SA];
-#pragma unroll
-        for (int k = 0; k < SA; ++k) col[k] = min(hx.first + k, gc_hi) - gc_lo;
-#pragma unroll 1
-        for (int p = wave; p < mh; p += 4) {
-            const Hit* hy = &rowA[p];
-            const int first_y = __builtin_amdgcn_readfirstlane(hy->first);
-            const int n_y = __builtin_amdgcn_readfirstlane(hy->n);                    // <= 3: scale2 >= 1
-            const unsigned both_y = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(hy->both)));
-            float g[SA][SA];
-#pragma unroll
-            for (int ky = 0; ky < SA; ++ky) {
-                const float* grow = G + (min(first_y + ky, gr_hi) - gr_lo) * kDimGyStride;
-#pragma unroll
-                for (int kx = 0; kx < SA; ++kx) g[ky][kx] = grow[col[kx]];
-            }
-            float acc = 0.0f;
-            if (!any_both_x && both_y == 0u) {
-#pragma unroll
-                for (int ky = 0; ky < SA; ++ky)
-                    if (ky < n_y)
-#pragma unroll
-                        for (int kx = 0; kx < SA; ++kx)
-                            acc = hit_accumulate<true>(acc, g[ky][kx], hy->w[ky], 0.0f, false, hx, kx);
-            } else {
-#pragma unroll
-                for (int ky = 0; ky < SA; ++ky)
-                    if (ky < n_y)
-#pragma unroll
-                        for (int kx = 0; kx < SA; ++kx)
-                            acc = hit_accumulate<false>(acc, g[ky][kx], hy->w[ky], hy->w2[ky], (both_y >> ky) & 1u, hx, kx);
-            }
-            mid[p * 64 + lane] = acc;
-        }
-    } else {
-    // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c], gathered from global memory (any size / alignment)
+    // -- stage A: mid[p][c] = d(rescaled)[ry_lo + p][rx_lo + c]
+    {
         Hit hx = colA[lane < mw ? lane : 0];
         if (lane >= mw) hx.n = 0;
         const bool any_both_x = __builtin_amdgcn_readfirstlane(__any(hx.both != 0u)) != 0;
@@ -888,13 +768,12 @@ extern "C" int ta_dim_fwd(const float* x, float* y, int64_t planes, int size, in
             const int64_t lane_blocks = planes * tiles_x * tiles_y;
             TA_REQUIRE(lane_blocks < (1ll << 31) - 8, "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-            const int vec = (size % 4 == 0 && aligned16(x)) ? 1 : 0;          // stage the rows of x through LDS in 16-byte cells
             if (rows <= 40)
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<10>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, vec);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             else
                 hipLaunchKernelGGL(dim_fwd_lanes_kernel<17>, grid, dim3(kBlock), 0, st, x, y, size, resize, rnd, top, left,
-                                   scale1, scale2, tw, tiles_x, tiles_y, vec);
+                                   scale1, scale2, tw, tiles_x, tiles_y);
             return check_launch("dim_fwd_lanes");
         }
     }
@@ -932,17 +811,16 @@ extern "C" int ta_dim_bwd(const float* gy, float* gx, float* ws, int64_t planes,
             const int64_t lane_blocks = planes / pp * tiles_x * tiles_y;
             TA_REQUIRE(planes * tiles_x * tiles_y < (1ll << 31) - 8, "too many tiles");
             const dim3 grid(static_cast<unsigned>(lane_blocks));
-            const int vec = (size % 4 == 0 && aligned16(gy)) ? 1 : 0;          // stage the gy window through LDS in 16-byte cells
             const bool three = max_hits(size, rnd) <= 3;       // true for every rnd < 1.5 * size away from degenerate sizes
             const bool two_a = max_hits(resize, size) <= 2;    // stage A: outputs per padded index (<= 2 whenever resize > size)
 #define TA_DIM_BWD_PP(RPW, SB, SA)                                                                                       \
     do {                                                                                                                 \
         if (pp == 3)                                                                                                     \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 3, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, vec);                       \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
         else                                                                                                             \
             hipLaunchKernelGGL((dim_bwd_lanes_kernel<RPW, SB, 1, SA>), grid, dim3(kBlock), 0, st, gy, gx, ws, size,      \
-                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y, vec);                       \
+                               resize, rnd, top, left, scale1, scale2, tw, tiles_x, tiles_y);                            \
     } while (0)
 #define TA_DIM_BWD(RPW, SB) do { if (two_a) TA_DIM_BWD_PP(RPW, SB, 2); else TA_DIM_BWD_PP(RPW, SB, 3); } while (0)
             if (rows <= 40) { if (three) TA_DIM_BWD(10, 3); else TA_DIM_BWD(10, 4); }
