@@ -10,6 +10,7 @@ find mode this makes the choice of kernel, hence the last bits of an activation,
 """
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -99,7 +100,10 @@ def conv(kind, index, a, w, d0, d1, d2, e, geom):
     """one launch on ``a``'s device and current stream; -> 0 launched / UNSUPPORTED; raises otherwise"""
     p = lambda t: None if t is None else t.data_ptr()      # noqa: E731
     dev = a.device
-    with torch.cuda.device(dev):
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):                        # the launch needs the tensor's device current in THIS thread
+            rc = load().ta_ck_conv(kind, index, p(a), p(w), p(d0), p(d1), p(d2), p(e), *geom, torch.cuda.current_stream(dev).cuda_stream)
+    else:
         rc = load().ta_ck_conv(kind, index, p(a), p(w), p(d0), p(d1), p(d2), p(e), *geom, torch.cuda.current_stream(dev).cuda_stream)
     if rc not in (0, UNSUPPORTED):
         raise _hip.HipExtensionError("ta_ck_conv failed (rc=%d): %s" % (rc, load().ta_ck_last_error().decode("utf-8", "replace")))
@@ -108,9 +112,12 @@ def conv(kind, index, a, w, d0, d1, d2, e, geom):
     return rc
 
 
-def _time(fn, reps=3):
+def _time(fn, reps=6):
+    """milliseconds per call on the device.  A first call outside the clock, then ``reps`` queued back to back: the host's own
+    cost of a call (torch's dispatcher for the two-kernel form) hides behind the previous call's kernels, as it does in the loop"""
     fn()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
     start.record()
     for _ in range(reps):
         fn()
@@ -140,7 +147,7 @@ def choose(key, kind, geom, run_fused, run_two_kernels):
             best = None
         if os.environ.get("TA_CK_DEBUG"):
             print("ck site %s: two kernels %.1f us, fused %s" % (key, base_ms * 1e3, "none faster" if best is None else "%.1f us (%s)" % (
-                best_ms * 1e3, load().ta_ck_instance_name(kind, geom[5], geom[6], geom[7], best).decode())), flush=True)
+                best_ms * 1e3, load().ta_ck_instance_name(kind, geom[5], geom[6], geom[7], best).decode())), file=sys.stderr, flush=True)
     plans[key] = best
     stats["tuned_sites"] += 1
     stats["sites_on_ck"] += best is not None

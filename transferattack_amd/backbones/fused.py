@@ -41,13 +41,37 @@ def _conv_input_grad(g, x_like, conv):
 # ---- convolution sites.  Each is "MIOpen convolution + one glue kernel" (the two-kernel form), or -- with TA_CK_EPILOGUE=1, NHWC
 # operands and a shape for which it measured faster (``_ck.choose``) -- ONE composable_kernel convolution with the glue as its
 # epilogue (libta_ck.so, include/ta_ck.h).  Same rounding points either way; the fused form leaves no pass bits (CK's epilogue
-# operands are element tensors), so a backward site behind it reads the activation itself.
-def _ck_ready(*tensors):
-    return _ck.enabled() and all(t is None or _ck.nhwc(t) for t in tensors)
+# operands are element tensors), so a backward site behind it reads the activation itself.  The decision and everything that
+# only depends on (convolution, shapes) is kept on the convolution module: a decided site costs one dictionary lookup, one
+# allocation and one ctypes call on the host (a ResNet-50 iteration has ~100 of them).
+_CL = torch.channels_last
 
 
-def _empty_nhwc(like, n, c, h, w):
-    return torch.empty((n, c, h, w), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+def _dense_nhwc(*tensors):
+    return all(t is None or (t.is_contiguous(memory_format=_CL) and t.dtype == torch.float32 and t.is_cuda) for t in tensors)
+
+
+def _site(conv, tag, x_shape, kind):
+    """the cached plan of this convolution for this role and input shape: (configuration index | None, geometry, KYXC weight, output
+    height, width) -- or the string "tune" when the site has not been decided yet, or None when the fused form cannot take it"""
+    cache = conv.__dict__.get("_ta_ck_sites")
+    if cache is None:
+        cache = conv.__dict__["_ta_ck_sites"] = {}
+    key = (tag, tuple(x_shape), conv.weight._version)
+    plan = cache.get(key, "new")
+    if plan == "new":
+        geom = _ck.geometry(x_shape, conv)
+        if geom is None or _ck.load().ta_ck_instances(kind, geom[5], geom[6], geom[7]) == 0:
+            plan = cache[key] = None
+        else:
+            return "tune", cache, key, geom
+    return plan, cache, key, None
+
+
+def _decide(cache, key, tag, kind, geom, conv, fused, two_kernels):
+    idx = _ck.choose((tag, geom), kind, geom, fused, two_kernels)
+    plan = cache[key] = None if idx is None else (idx, geom, _ck.weight_kyxc(conv)) + _ck.out_hw(geom)
+    return plan
 
 
 def _site_bias_relu(x, conv, new_bits):
@@ -57,17 +81,19 @@ def _site_bias_relu(x, conv, new_bits):
         m = new_bits(y)
         _hip.bias_act_(y, conv.bias, mask=m)
         return y, m
-    geom = _ck.geometry(x.shape, conv) if _ck_ready(x) else None
-    if geom is None:
+    if not (_ck.enabled() and _dense_nhwc(x)):
         return two_kernels()
-    w = _ck.weight_kyxc(conv)
-    ho, wo = _ck.out_hw(geom)
-    y = _empty_nhwc(x, geom[0], geom[4], ho, wo)
-    fused = lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom)      # noqa: E731
-    idx = _ck.choose(("bias_relu", geom), _ck.FWD_BIAS_RELU, geom, fused, two_kernels)
-    if idx is None:
+    plan, cache, key, geom = _site(conv, "bias_relu", x.shape, _ck.FWD_BIAS_RELU)
+    if plan == "tune":
+        w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
+        y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        plan = _decide(cache, key, "bias_relu", _ck.FWD_BIAS_RELU, geom, conv,
+                       lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom), two_kernels)
+    if plan is None:
         return two_kernels()
-    fused(idx)
+    idx, geom, w, ho, wo = plan
+    y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+    _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom)
     return y, None
 
 
@@ -78,41 +104,59 @@ def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
         m = new_bits(y)
         _hip.bias_add_relu_(y, conv.bias, other, bias_other, mask=m)
         return y, m
-    geom = _ck.geometry(x.shape, conv) if _ck_ready(x, other) else None
-    if geom is None:
+    if not (_ck.enabled() and _dense_nhwc(x, other)):
         return two_kernels()
     kind = _ck.FWD_BIAS_ADD_RELU if bias_other is None else _ck.FWD_BIAS_ADD_BIAS_RELU
-    w = _ck.weight_kyxc(conv)
-    ho, wo = _ck.out_hw(geom)
-    if tuple(other.shape) != (geom[0], geom[4], ho, wo):
+    tag = "bias_add_relu" if bias_other is None else "bias_add_bias_relu"
+    plan, cache, key, geom = _site(conv, tag, x.shape, kind)
+    if plan == "tune":
+        w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
+        if tuple(other.shape) != (geom[0], geom[4], ho, wo):
+            plan = cache[key] = None
+        else:
+            y = torch.empty_like(other)
+            plan = _decide(cache, key, tag, kind, geom, conv,
+                           lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom), two_kernels)
+    if plan is None:
         return two_kernels()
-    y = _empty_nhwc(x, geom[0], geom[4], ho, wo)
-    fused = lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)      # noqa: E731
-    idx = _ck.choose(("bias_add_relu", bias_other is not None, geom), kind, geom, fused, two_kernels)
-    if idx is None:
-        return two_kernels()
-    fused(idx)
+    idx, geom, w, ho, wo = plan
+    y = torch.empty_like(other)
+    _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)
     return y, None
 
 
-def _site_input_grad_mask(g, conv, act, bits, other=None):
+def _site_input_grad_mask(g, conv, act, bits, other=None, other_is_scratch=False):
     """-> threshold_backward(conv's input gradient of ``g`` [+ other], act, 0): the ReLU in front of ``conv`` (``other``: the second
-    branch of a residual junction).  ``bits``: act's pass bits where the forward left them."""
+    branch of a residual junction).  ``bits``: act's pass bits where the forward left them.  ``other_is_scratch``: nobody reads
+    ``other`` afterwards -- the fused form then writes its result over it (composable_kernel zero-fills the output of a
+    backward-data convolution first unless one of its epilogue operands IS the output: a memset of the whole map saved)."""
     def two_kernels():
         gx = _like(_conv_input_grad(g, act, conv), act)
         return _hip.relu_mask(gx, act, gx, gb=other, mask=bits)
-    geom = _ck.geometry(act.shape, conv) if _ck_ready(g, act, other) else None
-    if geom is None:
+    if not (_ck.enabled() and _dense_nhwc(g, act, other)):
         return two_kernels()
     kind = _ck.BWD_MASK if other is None else _ck.BWD_ADD_MASK
-    w = _ck.weight_kyxc(conv)
-    gx = torch.empty_like(act)
-    d0, d1 = (act, None) if other is None else (other, act)
-    fused = lambda idx: _ck.conv(kind, idx, g, w, d0, d1, None, gx, geom)      # noqa: E731
-    idx = _ck.choose(("input_grad_mask", other is not None, bits is not None, geom), kind, geom, fused, two_kernels)
-    if idx is None:
+    tag = ("input_grad_mask", other is not None, bits is not None)
+    plan, cache, key, geom = _site(conv, tag, act.shape, kind)
+    if plan == "tune":
+        w = _ck.weight_kyxc(conv)
+        # tuned on the form that will run: in place over a scratch copy of the other addend where the caller allows it
+        out = other.clone(memory_format=torch.preserve_format) if (other is not None and other_is_scratch) else torch.empty_like(act)
+        d0, d1 = (act, None) if other is None else ((out if other_is_scratch else other), act)
+        plan = _decide(cache, key, tag, kind, geom, conv, lambda idx: _ck.conv(kind, idx, g, w, d0, d1, None, out, geom), two_kernels)
+    if plan is None:
         return two_kernels()
-    fused(idx)
+    idx, geom, w, _, _ = plan
+    if other is None:
+        gx = torch.empty_like(act)
+        _ck.conv(kind, idx, g, w, act, None, None, gx, geom)
+    elif other_is_scratch:
+        gx = other
+        _ck.conv(kind, idx, g, w, other, act, None, other, geom)
+        _hip.invalidate_partials(other)
+    else:
+        gx = torch.empty_like(act)
+        _ck.conv(kind, idx, g, w, other, act, None, gx, geom)
     return gx
 
 
@@ -266,7 +310,8 @@ class _ResNetFn(torch.autograd.Function):
                 ga_ = _site_input_grad_mask(gm, blk.conv2, a, ma)
             g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
             if i > 0:
-                gm = _site_input_grad_mask(ga_, blk.conv1, x_in, masks[i - 1][2], other=g_skip)
+                # (g_skip -- this block's gm, or the projection's fresh input gradient -- has no reader after this junction)
+                gm = _site_input_grad_mask(ga_, blk.conv1, x_in, masks[i - 1][2], other=g_skip, other_is_scratch=True)
             else:                                                              # the pooled map has no ReLU of its own: the junction
                 g, pending = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in), g_skip      # is summed by the max-pool backward
         # the stem's ReLU sits before the max-pool: junction add + max-pool backward + threshold
