@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 10
+#define TA_ABI_VERSION 11
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -125,6 +125,10 @@ int ta_mi_update_u8(const float* g, const float* v, const float* m_in, float* m_
  *                            image plane this path sees; a plane size that is not a multiple of 4 takes the scalar form, whose
  *                            fixed summation order is another one: equal to fp32 summation error). */
 int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
+                         const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream);
+/* the same pass writing y in NHWC memory ([n][hw][c]: what a channels_last surrogate's first convolution reads -- no layout copy
+ * in front of it); three-channel images, hw % 4 == 0, 16-byte aligned operands, TA_EINVAL otherwise.  Same bits per element. */
+int ta_normalize_adv_fwd_nhwc(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
                          const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream);
 int ta_mi_update_std(const float* gy, const float* stdv, const float* m_in, float* m_out, float* delta, const float* x,
                      const uint8_t* x_u8, const int* u8_mismatch, float* ws, int ws_slots, float decay, float alpha,

@@ -204,6 +204,11 @@ def test_normalize_folded_update(shape):
         _hip.normalize_fwd(xa, y_ref, mean, std)
         _hip.normalize_adv_fwd(x, delta, y, mean, std, data_u8=source)
         assert torch.equal(y, y_ref)
+        if c == 3 and x[0, 0].numel() % 4 == 0:                             # the NHWC form for a channels_last surrogate: same values
+            y_cl = torch.full_like(x, float("nan"), memory_format=torch.channels_last)
+            _hip.normalize_adv_fwd(x, delta, y_cl, mean, std, data_u8=source)
+            assert not y_cl.is_contiguous() and torch.equal(y_cl, y_ref)
+            assert torch.equal(y_cl.permute(0, 2, 3, 1).contiguous(), y_ref.permute(0, 2, 3, 1).contiguous())
     # backward end
     launches = _hip.stats["std_form_launches"]
     for m_in, keep in ((mom, True), (None, True), (None, False)):

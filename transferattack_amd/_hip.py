@@ -43,6 +43,7 @@ SIGNATURES = {
     "ta_mi_update_u8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _i64, _vp]),
     "ta_u8_source_probe": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "ta_normalize_adv_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "ta_normalize_adv_fwd_nhwc": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_mi_update_std": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f32, _f32, _f32, _i64, _int, _i64, _vp]),
     "ta_abs_sum_partials_std": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_stem_tiles": (_i64, [_int, _int]),
@@ -82,7 +83,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HipExtensionError(RuntimeError):
@@ -462,6 +463,12 @@ def normalize_adv_fwd(data, delta, y, mean, std, data_u8=None):
     if mean.numel() != c or std.numel() != c:
         raise ValueError("mean / std have %d / %d entries for %d channels" % (mean.numel(), std.numel(), c))
     _wrote(y)
+    if not y.is_contiguous() and y.is_contiguous(memory_format=torch.channels_last):
+        # y in NHWC memory for a channels_last surrogate (its first convolution reads it without a layout copy)
+        _call("ta_normalize_adv_fwd_nhwc", data, _ptr(data, name="data"), _ptr(u8, torch.uint8, name="data_u8"),
+              _ptr(flag, torch.int32, name="mismatch"), _ptr(delta, name="delta"), _ptr_any(y, "y"), _ptr(mean, name="mean"),
+              _ptr(std, name="std"), n, c, data[0, 0].numel())
+        return
     _call("ta_normalize_adv_fwd", data, _ptr(data, name="data"), _ptr(u8, torch.uint8, name="data_u8"),
           _ptr(flag, torch.int32, name="mismatch"), _ptr(delta, name="delta"), _ptr(y, name="y"), _ptr(mean, name="mean"),
           _ptr(std, name="std"), n, c, data[0, 0].numel())

@@ -239,8 +239,12 @@ class Attack(object):
         backbone = self.model[1]
         momentum = 0
         src = self._byte_source_of(data)
+        # a surrogate kept in NHWC memory (TA_CHANNELS_LAST=1) gets its input written in NHWC: no layout copy before its first layer
+        first = next((p for p in backbone.parameters() if p.dim() == 4), None)
+        nhwc = (first is not None and not first.is_contiguous() and first.is_contiguous(memory_format=torch.channels_last)
+                and data.shape[1] == 3 and data[0, 0].numel() % 4 == 0)
         for it in range(self.epoch):
-            y = torch.empty_like(data)
+            y = torch.empty_like(data, memory_format=torch.channels_last) if nhwc else torch.empty_like(data)
             _hip.normalize_adv_fwd(data, delta.detach(), y, mean, std, data_u8=src)
             y.requires_grad_(True)
             setattr(y, _hip._SCALE_ATTR, std)          # a fused backbone hands it to its last backward kernel

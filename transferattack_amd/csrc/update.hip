@@ -237,6 +237,50 @@ __global__ __launch_bounds__(kBlock) void normalize_adv_fwd_kernel(const float* 
     }
 }
 
+// The same pass for a surrogate that runs in NHWC memory (three-channel images): y[n][p][c] -- the backbone's first convolution
+// reads it as it is, the NCHW -> NHWC copy torch would insert in front of it (146 us per iteration at batch 125, r6e) disappears.
+// A lane owns four pixels: three 16-byte loads of delta, three 4-byte (or 16-byte) loads of the image, three 16-byte stores of
+// twelve consecutive floats.  Same expression per element as above: same bits, other layout.
+template <bool X_U8>
+__global__ __launch_bounds__(kBlock) void normalize_adv_fwd_nhwc3_kernel(const float* __restrict__ x, const uint8_t* __restrict__ x_u8,
+                                                                         const int* __restrict__ u8_mismatch,
+                                                                         const float* __restrict__ delta, float* __restrict__ y,
+                                                                         const float* __restrict__ mean,
+                                                                         const float* __restrict__ stdv, int64_t hw) {
+    const int64_t img = blockIdx.y;
+    const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+    if (p >= hw) return;
+    const bool bytes = X_U8 && uniform_int(*u8_mismatch) == 0;
+    float o[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t off = (img * 3 + c) * hw + p;
+        Pack<4> a, d;
+        d.load(delta + off);
+        if (X_U8 && bytes) {
+            const uint32_t pb = *reinterpret_cast<const uint32_t*>(x_u8 + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = u8_to_unit((pb >> (8 * k)) & 0xffu);
+        } else {
+            a.load(x + off);
+        }
+        const float m = mean[c], sd = stdv[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[c][k] = ((a[k] + d[k]) - m) / sd;
+    }
+    float* out = y + (img * hw + p) * 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        Pack<4> v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * q + k;                     // i = 3 * pixel + channel
+            v[k] = o[i % 3][i / 3];
+        }
+        v.store(out + 4 * q);
+    }
+}
+
 template <int VEC, bool HAS_V>      // HAS_V: the tile sums are of |gx + v| (VMI-FGSM: the momentum normalises grad + variance)
 __global__ __launch_bounds__(kBlock) void normalize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                const float* __restrict__ stdv,
@@ -984,6 +1028,23 @@ extern "C" int ta_normalize_adv_fwd(const float* x, const uint8_t* x_u8, const i
     else
         hipLaunchKernelGGL((normalize_adv_fwd_kernel<1, false>), grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, e, hw);
     return check_launch("normalize_adv_fwd");
+}
+
+extern "C" int ta_normalize_adv_fwd_nhwc(const float* x, const uint8_t* x_u8, const int* u8_mismatch, const float* delta, float* y,
+                                         const float* mean, const float* stdv, int64_t n, int c, int64_t hw, void* stream) {
+    const int64_t e = static_cast<int64_t>(c) * hw;
+    if (int rc = check_planes(n, e)) return rc;
+    TA_REQUIRE(x && delta && y && mean && stdv, "null pointer");
+    TA_REQUIRE((x_u8 == nullptr) == (u8_mismatch == nullptr), "x_u8 and its probe flag come together");
+    TA_REQUIRE(c == 3 && hw % 4 == 0 && aligned16(x) && aligned16(delta) && aligned16(y),
+               "the NHWC form takes three-channel images with hw %% 4 == 0 and 16-byte aligned operands (c=%d, hw=%lld)", c, (long long)hw);
+    const dim3 grid(static_cast<unsigned>(ceil_div(hw / 4, kBlock)), static_cast<unsigned>(n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (x_u8 != nullptr && (reinterpret_cast<uintptr_t>(x_u8) & 3u) == 0)
+        hipLaunchKernelGGL(normalize_adv_fwd_nhwc3_kernel<true>, grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, hw);
+    else
+        hipLaunchKernelGGL(normalize_adv_fwd_nhwc3_kernel<false>, grid, dim3(kBlock), 0, st, x, x_u8, u8_mismatch, delta, y, mean, stdv, hw);
+    return check_launch("normalize_adv_fwd_nhwc");
 }
 
 // x_u8[i] = round(x[i] * 255) and *mismatch |= (float(x_u8[i]) / 255 != x[i]) -- the caller zeroes *mismatch first
