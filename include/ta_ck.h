@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TA_CK_ABI_VERSION 1
+#define TA_CK_ABI_VERSION 2
 #define TA_CK_EINVAL (-1)
 #define TA_CK_UNSUPPORTED 1
 
@@ -33,6 +33,11 @@ extern "C" {
 #define TA_CK_FWD_BIAS_ADD_BIAS_RELU 3 /* e = clamp_min((acc + d0[k]) + (d1 + d2[k]), 0)          ... with a projection shortcut */
 #define TA_CK_BWD_MASK 4               /* e = d0 <= 0 ? 0 : acc                                   conv backward-data + ta_relu_mask */
 #define TA_CK_BWD_ADD_MASK 5           /* e = d1 <= 0 ? 0 : acc + d0                              ... with the junction add     */
+/* A stride-1 convolution's input gradient IS a forward convolution of the output gradient with the flipped, transposed filter
+ * (w'[c][Y-1-y][X-1-x][k] = w[k][y][x][c], padding ksize - 1 - pad): the two kinds below are FORWARD kernels with the backward glue
+ * as epilogue -- any square filter; a = output gradient in the role of the input, w = w', e = input gradient. */
+#define TA_CK_FWD_MASK 6               /* e = d0 <= 0 ? 0 : acc                                   conv backward-data + ta_relu_mask */
+#define TA_CK_FWD_ADD_MASK 7           /* e = d1 <= 0 ? 0 : acc + d0                              ... with the junction add     */
 
 int ta_ck_abi_version(void);
 const char* ta_ck_last_error(void);
@@ -45,6 +50,8 @@ const char* ta_ck_instance_name(int kind, int ksize, int stride, int pad, int in
  * backward kinds: a = output gradient [n, ho, wo, k], w = the same weight, e = input gradient [n, hi, wi, c];
  *                 TA_CK_BWD_MASK: d0 = the activation in front of the convolution [n, hi, wi, c] (its ReLU's threshold);
  *                 TA_CK_BWD_ADD_MASK: d0 = the other addend of the junction, d1 = that activation
+ * TA_CK_FWD_MASK / _ADD_MASK: forward geometry of the rewritten problem (c = the gradient's channels, k = the input's), d0 / d1
+ *                 as for the backward kinds but with e's shape [n, ho, wo, k].
  * unused d pointers are NULL.  ho = (hi + 2*pad - ksize) / stride + 1. */
 int ta_ck_conv(int kind, int index, const float* a, const float* w, const float* d0, const float* d1, const float* d2, float* e,
                int n, int c, int hi, int wi, int k, int ksize, int stride, int pad, void* stream);

@@ -180,10 +180,14 @@ def test_ck_abi_symbols_exported():
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ta_ck.h")).read()
     declared = set(re.findall(r"\b(ta_ck_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_ck.SIGNATURES), declared ^ set(_ck.SIGNATURES)
-    assert lib.ta_ck_abi_version() == _ck.ABI_VERSION == 1
+    assert lib.ta_ck_abi_version() == _ck.ABI_VERSION == 2
     assert lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 3, 1, 1) >= 8 and lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 1, 1, 0) >= 8
     for kind in (_ck.FWD_BIAS_ADD_RELU, _ck.FWD_BIAS_ADD_BIAS_RELU, _ck.BWD_MASK, _ck.BWD_ADD_MASK):
         assert lib.ta_ck_instances(kind, 1, 1, 0) >= 6 and lib.ta_ck_instances(kind, 3, 1, 1) == 0
+    for kind in (_ck.FWD_MASK, _ck.FWD_ADD_MASK):                  # the backward glue on the forward kernels: any filter
+        assert lib.ta_ck_instances(kind, 1, 1, 0) >= 8 and lib.ta_ck_instances(kind, 3, 1, 1) >= 8
+    assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 1, 1)) == (4, 128, 56, 56, 64, 3, 1, 1)
+    assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 2, 1)) is None
     assert b"Xdl_CShuffle" in lib.ta_ck_instance_name(_ck.BWD_ADD_MASK, 1, 1, 0, 0)
     assert lib.ta_ck_conv(_ck.FWD_BIAS_RELU, 0, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, None) == -1       # TA_CK_EINVAL
     assert b"null" in lib.ta_ck_last_error()
@@ -511,3 +515,21 @@ def test_config2_miniature_matches_reference(golden, monkeypatch):
     delta = make("mifgsm", models=[model])(x, t(g["label"]))
     import fgsm_oracle as O
     assert np.array_equal(O.quantize_u8(x + delta), g["adv_u8"])
+
+
+def test_backward_as_forward_rewrite():
+    """_ck.weight_flipped_cyxk / backward_as_forward: the input gradient of a stride-1 convolution equals the FORWARD convolution of
+    the output gradient with the flipped, transposed filter at padding ksize - 1 - pad (what libta_ck.so's TA_CK_FWD_MASK kinds run)"""
+    from transferattack_amd import _ck
+    gen = torch.Generator().manual_seed(3)
+    for cin, cout, ks, pad in ((5, 7, 3, 1), (6, 4, 1, 0), (3, 8, 5, 2)):
+        conv = torch.nn.Conv2d(cin, cout, ks, padding=pad, bias=False).double()
+        x = torch.randn(2, cin, 9, 11, generator=gen, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(2, cout, 9, 11, generator=gen, dtype=torch.float64)
+        want = torch.autograd.grad(conv(x), x, g)[0]
+        geom = _ck.geometry(x.shape, conv)
+        fgeom = _ck.backward_as_forward(geom)
+        assert fgeom == (2, cout, 9, 11, cin, ks, 1, ks - 1 - pad)
+        w_cyxk = _ck.weight_flipped_cyxk(conv)                             # [c, y, x, k] -> torch's [out = c, in = k, y, x]
+        got = torch.nn.functional.conv2d(g, w_cyxk.permute(0, 3, 1, 2), padding=fgeom[7])
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)

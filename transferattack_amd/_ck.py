@@ -18,9 +18,9 @@ from . import _hip
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TA_CK_LIB", os.path.join(_HERE, "lib", "libta_ck.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-FWD_BIAS_RELU, FWD_BIAS_ADD_RELU, FWD_BIAS_ADD_BIAS_RELU, BWD_MASK, BWD_ADD_MASK = 1, 2, 3, 4, 5
+FWD_BIAS_RELU, FWD_BIAS_ADD_RELU, FWD_BIAS_ADD_BIAS_RELU, BWD_MASK, BWD_ADD_MASK, FWD_MASK, FWD_ADD_MASK = 1, 2, 3, 4, 5, 6, 7
 UNSUPPORTED = 1
 
 _int, _vp = ctypes.c_int, ctypes.c_void_p
@@ -126,29 +126,54 @@ def _time(fn, reps=6):
     return start.elapsed_time(end) / reps
 
 
-def choose(key, kind, geom, run_fused, run_two_kernels):
-    """-> the configuration index of the fused form for this site, or None where the two-kernel form is at least as fast.
-    Decided once per key by timing both on the caller's own tensors (``run_fused(index)`` -> rc, ``run_two_kernels()``: both
-    leave their inputs untouched); a fused form must win by 3 % to be taken."""
+def weight_flipped_cyxk(conv):
+    """the filter of the FORWARD convolution that computes ``conv``'s input gradient (stride 1): w'[c][Y-1-y][X-1-x][k] = w[k][c][y][x],
+    dense [c, y, x, k] memory -- its "output" channels are conv's input channels; cached on the module"""
+    w = conv.weight
+    cached = getattr(conv, "_ta_ck_weight_t", None)
+    if cached is None or cached[0] != w._version or cached[1].device != w.device:
+        cached = (w._version, w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        conv._ta_ck_weight_t = cached
+    return cached[1]
+
+
+def backward_as_forward(geom):
+    """the forward problem whose result is the input gradient of the stride-1 convolution ``geom``, or None (strided convolution)"""
+    n, c, h, w, k, ks, st, pd = geom
+    if st != 1 or ks - 1 - pd < 0:
+        return None
+    ho, wo = out_hw(geom)
+    return (n, k, ho, wo, c, ks, 1, ks - 1 - pd)
+
+
+def choose(key, families, run_two_kernels):
+    """-> (family, configuration index) of the fastest fused form for this site, or None where the two-kernel form is at least as
+    fast.  ``families``: [(kind, geometry, run(index) -> rc)] -- e.g. the backward-data kernels and the forward kernels on the
+    rewritten problem.  Decided once per key by timing all of them on the caller's own tensors (none may modify its inputs); a
+    fused form must win by 3 % to be taken."""
     if key in plans:
         return plans[key]
-    n_cfg = load().ta_ck_instances(kind, geom[5], geom[6], geom[7])
-    best, best_ms = None, float("inf")
-    if n_cfg > 0:
-        torch.cuda.synchronize()
-        base_ms = _time(run_two_kernels)
+    best, best_ms, base_ms = None, float("inf"), None
+    for fam, (kind, geom, run) in enumerate(families):
+        n_cfg = load().ta_ck_instances(kind, geom[5], geom[6], geom[7])
+        if n_cfg <= 0:
+            continue
+        if base_ms is None:
+            torch.cuda.synchronize()
+            base_ms = _time(run_two_kernels)
         for idx in range(n_cfg):
-            if run_fused(idx) != 0:
+            if run(idx) != 0:
                 continue
-            ms = _time(lambda: run_fused(idx))
+            ms = _time(lambda: run(idx))
             if ms < best_ms:
-                best, best_ms = idx, ms
-        if best is not None and best_ms > 0.97 * base_ms:
-            best = None
-        if os.environ.get("TA_CK_DEBUG"):
-            print("ck site %s: two kernels %.1f us, fused %s" % (key, base_ms * 1e3, "none faster" if best is None else "%.1f us (%s)" % (
-                best_ms * 1e3, load().ta_ck_instance_name(kind, geom[5], geom[6], geom[7], best).decode())), file=sys.stderr, flush=True)
+                best, best_ms = (fam, idx), ms
+    if best is not None and best_ms > 0.97 * base_ms:
+        best = None
+    if base_ms is not None and os.environ.get("TA_CK_DEBUG"):
+        name = "none faster" if best is None else "%.1f us (%s, kind %d)" % (
+            best_ms * 1e3, load().ta_ck_instance_name(families[best[0]][0], *families[best[0]][1][5:8], best[1]).decode(), families[best[0]][0])
+        print("ck site %s: two kernels %.1f us, fused %s" % (key, base_ms * 1e3, name), file=sys.stderr, flush=True)
     plans[key] = best
-    stats["tuned_sites"] += 1
+    stats["tuned_sites"] += base_ms is not None
     stats["sites_on_ck"] += best is not None
     return best

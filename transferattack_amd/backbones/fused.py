@@ -51,27 +51,14 @@ def _dense_nhwc(*tensors):
     return all(t is None or (t.is_contiguous(memory_format=_CL) and t.dtype == torch.float32 and t.is_cuda) for t in tensors)
 
 
-def _site(conv, tag, x_shape, kind):
-    """the cached plan of this convolution for this role and input shape: (configuration index | None, geometry, KYXC weight, output
-    height, width) -- or the string "tune" when the site has not been decided yet, or None when the fused form cannot take it"""
+def _site(conv, tag, x_shape):
+    """the cached plan of this convolution for this role and input shape -- a tuple the site unpacks, or None where the two-kernel
+    form runs -- or "new" when the site has not been decided yet"""
     cache = conv.__dict__.get("_ta_ck_sites")
     if cache is None:
         cache = conv.__dict__["_ta_ck_sites"] = {}
     key = (tag, tuple(x_shape), conv.weight._version)
-    plan = cache.get(key, "new")
-    if plan == "new":
-        geom = _ck.geometry(x_shape, conv)
-        if geom is None or _ck.load().ta_ck_instances(kind, geom[5], geom[6], geom[7]) == 0:
-            plan = cache[key] = None
-        else:
-            return "tune", cache, key, geom
-    return plan, cache, key, None
-
-
-def _decide(cache, key, tag, kind, geom, conv, fused, two_kernels):
-    idx = _ck.choose((tag, geom), kind, geom, fused, two_kernels)
-    plan = cache[key] = None if idx is None else (idx, geom, _ck.weight_kyxc(conv)) + _ck.out_hw(geom)
-    return plan
+    return cache.get(key, "new"), cache, key
 
 
 def _site_bias_relu(x, conv, new_bits):
@@ -83,12 +70,16 @@ def _site_bias_relu(x, conv, new_bits):
         return y, m
     if not (_ck.enabled() and _dense_nhwc(x)):
         return two_kernels()
-    plan, cache, key, geom = _site(conv, "bias_relu", x.shape, _ck.FWD_BIAS_RELU)
-    if plan == "tune":
-        w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
-        y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
-        plan = _decide(cache, key, "bias_relu", _ck.FWD_BIAS_RELU, geom, conv,
-                       lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom), two_kernels)
+    plan, cache, key = _site(conv, "bias_relu", x.shape)
+    if plan == "new":
+        geom, plan = _ck.geometry(x.shape, conv), None
+        if geom is not None:
+            w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
+            y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+            run = lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom)      # noqa: E731
+            best = _ck.choose(("bias_relu", geom), [(_ck.FWD_BIAS_RELU, geom, run)], two_kernels)
+            plan = None if best is None else (best[1], geom, w, ho, wo)
+        cache[key] = plan
     if plan is None:
         return two_kernels()
     idx, geom, w, ho, wo = plan
@@ -108,18 +99,19 @@ def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
         return two_kernels()
     kind = _ck.FWD_BIAS_ADD_RELU if bias_other is None else _ck.FWD_BIAS_ADD_BIAS_RELU
     tag = "bias_add_relu" if bias_other is None else "bias_add_bias_relu"
-    plan, cache, key, geom = _site(conv, tag, x.shape, kind)
-    if plan == "tune":
-        w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
-        if tuple(other.shape) != (geom[0], geom[4], ho, wo):
-            plan = cache[key] = None
-        else:
+    plan, cache, key = _site(conv, tag, x.shape)
+    if plan == "new":
+        geom, plan = _ck.geometry(x.shape, conv), None
+        if geom is not None and tuple(other.shape) == (geom[0], geom[4]) + _ck.out_hw(geom):
+            w = _ck.weight_kyxc(conv)
             y = torch.empty_like(other)
-            plan = _decide(cache, key, tag, kind, geom, conv,
-                           lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom), two_kernels)
+            run = lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)      # noqa: E731
+            best = _ck.choose((tag, geom), [(kind, geom, run)], two_kernels)
+            plan = None if best is None else (best[1], geom, w)
+        cache[key] = plan
     if plan is None:
         return two_kernels()
-    idx, geom, w, ho, wo = plan
+    idx, geom, w = plan
     y = torch.empty_like(other)
     _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)
     return y, None
@@ -127,36 +119,61 @@ def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
 
 def _site_input_grad_mask(g, conv, act, bits, other=None, other_is_scratch=False):
     """-> threshold_backward(conv's input gradient of ``g`` [+ other], act, 0): the ReLU in front of ``conv`` (``other``: the second
-    branch of a residual junction).  ``bits``: act's pass bits where the forward left them.  ``other_is_scratch``: nobody reads
-    ``other`` afterwards -- the fused form then writes its result over it (composable_kernel zero-fills the output of a
-    backward-data convolution first unless one of its epilogue operands IS the output: a memset of the whole map saved)."""
+    branch of a residual junction).  ``bits``: act's pass bits where the forward left them.  Fused candidates: composable_kernel's
+    backward-data kernels (1x1 filters), and -- for any stride-1 filter -- its FORWARD kernels on the rewritten problem (the input
+    gradient of a stride-1 convolution is a forward convolution of ``g`` with the flipped, transposed filter).
+    ``other_is_scratch``: nobody reads ``other`` afterwards -- the backward-data form then writes its result over it (CK zero-fills
+    the output of a backward-data convolution first unless one of its epilogue operands IS the output: a memset of the whole map
+    saved)."""
     def two_kernels():
         gx = _like(_conv_input_grad(g, act, conv), act)
         return _hip.relu_mask(gx, act, gx, gb=other, mask=bits)
     if not (_ck.enabled() and _dense_nhwc(g, act, other)):
         return two_kernels()
-    kind = _ck.BWD_MASK if other is None else _ck.BWD_ADD_MASK
     tag = ("input_grad_mask", other is not None, bits is not None)
-    plan, cache, key, geom = _site(conv, tag, act.shape, kind)
-    if plan == "tune":
-        w = _ck.weight_kyxc(conv)
-        # tuned on the form that will run: in place over a scratch copy of the other addend where the caller allows it
-        out = other.clone(memory_format=torch.preserve_format) if (other is not None and other_is_scratch) else torch.empty_like(act)
-        d0, d1 = (act, None) if other is None else ((out if other_is_scratch else other), act)
-        plan = _decide(cache, key, tag, kind, geom, conv, lambda idx: _ck.conv(kind, idx, g, w, d0, d1, None, out, geom), two_kernels)
+    plan, cache, key = _site(conv, tag, act.shape)
+    if plan == "new":
+        geom, plan = _ck.geometry(act.shape, conv), None
+        if geom is not None:
+            families = []
+            # (a) the backward-data kernels, tuned on the form that will run: in place over a scratch copy of the other addend
+            kind_b = _ck.BWD_MASK if other is None else _ck.BWD_ADD_MASK
+            w = _ck.weight_kyxc(conv)
+            out = other.clone(memory_format=torch.preserve_format) if (other is not None and other_is_scratch) else torch.empty_like(act)
+            d0, d1 = (act, None) if other is None else ((out if other_is_scratch else other), act)
+            families.append((kind_b, geom, lambda idx: _ck.conv(kind_b, idx, g, w, d0, d1, None, out, geom)))
+            # (b) the forward kernels on the rewritten problem
+            fgeom = _ck.backward_as_forward(geom)
+            if fgeom is not None:
+                kind_f = _ck.FWD_MASK if other is None else _ck.FWD_ADD_MASK
+                wt = _ck.weight_flipped_cyxk(conv)
+                out_f = torch.empty_like(act)
+                e0, e1 = (act, None) if other is None else (other, act)
+                families.append((kind_f, fgeom, lambda idx: _ck.conv(kind_f, idx, g, wt, e0, e1, None, out_f, fgeom)))
+            best = _ck.choose((tag, geom), families, two_kernels)
+            if best is not None:
+                fam, idx = best
+                plan = ("bwd", idx, geom, w) if fam == 0 else ("fwd", idx, fgeom, wt)
+        cache[key] = plan
     if plan is None:
         return two_kernels()
-    idx, geom, w, _, _ = plan
-    if other is None:
+    form, idx, geom, w = plan
+    if form == "fwd":
         gx = torch.empty_like(act)
-        _ck.conv(kind, idx, g, w, act, None, None, gx, geom)
+        if other is None:
+            _ck.conv(_ck.FWD_MASK, idx, g, w, act, None, None, gx, geom)
+        else:
+            _ck.conv(_ck.FWD_ADD_MASK, idx, g, w, other, act, None, gx, geom)
+    elif other is None:
+        gx = torch.empty_like(act)
+        _ck.conv(_ck.BWD_MASK, idx, g, w, act, None, None, gx, geom)
     elif other_is_scratch:
         gx = other
-        _ck.conv(kind, idx, g, w, other, act, None, other, geom)
+        _ck.conv(_ck.BWD_ADD_MASK, idx, g, w, other, act, None, other, geom)
         _hip.invalidate_partials(other)
     else:
         gx = torch.empty_like(act)
-        _ck.conv(kind, idx, g, w, other, act, None, gx, geom)
+        _ck.conv(_ck.BWD_ADD_MASK, idx, g, w, other, act, None, gx, geom)
     return gx
 
 

@@ -29,6 +29,8 @@ static A5 bias_str(const Geom& g) { return {g.k, 0, 1, 0, 0}; }
 static std::vector<std::unique_ptr<FwdBias>> r_fwd_bias_any, r_fwd_bias_1x1;
 static std::vector<std::unique_ptr<FwdBiasAdd>> r_fwd_bias_add_1x1;
 static std::vector<std::unique_ptr<FwdBiasAddBias>> r_fwd_bias_add_bias_1x1;
+static std::vector<std::unique_ptr<FwdMask>> r_fwd_mask_any, r_fwd_mask_1x1;
+static std::vector<std::unique_ptr<FwdAddMask>> r_fwd_add_mask_any, r_fwd_add_mask_1x1;
 static std::vector<std::unique_ptr<BwdMask>> r_bwd_mask_1x1;
 static std::vector<std::unique_ptr<BwdAddMask>> r_bwd_add_mask_1x1;
 static std::once_flag g_once;
@@ -39,6 +41,10 @@ static void fill() {
         add_fwd_bias_1x1(r_fwd_bias_1x1);
         add_fwd_bias_add_1x1(r_fwd_bias_add_1x1);
         add_fwd_bias_add_bias_1x1(r_fwd_bias_add_bias_1x1);
+        add_fwd_mask_any(r_fwd_mask_any);
+        add_fwd_mask_1x1(r_fwd_mask_1x1);
+        add_fwd_add_mask_any(r_fwd_add_mask_any);
+        add_fwd_add_mask_1x1(r_fwd_add_mask_1x1);
         add_bwd_mask_1x1(r_bwd_mask_1x1);
         add_bwd_add_mask_1x1(r_bwd_add_mask_1x1);
     });
@@ -65,6 +71,8 @@ template <typename F> static int with_registry(int kind, int ksize, int stride, 
     case TA_CK_FWD_BIAS_RELU: return one ? f(r_fwd_bias_1x1) : f(r_fwd_bias_any);
     case TA_CK_FWD_BIAS_ADD_RELU: return one ? f(r_fwd_bias_add_1x1) : 0;
     case TA_CK_FWD_BIAS_ADD_BIAS_RELU: return one ? f(r_fwd_bias_add_bias_1x1) : 0;
+    case TA_CK_FWD_MASK: return one ? f(r_fwd_mask_1x1) : f(r_fwd_mask_any);
+    case TA_CK_FWD_ADD_MASK: return one ? f(r_fwd_add_mask_1x1) : f(r_fwd_add_mask_any);
     case TA_CK_BWD_MASK: return one ? f(r_bwd_mask_1x1) : 0;
     case TA_CK_BWD_ADD_MASK: return one ? f(r_bwd_add_mask_1x1) : 0;
     }
@@ -123,6 +131,20 @@ extern "C" int ta_ck_conv(int kind, int index, const float* a, const float* w, c
         auto arg = op.MakeArgumentPointer(a, w, {d0, d1, d2}, e, in_len(g), in_str(g), w_len(g), w_str(g), {out_len(g), out_len(g), out_len(g)},
                                           {bias_str(g), out_str(g), bias_str(g)}, out_len(g), out_str(g), st, dil, pl, pr, PassThrough{},
                                           PassThrough{}, BiasAddBiasRelu{});
+        return launch(op, arg, stream);
+    }
+    case TA_CK_FWD_MASK: {
+        auto& op = *(one ? r_fwd_mask_1x1 : r_fwd_mask_any)[index];
+        auto arg = op.MakeArgumentPointer(a, w, {d0}, e, in_len(g), in_str(g), w_len(g), w_str(g), {out_len(g)}, {out_str(g)}, out_len(g),
+                                          out_str(g), st, dil, pl, pr, PassThrough{}, PassThrough{}, Mask{});
+        return launch(op, arg, stream);
+    }
+    case TA_CK_FWD_ADD_MASK: {
+        if (!d1) return fail("the activation is missing");
+        auto& op = *(one ? r_fwd_add_mask_1x1 : r_fwd_add_mask_any)[index];
+        auto arg = op.MakeArgumentPointer(a, w, {d0, d1}, e, in_len(g), in_str(g), w_len(g), w_str(g), {out_len(g), out_len(g)},
+                                          {out_str(g), out_str(g)}, out_len(g), out_str(g), st, dil, pl, pr, PassThrough{}, PassThrough{},
+                                          AddMask{});
         return launch(op, arg, stream);
     }
     case TA_CK_BWD_MASK: {

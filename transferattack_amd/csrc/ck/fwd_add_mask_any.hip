@@ -1,0 +1,4 @@
+#include "fwd_instances.h"
+namespace ta_ck {
+void add_fwd_add_mask_any(std::vector<std::unique_ptr<FwdAddMask>>& v) { add_fwd<ck::Tuple<NHWGK, NHWGK>, ck::Tuple<F32, F32>, AddMask, ConvolutionForwardSpecialization::Default, FwdAddMask>(v); }
+}

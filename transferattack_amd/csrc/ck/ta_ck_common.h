@@ -62,6 +62,10 @@ using FwdBase = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD<2,
 using FwdBias = FwdBase<ck::Tuple<G_K>, ck::Tuple<F32>, BiasRelu>;
 using FwdBiasAdd = FwdBase<ck::Tuple<G_K, NHWGK>, ck::Tuple<F32, F32>, BiasAddRelu>;
 using FwdBiasAddBias = FwdBase<ck::Tuple<G_K, NHWGK, G_K>, ck::Tuple<F32, F32, F32>, BiasAddBiasRelu>;
+// a stride-1 convolution's input gradient as a FORWARD convolution of the output gradient with the flipped, transposed filter:
+// the forward kernels with the backward glue as epilogue (their D operands have the layout of this "forward" output)
+using FwdMask = FwdBase<ck::Tuple<NHWGK>, ck::Tuple<F32>, Mask>;
+using FwdAddMask = FwdBase<ck::Tuple<NHWGK, NHWGK>, ck::Tuple<F32, F32>, AddMask>;
 // backward data: A = output gradient (NHWGK), B = weight (GKYXC), E = input gradient (NHWGC)
 template <typename DsLayout, typename DsData, typename Op>
 using BwdBase = ck::tensor_operation::device::DeviceGroupedConvBwdDataMultipleD<2, NHWGK, GKYXC, DsLayout, NHWGC, F32, F32, DsData, F32,
@@ -74,6 +78,10 @@ void add_fwd_bias_any(std::vector<std::unique_ptr<FwdBias>>& v);              //
 void add_fwd_bias_1x1(std::vector<std::unique_ptr<FwdBias>>& v);              // 1x1 / stride 1 / no padding
 void add_fwd_bias_add_1x1(std::vector<std::unique_ptr<FwdBiasAdd>>& v);
 void add_fwd_bias_add_bias_1x1(std::vector<std::unique_ptr<FwdBiasAddBias>>& v);
+void add_fwd_mask_any(std::vector<std::unique_ptr<FwdMask>>& v);
+void add_fwd_mask_1x1(std::vector<std::unique_ptr<FwdMask>>& v);
+void add_fwd_add_mask_any(std::vector<std::unique_ptr<FwdAddMask>>& v);
+void add_fwd_add_mask_1x1(std::vector<std::unique_ptr<FwdAddMask>>& v);
 void add_bwd_mask_1x1(std::vector<std::unique_ptr<BwdMask>>& v);
 void add_bwd_add_mask_1x1(std::vector<std::unique_ptr<BwdAddMask>>& v);
 }  // namespace ta_ck
