@@ -182,13 +182,13 @@ def test_ck_abi_symbols_exported():
     assert declared == set(_ck.SIGNATURES), declared ^ set(_ck.SIGNATURES)
     assert lib.ta_ck_abi_version() == _ck.ABI_VERSION == 2
     assert lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 3, 1, 1) >= 8 and lib.ta_ck_instances(_ck.FWD_BIAS_RELU, 1, 1, 0) >= 8
-    for kind in (_ck.FWD_BIAS_ADD_RELU, _ck.FWD_BIAS_ADD_BIAS_RELU, _ck.BWD_MASK, _ck.BWD_ADD_MASK):
+    for kind in (_ck.FWD_BIAS_ADD_RELU, _ck.FWD_BIAS_ADD_BIAS_RELU):
         assert lib.ta_ck_instances(kind, 1, 1, 0) >= 6 and lib.ta_ck_instances(kind, 3, 1, 1) == 0
     for kind in (_ck.FWD_MASK, _ck.FWD_ADD_MASK):                  # the backward glue on the forward kernels: any filter
         assert lib.ta_ck_instances(kind, 1, 1, 0) >= 8 and lib.ta_ck_instances(kind, 3, 1, 1) >= 8
     assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 1, 1)) == (4, 128, 56, 56, 64, 3, 1, 1)
     assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 2, 1)) is None
-    assert b"Xdl_CShuffle" in lib.ta_ck_instance_name(_ck.BWD_ADD_MASK, 1, 1, 0, 0)
+    assert b"Xdl_CShuffle" in lib.ta_ck_instance_name(_ck.FWD_ADD_MASK, 1, 1, 0, 0)
     assert lib.ta_ck_conv(_ck.FWD_BIAS_RELU, 0, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, None) == -1       # TA_CK_EINVAL
     assert b"null" in lib.ta_ck_last_error()
 

@@ -4,7 +4,9 @@ the convolution's epilogue -- composable_kernel instances, the library kernels M
 Opt-in (``TA_CK_EPILOGUE=1``; ``bench.py`` switches it on and says so) and used by ``backbones/fused.py`` only.  Per
 (epilogue, shape) the first call times the two-kernel form it would replace -- MIOpen's convolution + the glue kernel of
 libta_hip.so -- against every tile configuration of the fused form and keeps the faster (``choose``): a layer for which MIOpen's
-assembly kernels win stays on them (the 3 x 3 backward-data layers do, profiles/r06/ck_conv_probe_b125_r6b.json).  Like MIOpen's
+assembly kernels win stays on them (a few 3 x 3 layers of the deep stages do, profiles/r06/ck_site_decisions_b125_r6h.txt).
+Backward sites run the FORWARD kernels on the rewritten problem (``backward_as_forward``): composable_kernel's own backward-data
+kernels lost at every site (and zero-fill their output first).  Like MIOpen's
 find mode this makes the choice of kernel, hence the last bits of an activation, a property of the process: under
 ``TA_DETERMINISTIC=1`` the path is off.  No fallback inside: a missing library raises when the path is asked for.
 """
@@ -20,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TA_CK_LIB", os.path.join(_HERE, "lib", "libta_ck.so"))
 ABI_VERSION = 2
 
-FWD_BIAS_RELU, FWD_BIAS_ADD_RELU, FWD_BIAS_ADD_BIAS_RELU, BWD_MASK, BWD_ADD_MASK, FWD_MASK, FWD_ADD_MASK = 1, 2, 3, 4, 5, 6, 7
+FWD_BIAS_RELU, FWD_BIAS_ADD_RELU, FWD_BIAS_ADD_BIAS_RELU, FWD_MASK, FWD_ADD_MASK = 1, 2, 3, 4, 5
 UNSUPPORTED = 1
 
 _int, _vp = ctypes.c_int, ctypes.c_void_p
@@ -148,8 +150,7 @@ def backward_as_forward(geom):
 
 def choose(key, families, run_two_kernels):
     """-> (family, configuration index) of the fastest fused form for this site, or None where the two-kernel form is at least as
-    fast.  ``families``: [(kind, geometry, run(index) -> rc)] -- e.g. the backward-data kernels and the forward kernels on the
-    rewritten problem.  Decided once per key by timing all of them on the caller's own tensors (none may modify its inputs); a
+    fast.  ``families``: [(kind, geometry, run(index) -> rc)] -- alternative kernel families for one site.  Decided once per key by timing all of them on the caller's own tensors (none may modify its inputs); a
     fused form must win by 3 % to be taken."""
     if key in plans:
         return plans[key]

@@ -117,63 +117,37 @@ def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
     return y, None
 
 
-def _site_input_grad_mask(g, conv, act, bits, other=None, other_is_scratch=False):
+def _site_input_grad_mask(g, conv, act, bits, other=None):
     """-> threshold_backward(conv's input gradient of ``g`` [+ other], act, 0): the ReLU in front of ``conv`` (``other``: the second
-    branch of a residual junction).  ``bits``: act's pass bits where the forward left them.  Fused candidates: composable_kernel's
-    backward-data kernels (1x1 filters), and -- for any stride-1 filter -- its FORWARD kernels on the rewritten problem (the input
-    gradient of a stride-1 convolution is a forward convolution of ``g`` with the flipped, transposed filter).
-    ``other_is_scratch``: nobody reads ``other`` afterwards -- the backward-data form then writes its result over it (CK zero-fills
-    the output of a backward-data convolution first unless one of its epilogue operands IS the output: a memset of the whole map
-    saved)."""
+    branch of a residual junction).  ``bits``: act's pass bits where the forward left them.  The fused form, for any stride-1
+    filter: composable_kernel's FORWARD kernel on the rewritten problem -- the input gradient of a stride-1 convolution is a forward
+    convolution of ``g`` with the flipped, transposed filter -- with the threshold (and the junction add) as its epilogue."""
     def two_kernels():
         gx = _like(_conv_input_grad(g, act, conv), act)
         return _hip.relu_mask(gx, act, gx, gb=other, mask=bits)
     if not (_ck.enabled() and _dense_nhwc(g, act, other)):
         return two_kernels()
     tag = ("input_grad_mask", other is not None, bits is not None)
+    kind = _ck.FWD_MASK if other is None else _ck.FWD_ADD_MASK
     plan, cache, key = _site(conv, tag, act.shape)
     if plan == "new":
         geom, plan = _ck.geometry(act.shape, conv), None
-        if geom is not None:
-            families = []
-            # (a) the backward-data kernels, tuned on the form that will run: in place over a scratch copy of the other addend
-            kind_b = _ck.BWD_MASK if other is None else _ck.BWD_ADD_MASK
-            w = _ck.weight_kyxc(conv)
-            out = other.clone(memory_format=torch.preserve_format) if (other is not None and other_is_scratch) else torch.empty_like(act)
-            d0, d1 = (act, None) if other is None else ((out if other_is_scratch else other), act)
-            families.append((kind_b, geom, lambda idx: _ck.conv(kind_b, idx, g, w, d0, d1, None, out, geom)))
-            # (b) the forward kernels on the rewritten problem
-            fgeom = _ck.backward_as_forward(geom)
-            if fgeom is not None:
-                kind_f = _ck.FWD_MASK if other is None else _ck.FWD_ADD_MASK
-                wt = _ck.weight_flipped_cyxk(conv)
-                out_f = torch.empty_like(act)
-                e0, e1 = (act, None) if other is None else (other, act)
-                families.append((kind_f, fgeom, lambda idx: _ck.conv(kind_f, idx, g, wt, e0, e1, None, out_f, fgeom)))
-            best = _ck.choose((tag, geom), families, two_kernels)
-            if best is not None:
-                fam, idx = best
-                plan = ("bwd", idx, geom, w) if fam == 0 else ("fwd", idx, fgeom, wt)
+        fgeom = None if geom is None else _ck.backward_as_forward(geom)
+        if fgeom is not None:
+            wt = _ck.weight_flipped_cyxk(conv)
+            out = torch.empty_like(act)
+            d0, d1 = (act, None) if other is None else (other, act)
+            best = _ck.choose((tag, geom), [(kind, fgeom, lambda idx: _ck.conv(kind, idx, g, wt, d0, d1, None, out, fgeom))], two_kernels)
+            plan = None if best is None else (best[1], fgeom, wt)
         cache[key] = plan
     if plan is None:
         return two_kernels()
-    form, idx, geom, w = plan
-    if form == "fwd":
-        gx = torch.empty_like(act)
-        if other is None:
-            _ck.conv(_ck.FWD_MASK, idx, g, w, act, None, None, gx, geom)
-        else:
-            _ck.conv(_ck.FWD_ADD_MASK, idx, g, w, other, act, None, gx, geom)
-    elif other is None:
-        gx = torch.empty_like(act)
-        _ck.conv(_ck.BWD_MASK, idx, g, w, act, None, None, gx, geom)
-    elif other_is_scratch:
-        gx = other
-        _ck.conv(_ck.BWD_ADD_MASK, idx, g, w, other, act, None, other, geom)
-        _hip.invalidate_partials(other)
+    idx, fgeom, wt = plan
+    gx = torch.empty_like(act)
+    if other is None:
+        _ck.conv(kind, idx, g, wt, act, None, None, gx, fgeom)
     else:
-        gx = torch.empty_like(act)
-        _ck.conv(_ck.BWD_ADD_MASK, idx, g, w, other, act, None, gx, geom)
+        _ck.conv(kind, idx, g, wt, other, act, None, gx, fgeom)
     return gx
 
 
@@ -327,8 +301,7 @@ class _ResNetFn(torch.autograd.Function):
                 ga_ = _site_input_grad_mask(gm, blk.conv2, a, ma)
             g_skip = gm if blk.downsample is None else _like(_conv_input_grad(gm, x_in, blk.downsample[0]), x_in)
             if i > 0:
-                # (g_skip -- this block's gm, or the projection's fresh input gradient -- has no reader after this junction)
-                gm = _site_input_grad_mask(ga_, blk.conv1, x_in, masks[i - 1][2], other=g_skip, other_is_scratch=True)
+                gm = _site_input_grad_mask(ga_, blk.conv1, x_in, masks[i - 1][2], other=g_skip)
             else:                                                              # the pooled map has no ReLU of its own: the junction
                 g, pending = _like(_conv_input_grad(ga_, x_in, blk.conv1), x_in), g_skip      # is summed by the max-pool backward
         # the stem's ReLU sits before the max-pool: junction add + max-pool backward + threshold

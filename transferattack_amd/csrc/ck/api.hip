@@ -31,8 +31,6 @@ static std::vector<std::unique_ptr<FwdBiasAdd>> r_fwd_bias_add_1x1;
 static std::vector<std::unique_ptr<FwdBiasAddBias>> r_fwd_bias_add_bias_1x1;
 static std::vector<std::unique_ptr<FwdMask>> r_fwd_mask_any, r_fwd_mask_1x1;
 static std::vector<std::unique_ptr<FwdAddMask>> r_fwd_add_mask_any, r_fwd_add_mask_1x1;
-static std::vector<std::unique_ptr<BwdMask>> r_bwd_mask_1x1;
-static std::vector<std::unique_ptr<BwdAddMask>> r_bwd_add_mask_1x1;
 static std::once_flag g_once;
 
 static void fill() {
@@ -45,8 +43,6 @@ static void fill() {
         add_fwd_mask_1x1(r_fwd_mask_1x1);
         add_fwd_add_mask_any(r_fwd_add_mask_any);
         add_fwd_add_mask_1x1(r_fwd_add_mask_1x1);
-        add_bwd_mask_1x1(r_bwd_mask_1x1);
-        add_bwd_add_mask_1x1(r_bwd_add_mask_1x1);
     });
 }
 
@@ -73,8 +69,6 @@ template <typename F> static int with_registry(int kind, int ksize, int stride, 
     case TA_CK_FWD_BIAS_ADD_BIAS_RELU: return one ? f(r_fwd_bias_add_bias_1x1) : 0;
     case TA_CK_FWD_MASK: return one ? f(r_fwd_mask_1x1) : f(r_fwd_mask_any);
     case TA_CK_FWD_ADD_MASK: return one ? f(r_fwd_add_mask_1x1) : f(r_fwd_add_mask_any);
-    case TA_CK_BWD_MASK: return one ? f(r_bwd_mask_1x1) : 0;
-    case TA_CK_BWD_ADD_MASK: return one ? f(r_bwd_add_mask_1x1) : 0;
     }
     return 0;
 }
@@ -145,19 +139,6 @@ extern "C" int ta_ck_conv(int kind, int index, const float* a, const float* w, c
         auto arg = op.MakeArgumentPointer(a, w, {d0, d1}, e, in_len(g), in_str(g), w_len(g), w_str(g), {out_len(g), out_len(g)},
                                           {out_str(g), out_str(g)}, out_len(g), out_str(g), st, dil, pl, pr, PassThrough{}, PassThrough{},
                                           AddMask{});
-        return launch(op, arg, stream);
-    }
-    case TA_CK_BWD_MASK: {
-        auto& op = *r_bwd_mask_1x1[index];
-        auto arg = op.MakeArgumentPointer(a, w, {d0}, e, out_len(g), out_str(g), w_len(g), w_str(g), {in_len(g)}, {in_str(g)}, in_len(g),
-                                          in_str(g), st, dil, pl, pr, PassThrough{}, PassThrough{}, Mask{});
-        return launch(op, arg, stream);
-    }
-    case TA_CK_BWD_ADD_MASK: {
-        if (!d1) return fail("the activation is missing");
-        auto& op = *r_bwd_add_mask_1x1[index];
-        auto arg = op.MakeArgumentPointer(a, w, {d0, d1}, e, out_len(g), out_str(g), w_len(g), w_str(g), {in_len(g), in_len(g)},
-                                          {in_str(g), in_str(g)}, in_len(g), in_str(g), st, dil, pl, pr, PassThrough{}, PassThrough{}, AddMask{});
         return launch(op, arg, stream);
     }
     }

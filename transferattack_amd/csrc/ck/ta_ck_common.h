@@ -10,7 +10,6 @@
 #include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
 #include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
 #include "ck/tensor_operation/gpu/device/device_grouped_conv_fwd_multiple_abd.hpp"
-#include "ck/tensor_operation/gpu/device/device_grouped_conv_bwd_data_multiple_d.hpp"
 #include "ck/library/tensor_operation_instance/add_device_operation_instance.hpp"
 #include "../../../include/ta_ck.h"
 
@@ -66,13 +65,6 @@ using FwdBiasAddBias = FwdBase<ck::Tuple<G_K, NHWGK, G_K>, ck::Tuple<F32, F32, F
 // the forward kernels with the backward glue as epilogue (their D operands have the layout of this "forward" output)
 using FwdMask = FwdBase<ck::Tuple<NHWGK>, ck::Tuple<F32>, Mask>;
 using FwdAddMask = FwdBase<ck::Tuple<NHWGK, NHWGK>, ck::Tuple<F32, F32>, AddMask>;
-// backward data: A = output gradient (NHWGK), B = weight (GKYXC), E = input gradient (NHWGC)
-template <typename DsLayout, typename DsData, typename Op>
-using BwdBase = ck::tensor_operation::device::DeviceGroupedConvBwdDataMultipleD<2, NHWGK, GKYXC, DsLayout, NHWGC, F32, F32, DsData, F32,
-                                                                              PassThrough, PassThrough, Op>;
-using BwdMask = BwdBase<ck::Tuple<NHWGC>, ck::Tuple<F32>, Mask>;
-using BwdAddMask = BwdBase<ck::Tuple<NHWGC, NHWGC>, ck::Tuple<F32, F32>, AddMask>;
-
 // one translation unit each (the instantiation of ~12 kernels takes a minute):
 void add_fwd_bias_any(std::vector<std::unique_ptr<FwdBias>>& v);              // any filter
 void add_fwd_bias_1x1(std::vector<std::unique_ptr<FwdBias>>& v);              // 1x1 / stride 1 / no padding
@@ -82,6 +74,4 @@ void add_fwd_mask_any(std::vector<std::unique_ptr<FwdMask>>& v);
 void add_fwd_mask_1x1(std::vector<std::unique_ptr<FwdMask>>& v);
 void add_fwd_add_mask_any(std::vector<std::unique_ptr<FwdAddMask>>& v);
 void add_fwd_add_mask_1x1(std::vector<std::unique_ptr<FwdAddMask>>& v);
-void add_bwd_mask_1x1(std::vector<std::unique_ptr<BwdMask>>& v);
-void add_bwd_add_mask_1x1(std::vector<std::unique_ptr<BwdAddMask>>& v);
 }  // namespace ta_ck
