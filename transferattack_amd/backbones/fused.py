@@ -88,6 +88,44 @@ def _site_bias_relu(x, conv, new_bits):
     return y, None
 
 
+def _site_stem_bias_relu(x, conv):
+    """-> clamp_min(conv(x) + bias, 0) for the stem (a few input channels: 3).  composable_kernel's vector loads run along the
+    channels, so its form of this site pads the image to 4 channels (one torch pass, 75 -> 100 MB at batch 125) and the filter
+    with an all-zero fourth input plane: the products with it are exact zeros, the sum is unchanged.  Against MIOpen's
+    zero fill + 3-channel convolution + ta_bias_act: 568 -> 377 + ~50 us at batch 125 (profiles/r06/ck_stem_forward_probe_r6k.txt)."""
+    def two_kernels():
+        return _hip.bias_act_(_conv(x, conv), conv.bias)
+    cin = conv.weight.shape[1]
+    if not (_ck.enabled() and _dense_nhwc(x)) or cin % 4 == 0 or cin > 3:
+        return two_kernels()
+    plan, cache, key = _site(conv, "stem_bias_relu", x.shape)
+
+    def padded():
+        return torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 4 - cin))            # [n, h, w, 4], dense
+
+    if plan == "new":
+        geom3, plan = _ck.geometry(x.shape, conv), None
+        if geom3 is not None:
+            geom = (geom3[0], 4) + geom3[2:]
+            w4 = torch.nn.functional.pad(_ck.weight_kyxc(conv), (0, 4 - cin)).contiguous()
+            ho, wo = _ck.out_hw(geom)
+            y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+            x4 = padded()
+
+            def run_with_pad(idx):            # what will run: the padding pass + the convolution
+                return _ck.conv(_ck.FWD_BIAS_RELU, idx, padded(), w4, conv.bias, None, None, y, geom)
+            best = _ck.choose(("stem_bias_relu", geom), [(_ck.FWD_BIAS_RELU, geom, run_with_pad)], two_kernels)
+            del x4
+            plan = None if best is None else (best[1], geom, w4, ho, wo)
+        cache[key] = plan
+    if plan is None:
+        return two_kernels()
+    idx, geom, w4, ho, wo = plan
+    y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+    _ck.conv(_ck.FWD_BIAS_RELU, idx, padded(), w4, conv.bias, None, None, y, geom)
+    return y
+
+
 def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
     """-> (clamp_min((conv(x) + bias) + (other [+ bias_other]), 0), pass bits | None): a block's last convolution, its shortcut, its ReLU"""
     def two_kernels():
@@ -236,7 +274,7 @@ class _ResNetFn(torch.autograd.Function):
         # leaves that bit, the backward glue reads 1 bit instead of 4 bytes per element (TA_RELU_BITS=0: the activations)
         bits = os.environ.get("TA_RELU_BITS", "1") != "0"
         new_bits = (lambda t: _hip.pass_bits_like(t)) if bits else (lambda t: None)
-        stem = _hip.bias_act_(_conv(x, net.conv1), net.conv1.bias)
+        stem = _site_stem_bias_relu(x, net.conv1)
         pooled, idx = F.max_pool2d(stem, net.maxpool.kernel_size, net.maxpool.stride, net.maxpool.padding, return_indices=True)
         saved, masks, cur = [], [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
