@@ -34,6 +34,7 @@ def pytest_configure(config):
 # whole surrogates on the device (MIOpen algorithm choice, atomics: run-to-run noise) last, statistics (ASR) at the very end.
 _GPU_TIERS = (
     ("test_hip_kernels.py", None, 0),
+    ("test_hip_ck.py", None, 0),
     ("test_hip_configs.py", ("kernel_on_device",), 0),
     ("test_zz_hip_widened.py", ("kernels", "plane_groups", "properties", "full_size", "spectrum", "largest_ratio",
                                 "registry_rules", "reference_sum_order"), 0),

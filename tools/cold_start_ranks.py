@@ -11,6 +11,7 @@ concerned, and prints one JSON line per run:
     one:warm   one process on the databases ``one`` left          warm(1)
     staged     two ranks, rank 0 warms up first (the default)     expected ~ cold(1) + warm(1)
     together   two ranks, TA_BENCH_STAGED_WARMUP=0                 two contending cold starts
+    staged8    EIGHT ranks on the one device, rank 0 first         the launch the driver's 8-GPU run makes, minus RCCL
 
     python tools/cold_start_ranks.py [--runs one,one:warm,staged,together] [--batch 125]
 """
@@ -64,9 +65,10 @@ def main():
         dbs = os.path.join(args.root, "db_" + name)
         if not warm:
             shutil.rmtree(dbs, ignore_errors=True)
-        ranks = 1 if name == "one" else 2
+        ranks = 1 if name == "one" else (8 if name == "staged8" else 2)
         extra = {"TA_BENCH_STAGED_WARMUP": "0"} if name == "together" else {}
         tag = {"one": "one process", "staged": "two ranks on one device, rank 0 warms up first",
+               "staged8": "eight ranks on one device, rank 0 warms up first",
                "together": "two ranks on one device, both start cold together"}[name]
         tag += ", on the databases the previous run left" if warm else ", fresh MIOpen databases"
         print(json.dumps(run(tag, ranks, dbs, extra, args)), flush=True)

@@ -24,10 +24,6 @@ newtests6)
 coldranks)
   # bench.py --gpus 2 on ONE device with fresh MIOpen databases: rank 0 warms up first vs both together (tools/cold_start_ranks.py)
   timeout 2400 python tools/cold_start_ranks.py --runs ${TA_COLD_RUNS:-one,one:warm,staged,together} 2> $OUT/cold_start_ranks.err | tee $OUT/cold_start_ranks.jsonl ;;
-ckprobe)
-  # review r5 item 4: MIOpen convolution + glue kernel vs composable_kernel instances with the glue as epilogue (tools/ck_probe)
-  [ -f tools/bin/libck_probe.so ] || bash tools/ck_probe/build.sh > $OUT/ck_probe_build.log 2>&1
-  timeout 1500 python tools/ck_conv_probe.py --json $OUT/ck_conv_probe.json 2> $OUT/ck_conv_probe.err | tee $OUT/ck_conv_probe.jsonl | cut -c1-600 ;;
 stem)
   timeout 300 python tools/stem_microbench.py 2>&1 | tee $OUT/stem_microbench.txt ;;
 asrlong)

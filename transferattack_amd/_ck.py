@@ -66,11 +66,6 @@ def load():
     return lib
 
 
-def nhwc(t):
-    """is ``t`` ([n, c, h, w]) dense NHWC memory?"""
-    return t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda and t.permute(0, 2, 3, 1).is_contiguous()
-
-
 def weight_kyxc(conv):
     """the convolution's weight as dense [k, y, x, c] memory, cached on the module (frozen weights: built once)"""
     w = conv.weight
