@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 11
+#define TA_ABI_VERSION 12
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -278,6 +278,11 @@ int ta_stem7s2_prepare(const float* w, float* w2, void* stream);
  * workgroup, ta_stem_tiles consecutive per image, fixed order -- the layout ta_mi_update_std takes through `ws_slots` */
 int64_t ta_stem_tiles(int oh, int ow);
 int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh, int ow,
+                          void* stream);
+/* the same for dy in NCHW memory [n, 64, oh, ow] -- what autograd hands over on the plain module path of an NCHW surrogate
+ * (the reference-literal arrangement): only the staging of the dy window differs, same MFMA schedule, same bits as the
+ * channels_last form on the same values */
+int ta_stem7s2_input_grad_nchw(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh, int ow,
                           void* stream);
 
 /* ---- output: save_images  transferattack/utils.py:63-66 (+ main.py:53 add) ---------------------------

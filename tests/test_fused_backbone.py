@@ -79,6 +79,24 @@ def test_stem_input_grad_kernel(monkeypatch, n, oh, ow):
     err_got, err_ref = float((got.double() - truth).abs().max()) / scale, float((ref32.double() - truth).abs().max()) / scale
     assert not torch.isnan(got).any()
     assert err_got <= max(4 * err_ref, 2e-6), (err_got, err_ref)
+    # dy in NCHW memory (the plain module path of an NCHW surrogate): other staging loads, same schedule -> the SAME bits, also
+    # with the |dx / std| sums; and through the module path's autograd node
+    std = torch.tensor([0.229, 0.224, 0.225])
+    got_nchw = _hip.stem7s2_input_grad(dy.contiguous(), _hip.stem7s2_prepare(w), torch.full_like(x_like, float("nan")), std=std)
+    assert torch.equal(got_nchw, got)
+    got_cl = _hip.stem7s2_input_grad(dy, _hip.stem7s2_prepare(w), torch.full_like(x_like, float("nan")), std=std)
+    sums_a, sums_b = _hip.partials_of(got_nchw), _hip.partials_of(got_cl)
+    assert sums_a[1] == sums_b[1] and torch.equal(sums_a[0], sums_b[0])
+    from transferattack_amd.backbones import fused, resnet
+    net = resnet.resnet18().eval()
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    with torch.no_grad():
+        net.conv1.weight.copy_(w)
+    x = torch.randn(n, 3, 2 * oh, 2 * ow, generator=gen).requires_grad_(True)
+    y = fused._StemConvFn.apply(x, net, None)
+    assert torch.equal(y, net.conv1(x))
+    assert torch.equal(torch.autograd.grad(y, x, dy.contiguous())[0], got)
 
 
 @pytest.mark.parametrize("shape,k,s,p", [((2, 8, 16, 16), 3, 2, 1), ((1, 4, 9, 13), 3, 2, 1), ((2, 8, 12, 12), 2, 2, 0), ((1, 4, 11, 7), 3, 1, 1)])

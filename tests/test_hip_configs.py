@@ -360,6 +360,9 @@ def test_stem_input_grad_kernel_on_device(n, oh, ow):
         print("  first offenders (n, c, y, x):", idx)
     assert not torch.isnan(got).any() and torch.equal(got, again)
     assert e_got <= max(4 * e_ref, 2e-6)
+    # dy in NCHW memory (the module path of the reference-literal arrangement): the same bits
+    nchw = _hip.stem7s2_input_grad(dy.to(DEV).contiguous(), _hip.stem7s2_prepare(wd), torch.full_like(xd, float("nan"))).cpu().double()
+    assert torch.equal(nchw, got)
 
 
 @pytest.mark.parametrize("shape,k,s,p", [((4, 64, 112, 112), 3, 2, 1), ((2, 8, 9, 13), 3, 2, 1), ((2, 16, 12, 12), 2, 2, 0)])

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ta_dim_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp]),
     "ta_stem7s2_prepare": (_int, [_vp, _vp, _vp]),
     "ta_stem7s2_input_grad": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "ta_stem7s2_input_grad_nchw": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "ta_bias_act": (_int, [_vp, _vp, _int, _vp, _i64, _int, _i64, _vp]),
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -83,7 +84,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class HipExtensionError(RuntimeError):
@@ -761,21 +762,24 @@ def stem7s2_prepare(weight):
 
 def stem7s2_input_grad(dy, w2, dx, std=None):
     """dx [n, 3, 2*oh, 2*ow] (NCHW) = d/d(input) of the 7x7 / stride 2 / padding 3 stem convolution for the output gradient
-    ``dy`` [n, 64, oh, ow] in channels_last memory.  ``std`` (fp32 [3], optional): the consumer will divide dx by std[c]
-    (``mi_update(..., std=std)``) -- the kernel then also leaves the sums of |dx / std[c]| per workgroup and they are attached
-    to ``dx`` as its partials, so the update reads dx exactly once and nothing else does."""
+    ``dy`` [n, 64, oh, ow] in channels_last memory or -- the plain module path of an NCHW surrogate -- in NCHW memory.  ``std`` (fp32
+    [3], optional): the consumer will divide dx by std[c] (``mi_update(..., std=std)``) -- the kernel then also leaves the sums of
+    |dx / std[c]| per workgroup and they are attached to ``dx`` as its partials, so the update reads dx exactly once and nothing
+    else does."""
     n, k, oh, ow = dy.shape
-    if k != 64 or not dy.is_contiguous(memory_format=torch.channels_last) or tuple(dx.shape) != (n, 3, 2 * oh, 2 * ow):
-        raise ValueError("stem7s2_input_grad: dy must be channels_last [n, 64, oh, ow] and dx [n, 3, 2*oh, 2*ow]")
+    nchw = dy.is_contiguous()
+    if k != 64 or not (nchw or dy.is_contiguous(memory_format=torch.channels_last)) or tuple(dx.shape) != (n, 3, 2 * oh, 2 * ow):
+        raise ValueError("stem7s2_input_grad: dy must be dense [n, 64, oh, ow] (NCHW or channels_last) and dx [n, 3, 2*oh, 2*ow]")
+    entry = "ta_stem7s2_input_grad_nchw" if nchw else "ta_stem7s2_input_grad"
+    p_dy = _ptr(dy, name="dy") if nchw else _ptr_any(dy, "dy")
     _wrote(dx)
     if std is not None and std.numel() == 3 and std.dtype == torch.float32 and std.device == dx.device and std.is_contiguous():
         slots = load().ta_stem_tiles(oh, ow)
         ws = _new_ws(dx, n * slots)
-        _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), _ptr(std, name="std"),
-              _ptr(ws), n, oh, ow)
+        _call(entry, dy, p_dy, _ptr(w2, name="w2"), _ptr(dx, name="dx"), _ptr(std, name="std"), _ptr(ws), n, oh, ow)
         _register_partials(dx, ws, slots, std=std)
         return dx
-    _call("ta_stem7s2_input_grad", dy, _ptr_any(dy, "dy"), _ptr(w2, name="w2"), _ptr(dx, name="dx"), None, None, n, oh, ow)
+    _call(entry, dy, p_dy, _ptr(w2, name="w2"), _ptr(dx, name="dx"), None, None, n, oh, ow)
     return dx
 
 

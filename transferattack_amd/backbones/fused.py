@@ -372,6 +372,53 @@ def _stem_input_grad(net, g_stem, x, grad_scale=None):
     return _conv_input_grad(g_stem, x, conv)
 
 
+class _StemConvFn(torch.autograd.Function):
+    """``conv1(x)`` of the plain MODULE path with the input gradient on csrc/stem.hip: the stem's backward-data is the last kernel of
+    every surrogate backward and MIOpen's slowest (an implicit GEMM with a dimension of 3 input channels: 13 TFLOP/s), also -- in
+    fact most of all -- in the reference-literal arrangement (NCHW, separate BatchNorm), where nothing else of this file applies.
+    Forward = the module's own convolution; the kernel takes dy in either memory format, is deterministic, as accurate as MIOpen's
+    (1.2e-6 vs 1.3e-6 of max|dx| from fp64), and leaves the sums of |dx / std| when the attack loop has folded the surrogate's
+    Normalize into its update (attack.py) -- no sum-only pass before the update on this path either."""
+
+    @staticmethod
+    def forward(ctx, x, net, grad_scale):
+        conv = net.conv1
+        ctx.net, ctx.grad_scale, ctx.x_meta = net, grad_scale, (x.shape, x.dtype, x.device)
+        return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        shape, dtype, device = ctx.x_meta
+        if not (g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)):
+            g = g.contiguous()
+        net, conv = ctx.net, ctx.net.conv1
+        w2 = getattr(net, "_stem_w2", None)
+        if w2 is None or w2.device != conv.weight.device or net._stem_w2_version != conv.weight._version:
+            w2 = net._stem_w2 = _hip.stem7s2_prepare(conv.weight)
+            net._stem_w2_version = conv.weight._version
+        return _hip.stem7s2_input_grad(g, w2, torch.empty(shape, dtype=dtype, device=device), std=ctx.grad_scale), None, None
+
+
+def module_path_stem(net, x):
+    """``net.conv1(x)`` -- through ``_StemConvFn`` when only the input gradient can be asked for (frozen weights), the stem has the
+    7 x 7 / stride 2 / 3 -> 64 shape of csrc/stem.hip and nobody hooks ``conv1`` (module hooks expect the module's own call)."""
+    conv = net.conv1
+    if (os.environ.get("TA_STEM_KERNEL", "1") == "0" or not (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda
+            or x.dtype != torch.float32 or x.dim() != 4 or type(conv) is not torch.nn.Conv2d
+            or tuple(conv.weight.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3) or conv.dilation != (1, 1)
+            or conv.groups != 1 or conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)
+            or x.shape[-1] % 2 or x.shape[-2] % 2 or observed(conv) or _global_module_hooks()):
+        return conv(x)
+    return _StemConvFn.apply(x, net, getattr(x, _hip._SCALE_ATTR, None))
+
+
+def _global_module_hooks():
+    from torch.nn.modules import module as m
+    return any(getattr(m, name, None) for name in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks",
+                                                   "_global_backward_pre_hooks", "_global_forward_hooks_always_called"))
+
+
 def _like(t, ref):
     """``t`` in ``ref``'s dense memory format (a no-op when MIOpen already returned it that way)"""
     if ref.is_contiguous():

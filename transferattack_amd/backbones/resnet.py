@@ -84,7 +84,10 @@ class ResNet(nn.Module):
             from . import fused                  # the attack path: same convolutions, fused glue (backbones/fused.py)
             if fused.usable(self, x):
                 return fused.forward(self, x)
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            # the module path (e.g. the reference-literal arrangement): only the stem's input gradient leaves MIOpen
+            x = self.maxpool(self.relu(self.bn1(fused.module_path_stem(self, x))))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

@@ -15,7 +15,8 @@
 // two 16-position tiles, and per tap reads its A operands with four ds_read_b128 per tile (a lane's sixteen k-values are
 // contiguous channels: K is enumerated as channel = 16 * kk + s for MFMA step s, lane quarter kk).  The B operand -- the
 // prepared weights W2[tap][s][kk][col], 64 KB, built once per model by ta_stem7s2_prepare -- is read straight from
-// L2: 64 consecutive floats per MFMA, one coalesced load per wave.  dy: channels_last [N, OH, OW, 64]; dx: NCHW [N, 3, 2*OH, 2*OW].
+// L2: 64 consecutive floats per MFMA, one coalesced load per wave.  dy: channels_last [N, OH, OW, 64] (or NCHW, ta_stem7s2_input_grad_nchw);
+// dx: NCHW [N, 3, 2*OH, 2*OW].
 // Useful work is 49/64 of the taps and 12/16 of the columns: 57 % of the MFMA slots.
 #include "ta_common.h"
 
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(kBlock) void stem7s2_prepare_kernel(const float* __
 // the update (ta_mi_update_std) what it writes IS the update's operand: it then also leaves, per workgroup, the sum of
 // |dx / std[c]| over the elements it stored (fixed order: lane, wave butterfly, waves in index order) -- the per-image
 // sums of |g| that get_momentum's mean needs (attack.py:128), without another pass over dx.
-template <bool SUMS>
+// DY_NCHW: dy is [N, 64, OH, OW] (the layout autograd hands over on the reference-literal module path); only the staging of the
+// window differs -- 4-byte loads along a row (a 35-pixel run per channel and window row) into the same pixel-major LDS window.
+template <bool SUMS, bool DY_NCHW>
 __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float* __restrict__ dy, const float* __restrict__ w2,
                                                                     float* __restrict__ dx, int oh, int ow,
                                                                     const float* __restrict__ stdv, float* __restrict__ ws) {
@@ -71,7 +74,18 @@ __global__ __launch_bounds__(kBlock) void stem7s2_input_grad_kernel(const float*
     const int n = static_cast<int>(blockIdx.z);
     const float* dyn = dy + static_cast<int64_t>(n) * oh * ow * kStemK;
 
-    // -- stage the dy window (rows i0-1 .. i0+5, columns j0-1 .. j0+33, zeros outside the map): one float4 per step
+    // -- stage the dy window (rows i0-1 .. i0+5, columns j0-1 .. j0+33, zeros outside the map)
+    if (DY_NCHW) {
+        const int64_t plane = static_cast<int64_t>(oh) * ow;
+        for (int q = threadIdx.x; q < kStemK * kStemWinRows * kStemWinCols; q += kBlock) {
+            const int wc = q % kStemWinCols, t = q / kStemWinCols;
+            const int wr = t % kStemWinRows, ch = t / kStemWinRows;
+            const int oy = i0 - 1 + wr, ox = j0 - 1 + wc;
+            float v = 0.0f;
+            if (oy >= 0 && oy < oh && ox >= 0 && ox < ow) v = dyn[ch * plane + static_cast<int64_t>(oy) * ow + ox];
+            win[(wr * kStemWinCols + wc) * kStemLd + ch] = v;
+        }
+    } else                                                                       // channels_last: one float4 per step
     for (int q = threadIdx.x; q < kStemWinRows * kStemWinCols * (kStemK / 4); q += kBlock) {
         const int pix = q >> 4, c4 = (q & 15) * 4;
         const int wr = pix / kStemWinCols, wc = pix - wr * kStemWinCols;
@@ -149,17 +163,27 @@ extern "C" int64_t ta_stem_tiles(int oh, int ow) {
     return oh > 0 && ow > 0 ? ceil_div(ow, kStemCols) * ceil_div(oh, kStemRows) : 0;
 }
 
-extern "C" int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh,
-                                     int ow, void* stream) {
+static int stem_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh, int ow,
+                           bool dy_nchw, void* stream) {
     TA_REQUIRE(dy && w2 && dx && aligned16(dy) && aligned16(w2), "null or unaligned pointer");
     TA_REQUIRE((stdv == nullptr) == (ws == nullptr), "std and the sums' buffer come together");
     TA_REQUIRE(n > 0 && n <= 65535 && oh > 0 && ow > 0 && oh <= 4096 && ow <= 4096, "shape (n=%lld, oh=%d, ow=%d)", (long long)n, oh, ow);
     const dim3 grid(static_cast<unsigned>(ceil_div(ow, kStemCols)), static_cast<unsigned>(ceil_div(oh, kStemRows)),
                     static_cast<unsigned>(n));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ws != nullptr)
-        hipLaunchKernelGGL(stem7s2_input_grad_kernel<true>, grid, dim3(kBlock), 0, st, dy, w2, dx, oh, ow, stdv, ws);
-    else
-        hipLaunchKernelGGL(stem7s2_input_grad_kernel<false>, grid, dim3(kBlock), 0, st, dy, w2, dx, oh, ow, stdv, ws);
+#define TA_STEM(SUMS, NCHW) hipLaunchKernelGGL((stem7s2_input_grad_kernel<SUMS, NCHW>), grid, dim3(kBlock), 0, st, dy, w2, dx, oh, ow, stdv, ws)
+    if (ws != nullptr) { if (dy_nchw) TA_STEM(true, true); else TA_STEM(true, false); }
+    else { if (dy_nchw) TA_STEM(false, true); else TA_STEM(false, false); }
+#undef TA_STEM
     return check_launch("stem7s2_input_grad");
+}
+
+extern "C" int ta_stem7s2_input_grad(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh,
+                                     int ow, void* stream) {
+    return stem_input_grad(dy, w2, dx, stdv, ws, n, oh, ow, false, stream);
+}
+
+extern "C" int ta_stem7s2_input_grad_nchw(const float* dy, const float* w2, float* dx, const float* stdv, float* ws, int64_t n, int oh,
+                                          int ow, void* stream) {
+    return stem_input_grad(dy, w2, dx, stdv, ws, n, oh, ow, true, stream);
 }
