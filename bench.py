@@ -418,6 +418,10 @@ def staged_warmup(step, args, world, rank, independent=True):
     if staged:
         import datetime
         import torch.distributed as dist
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            # one node, rendezvous on the loopback: gloo would otherwise pick its interface by resolving the host NAME, which
+            # a container may not be able to do
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         group = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=2))
         if rank != 0:
             t0 = time.perf_counter()
