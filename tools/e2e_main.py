@@ -75,13 +75,15 @@ def main():
         print(json.dumps({"dataset": "%d synthetic 224x224 RGB PNGs (uniform noise: the worst case for the PNG codec)" % args.images,
                           "write_s": round(time.perf_counter() - t0, 1)}), flush=True)
     torch.backends.cudnn.benchmark = True
-    fast = {"TA_FOLD_BN": "1", "TA_CHANNELS_LAST": "1"}
-    plain = {"TA_FOLD_BN": "0", "TA_CHANNELS_LAST": "0"}
+    fast = {"TA_FOLD_BN": "1", "TA_CHANNELS_LAST": "1", "TA_CK_EPILOGUE": "0"}
+    plain = {"TA_FOLD_BN": "0", "TA_CHANNELS_LAST": "0", "TA_CK_EPILOGUE": "0"}
     runs = [("warm-up (MIOpen find)", 32, ["--coalesce", "4"], fast),
             ("reference batches of 32, one per device batch, reference-literal surrogate", 32, ["--coalesce", "1"], plain),
             ("reference batches of 32, one per device batch, folded BN + NHWC", 32, ["--coalesce", "1"], fast),
             ("reference batches of 32, four per device batch, folded BN + NHWC", 32, ["--coalesce", "4"], fast),
-            ("same, 16 io threads", 32, ["--coalesce", "4", "--io_threads", "16"], fast)]
+            ("same, 16 io threads", 32, ["--coalesce", "4", "--io_threads", "16"], fast),
+            ("same, glue passes as composable_kernel convolution epilogues (TA_CK_EPILOGUE=1)", 32,
+             ["--coalesce", "4", "--io_threads", "16"], dict(fast, TA_CK_EPILOGUE="1"))]
     for tag, bs, extra, env in runs:
         r = run(data, os.path.join(args.root, "adv"), args.attack, args.model, bs, extra, env)
         r["run"] = tag
