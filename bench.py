@@ -727,7 +727,8 @@ def main(argv=None):
                                    % ("configs[1]: MI-FGSM" if args.attack == "mifgsm" else args.attack, args.model,
                                       args.image_size, args.image_size, args.batch, layout),
                        # glue passes as epilogues of composable_kernel convolutions (libta_ck.so), site by site where faster
-                       "ck_epilogue": {"on": _ck.enabled(), "sites_tuned": _ck.stats["tuned_sites"], "sites_fused": _ck.stats["sites_on_ck"]},
+                       "ck_epilogue": {"on": _ck.enabled(), "sites_tuned": _ck.stats["tuned_sites"], "sites_from_plan_file": _ck.stats["sites_from_disk"],
+                                       "sites_fused": _ck.stats["sites_on_ck"]},
                        "byte_source": os.environ.get("TA_U8_SOURCE", "1") != "0",
                        # the surrogate's Normalize folded into the two HIP kernels either side of the backbone
                        # (attack.py::_forward_normalize_folded): no x + delta store, no gx = gy / std store

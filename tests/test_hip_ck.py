@@ -25,7 +25,7 @@ def run_all(kind, geom, a, w, d0, d1, d2, out_shape):
     got = []
     for idx in range(lib.ta_ck_instances(kind, geom[5], geom[6], geom[7])):
         e = torch.full(out_shape, float("nan"), device=DEV).contiguous(memory_format=CL)
-        if _ck.conv(kind, idx, a, w, d0, d1, d2, e, geom) == 0:
+        if _ck.conv(kind, idx, a, w, d0, d1, d2, e, geom, probing=True) == 0:
             got.append((lib.ta_ck_instance_name(kind, geom[5], geom[6], geom[7], idx).decode(), e))
     torch.cuda.synchronize()
     return got
@@ -116,3 +116,29 @@ def test_epilogue_arithmetic_is_exact_where_the_sums_are():
     want = torch.ops.aten.threshold_backward(gx, act, 0)
     for name, e in run_all(_ck.FWD_MASK, fgeom, g, wt, act, None, None, tuple(act.shape)):
         assert torch.equal(e, want), name                                       # incl. the NaN activation: the gradient passes
+
+
+def test_site_decisions_persist(tmp_path, monkeypatch):
+    """the tuner's decision for a site is written to the plan file and taken from there by a process that has not tuned (here:
+    the same process with its in-memory plans dropped) -- as MIOpen's find results persist in its user find-db"""
+    import json
+    from transferattack_amd.backbones import fused
+    monkeypatch.setenv("TA_CK_EPILOGUE", "1")
+    monkeypatch.setenv("TA_CK_PLAN_CACHE", str(tmp_path / "plans.json"))
+    monkeypatch.setattr(_ck, "_disk", None)
+    monkeypatch.setattr(_ck, "plans", {})
+    conv = torch.nn.Conv2d(64, 64, 1).to(DEV)
+    x = nhwc(torch.randn(8, 64, 28, 28))
+    want = torch.clamp_min(F.conv2d(x, conv.weight, conv.bias), 0)
+    before = dict(_ck.stats)
+    y1, _ = fused._site_bias_relu(x, conv, lambda t: None)
+    assert _ck.stats["tuned_sites"] == before["tuned_sites"] + 1
+    stored = json.load(open(tmp_path / "plans.json"))
+    assert len(stored) == 1
+    monkeypatch.setattr(_ck, "_disk", None)
+    monkeypatch.setattr(_ck, "plans", {})
+    conv.__dict__.pop("_ta_ck_sites")
+    y2, _ = fused._site_bias_relu(x, conv, lambda t: None)
+    assert _ck.stats["tuned_sites"] == before["tuned_sites"] + 1 and _ck.stats["sites_from_disk"] == before["sites_from_disk"] + 1
+    for y in (y1, y2):
+        assert float((y - want).abs().max()) <= 2e-5 * float(want.abs().max())

@@ -82,6 +82,8 @@ def main():
             ("reference batches of 32, one per device batch, folded BN + NHWC", 32, ["--coalesce", "1"], fast),
             ("reference batches of 32, four per device batch, folded BN + NHWC", 32, ["--coalesce", "4"], fast),
             ("same, 16 io threads", 32, ["--coalesce", "4", "--io_threads", "16"], fast),
+            ("warm-up (composable_kernel site tuning: the decisions persist in ~/.cache/transferattack_amd)", 32,
+             ["--coalesce", "4", "--io_threads", "16"], dict(fast, TA_CK_EPILOGUE="1")),
             ("same, glue passes as composable_kernel convolution epilogues (TA_CK_EPILOGUE=1)", 32,
              ["--coalesce", "4", "--io_threads", "16"], dict(fast, TA_CK_EPILOGUE="1"))]
     for tag, bs, extra, env in runs:

@@ -76,7 +76,7 @@ def _site_bias_relu(x, conv, new_bits):
         if geom is not None:
             w, (ho, wo) = _ck.weight_kyxc(conv), _ck.out_hw(geom)
             y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
-            run = lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom)      # noqa: E731
+            run = lambda idx: _ck.conv(_ck.FWD_BIAS_RELU, idx, x, w, conv.bias, None, None, y, geom, probing=True)      # noqa: E731
             best = _ck.choose(("bias_relu", geom), [(_ck.FWD_BIAS_RELU, geom, run)], two_kernels)
             plan = None if best is None else (best[1], geom, w, ho, wo)
         cache[key] = plan
@@ -113,7 +113,7 @@ def _site_stem_bias_relu(x, conv):
             x4 = padded()
 
             def run_with_pad(idx):            # what will run: the padding pass + the convolution
-                return _ck.conv(_ck.FWD_BIAS_RELU, idx, padded(), w4, conv.bias, None, None, y, geom)
+                return _ck.conv(_ck.FWD_BIAS_RELU, idx, padded(), w4, conv.bias, None, None, y, geom, probing=True)
             best = _ck.choose(("stem_bias_relu", geom), [(_ck.FWD_BIAS_RELU, geom, run_with_pad)], two_kernels)
             del x4
             plan = None if best is None else (best[1], geom, w4, ho, wo)
@@ -143,7 +143,7 @@ def _site_bias_add_relu(x, conv, other, bias_other, new_bits):
         if geom is not None and tuple(other.shape) == (geom[0], geom[4]) + _ck.out_hw(geom):
             w = _ck.weight_kyxc(conv)
             y = torch.empty_like(other)
-            run = lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom)      # noqa: E731
+            run = lambda idx: _ck.conv(kind, idx, x, w, conv.bias, other, bias_other, y, geom, probing=True)      # noqa: E731
             best = _ck.choose((tag, geom), [(kind, geom, run)], two_kernels)
             plan = None if best is None else (best[1], geom, w)
         cache[key] = plan
@@ -175,7 +175,7 @@ def _site_input_grad_mask(g, conv, act, bits, other=None):
             wt = _ck.weight_flipped_cyxk(conv)
             out = torch.empty_like(act)
             d0, d1 = (act, None) if other is None else (other, act)
-            best = _ck.choose((tag, geom), [(kind, fgeom, lambda idx: _ck.conv(kind, idx, g, wt, d0, d1, None, out, fgeom))], two_kernels)
+            best = _ck.choose((tag, geom), [(kind, fgeom, lambda idx: _ck.conv(kind, idx, g, wt, d0, d1, None, out, fgeom, probing=True))], two_kernels)
             plan = None if best is None else (best[1], fgeom, wt)
         cache[key] = plan
     if plan is None:
