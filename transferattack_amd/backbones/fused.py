@@ -18,6 +18,11 @@ bits (``tests/test_fused_backbone.py``: equality on the host stand-in and on the
 It is an execution strategy of the surrogate, not a different surrogate: ``ResNet.forward`` takes it only when the module
 tree is observed by nobody (no forward / backward hooks anywhere in the backbone -- model-related attacks that hook
 ``self.model[1]`` sub-modules get the plain module path), BatchNorm has been folded, and ``TA_FUSED_GLUE`` is not ``0``.
+
+Round 6, ``TA_CK_EPILOGUE=1``: a convolution and the glue pass behind it become ONE composable_kernel convolution with the pass as
+epilogue (libta_ck.so, ``_ck.py``) at every site where that measures faster than the two-kernel form -- forward (bias + ReLU, bias +
+shortcut + ReLU, the stem on a 4-channel padded image) and backward (the forward kernel on the rewritten problem + threshold /
+junction add).  And the plain MODULE path (``module_path_stem``) sends its stem's input gradient through csrc/stem.hip too.
 """
 import os
 
@@ -110,12 +115,10 @@ def _site_stem_bias_relu(x, conv):
             w4 = torch.nn.functional.pad(_ck.weight_kyxc(conv), (0, 4 - cin)).contiguous()
             ho, wo = _ck.out_hw(geom)
             y = torch.empty((geom[0], geom[4], ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
-            x4 = padded()
 
             def run_with_pad(idx):            # what will run: the padding pass + the convolution
                 return _ck.conv(_ck.FWD_BIAS_RELU, idx, padded(), w4, conv.bias, None, None, y, geom, probing=True)
             best = _ck.choose(("stem_bias_relu", geom), [(_ck.FWD_BIAS_RELU, geom, run_with_pad)], two_kernels)
-            del x4
             plan = None if best is None else (best[1], geom, w4, ho, wo)
         cache[key] = plan
     if plan is None:
