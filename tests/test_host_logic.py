@@ -188,6 +188,9 @@ def test_ck_abi_symbols_exported():
         assert lib.ta_ck_instances(kind, 1, 1, 0) >= 8 and lib.ta_ck_instances(kind, 3, 1, 1) >= 8
     assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 1, 1)) == (4, 128, 56, 56, 64, 3, 1, 1)
     assert _ck.backward_as_forward((4, 64, 56, 56, 128, 3, 2, 1)) is None
+    conv = torch.nn.Conv2d(64, 256, 1)
+    assert _ck.geometry((125, 64, 56, 56), conv) == (125, 64, 56, 56, 256, 1, 1, 0)
+    assert _ck.geometry((1000, 64, 56, 56), conv) is None            # a 3.2 GB output map: beyond the kernels' 32-bit byte offsets
     assert b"Xdl_CShuffle" in lib.ta_ck_instance_name(_ck.FWD_ADD_MASK, 1, 1, 0, 0)
     assert lib.ta_ck_conv(_ck.FWD_BIAS_RELU, 0, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, None) == -1       # TA_CK_EINVAL
     assert b"null" in lib.ta_ck_last_error()

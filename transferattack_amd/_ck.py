@@ -85,7 +85,11 @@ def geometry(x_shape, conv):
     n, cin, h, w = x_shape
     if cin != c:
         return None
-    return (int(n), int(c), int(h), int(w), int(k), int(ky), int(st[0]), int(pd[0]))
+    geom = (int(n), int(c), int(h), int(w), int(k), int(ky), int(st[0]), int(pd[0]))
+    ho, wo = out_hw(geom)
+    if max(n * h * w * c, n * ho * wo * k) * 4 >= 2 ** 31:       # the kernels address with 32-bit byte offsets: larger maps stay on MIOpen
+        return None
+    return geom
 
 
 def out_hw(geom):

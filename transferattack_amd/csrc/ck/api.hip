@@ -99,8 +99,8 @@ extern "C" int ta_ck_conv(int kind, int index, const float* a, const float* w, c
     if (n <= 0 || c <= 0 || hi <= 0 || wi <= 0 || k <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || hi + 2 * pad < ksize || wi + 2 * pad < ksize)
         return fail("bad shape (n=%d c=%d h=%d w=%d k=%d filter=%d stride=%d pad=%d)", n, c, hi, wi, k, ksize, stride, pad);
     const Geom g{n, c, hi, wi, k, ksize, ksize, stride, pad, (hi + 2 * pad - ksize) / stride + 1, (wi + 2 * pad - ksize) / stride + 1};
-    if (static_cast<int64_t>(n) * hi * wi * c >= (1ll << 31) || static_cast<int64_t>(n) * g.ho * g.wo * k >= (1ll << 31))
-        return fail("tensor of 2^31 elements or more");
+    if (static_cast<int64_t>(n) * hi * wi * c * 4 >= (1ll << 31) || static_cast<int64_t>(n) * g.ho * g.wo * k * 4 >= (1ll << 31))
+        return fail("tensor of 2 GiB or more (32-bit byte offsets)");
     if (index < 0 || index >= ta_ck_instances(kind, ksize, stride, pad)) return fail("no configuration %d for kind %d and this filter", index, kind);
     const bool one = is_1x1(ksize, stride, pad);
     const A2 st{stride, stride}, dil{1, 1}, pl{pad, pad}, pr{pad, pad};
