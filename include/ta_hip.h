@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 12
+#define TA_ABI_VERSION 13
 #define TA_EINVAL (-1)
 
 int ta_abi_version(void);
@@ -267,6 +267,16 @@ int ta_relu_mask(const float* ga, const float* gb, const float* y, const uint8_t
  *                        buffers: ga / gb / idx [n, ph, pw, c], y / out [n, h, w, c]; idx = ATen's argmax index h * w_ + w. */
 int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64_t* idx, const float* y, float* out, int64_t n, int channels,
                         int h, int w, int ph, int pw, int k, int s, int p, void* stream);
+/*   ta_maxpool3s2_fwd / ta_maxpool3s2_bwd_relu (ABI 13)  the same pair for THE stem pool -- 3 x 3, stride 2, padding 1, an even
+ *                        map, channels % 8 == 0 -- with the forward on this side too (replaces F.max_pool2d(..., return_indices=True)
+ *                        = at::max_pool2d_with_indices, the pooling behind torchvision's resnet.py maxpool): it leaves
+ *                          pooled [n, h/2, w/2, c]   the values max_pool2d gives (ATen's scan order and update rule, NaN included);
+ *                          arg    [n, h/2, w/2, c]   one byte: the winning tap kh * 3 + kw (ATen: an int64 h * w_ + w per element);
+ *                          mask   n*h*w*c / 8 bytes  the pass bits of the pooled ACTIVATION y (layout as above),
+ *                        and the backward takes arg + mask instead of idx + y: 1 1/8 byte where it read 12 per element. */
+int ta_maxpool3s2_fwd(const float* y, float* pooled, uint8_t* arg, uint8_t* mask, int64_t n, int channels, int h, int w, void* stream);
+int ta_maxpool3s2_bwd_relu(const float* ga, const float* gb, const uint8_t* arg, const uint8_t* mask, float* out, int64_t n,
+                           int channels, int h, int w, void* stream);
 
 /* ---- the stem convolution's input gradient (7 x 7, stride 2, padding 3, 3 -> 64 channels: ResNet / ImageNet CNN stems) ----
  * The last convolution of the surrogate's backward, producer of the gradient the update consumes (attack.py:118-122).

@@ -47,7 +47,14 @@ def build():
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
     sources = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     deps = sources + headers + [os.path.join(HERE, "hipcpu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"), __file__]
-    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+    stale = lambda: not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps)   # noqa: E731
+    if not stale():
+        return lib
+    import fcntl
+    with open(os.path.join(OUT, ".build.lock"), "w") as lock:      # pytest-xdist workers: one builds, the others wait and find it done
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not stale():
+            return lib
         for h in headers:
             with open(os.path.join(OUT, os.path.basename(h)), "w") as fh:
                 fh.write(_host_text(open(h).read()))
@@ -71,8 +78,9 @@ def build():
         extra = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-DHIPCPU_SINGLE_WORKER"] if SANITIZE else []
         cmd = ["g++", "-O1" if SANITIZE else "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
                "-pthread", "-Wno-attributes", "-Wno-unknown-pragmas", "-I", HERE, "-I", OUT] + extra + generated + [
-               os.path.join(HERE, "hipcpu.cpp"), "-o", lib]
+               os.path.join(HERE, "hipcpu.cpp"), "-o", lib + ".%d.tmp" % os.getpid()]
         subprocess.run(cmd, check=True, capture_output=True, text=True)
+        os.replace(cmd[-1], lib)          # a new inode: another pytest-xdist worker that has the old file mapped keeps its pages
     return lib
 
 
@@ -82,6 +90,7 @@ def load(tag=None):
     if tag is not None:
         import shutil
         private = lib.replace(".so", "_%s.so" % tag)
-        shutil.copyfile(lib, private)
+        shutil.copyfile(lib, private + ".%d.tmp" % os.getpid())
+        os.replace(private + ".%d.tmp" % os.getpid(), private)     # never write INTO a file another worker may have loaded
         lib = private
     return ctypes.CDLL(lib)

@@ -119,6 +119,48 @@ def test_maxpool_backward_relu_kernel(monkeypatch, shape, k, s, p):
         assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 16, 2, 6), (3, 64, 12, 10), (1, 8, 2, 2)])
+def test_stem_pool_pair(monkeypatch, shape):
+    """ta_maxpool3s2_fwd / ta_maxpool3s2_bwd_relu (the stem pool with a byte of argmax and the activation's pass bits) against
+    max_pool2d_with_indices, its backward and threshold_backward: pooled values, the element that wins each window (ties at the
+    ReLU's zeros and between equal positives included), the bits, and the gradient -- all EQUAL"""
+    host_kernels.install(monkeypatch)
+    gen = torch.Generator().manual_seed(sum(shape))
+    cl = torch.channels_last
+    n, c, h, w = shape
+    pre = torch.randn(shape, generator=gen)
+    y = (pre.clamp_min(0) * 4).round().div(4).contiguous(memory_format=cl)       # quarter steps: ties between positives too
+    y[0, :, 0, 0] = float("nan")                                                  # a NaN wins its windows, as in ATen
+    y[-1, 1, -1, -1] = float("inf")
+    assert _hip.maxpool3s2_takes(y, torch.nn.MaxPool2d(3, 2, 1))
+    assert not _hip.maxpool3s2_takes(y, torch.nn.MaxPool2d(3, 2, 1, ceil_mode=True))
+    assert not _hip.maxpool3s2_takes(y.contiguous(), torch.nn.MaxPool2d(3, 2, 1))
+    want, idx = torch.nn.functional.max_pool2d(y, 3, 2, 1, return_indices=True)
+    pooled, arg, bits = _hip.maxpool3s2_fwd(y)
+    assert pooled.is_contiguous(memory_format=cl) and arg.is_contiguous(memory_format=cl)
+    assert torch.equal(torch.nan_to_num(pooled, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+    kh, kw = arg.long() // 3, arg.long() % 3
+    ii = torch.arange(h // 2).view(1, 1, -1, 1)
+    jj = torch.arange(w // 2).view(1, 1, 1, -1)
+    assert torch.equal((2 * ii - 1 + kh) * w + (2 * jj - 1 + kw), idx)
+    passes = ~(y <= 0)                                                            # threshold_backward's test; NaN passes
+    flat = passes.permute(0, 2, 3, 1).reshape(-1, 8).to(torch.uint8)
+    assert torch.equal(bits, (flat << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8))
+    ga = torch.randn(want.shape, generator=gen).contiguous(memory_format=cl)
+    gb = torch.randn(want.shape, generator=gen).contiguous(memory_format=cl)
+    for second in (gb, None):
+        g = ga if second is None else ga + second
+        ref = torch.ops.aten.max_pool2d_with_indices_backward(g, y, [3, 3], [2, 2], [1, 1], [1, 1], False, idx)
+        ref = torch.ops.aten.threshold_backward(ref, y, 0)
+        generic = _hip.maxpool_bwd_relu(ga, idx.contiguous(memory_format=cl), y, torch.full_like(y, float("nan")), 3, 2, 1, gb=second)
+        got = _hip.maxpool3s2_bwd_relu(ga, arg, bits, torch.full_like(y, float("nan")), gb=second)
+        assert not torch.isnan(got).any()
+        assert torch.equal(got, generic)
+        assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        _hip.maxpool3s2_bwd_relu(ga, arg, bits[:-1], torch.empty_like(y))
+
+
 def test_fused_path_steps_aside(monkeypatch):
     """hooks anywhere in the backbone, an unfolded BatchNorm, training mode or a trainable weight: the module path runs"""
     host_kernels.install(monkeypatch)

@@ -365,6 +365,37 @@ def test_stem_input_grad_kernel_on_device(n, oh, ow):
     assert torch.equal(nchw, got)
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 112, 112), (2, 8, 6, 14), (1, 128, 2, 2)])
+def test_stem_pool_pair_on_device(shape):
+    """ta_maxpool3s2_fwd / ta_maxpool3s2_bwd_relu on MI355X against ATen's device kernels: the pooled values, WHICH element wins
+    every window (ties at the ReLU's zeros, ties between equal positives, NaN) and the activation's pass bits are EQUAL to
+    max_pool2d_with_indices; the gradient equals the generic gather (ta_maxpool_bwd_relu on ATen's int64 indices) bit for bit
+    and ATen's atomic-add backward to summation order"""
+    gen = torch.Generator().manual_seed(sum(shape))
+    cl = torch.channels_last
+    n, c, h, w = shape
+    y = (torch.randn(shape, generator=gen).clamp_min(0) * 4).round().div(4)
+    y[0, :, 0, 0] = float("nan")
+    y = y.to(DEV).contiguous(memory_format=cl)
+    want, idx = torch.nn.functional.max_pool2d(y, 3, 2, 1, return_indices=True)
+    pooled, arg, bits = _hip.maxpool3s2_fwd(y)
+    assert torch.equal(torch.nan_to_num(pooled, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+    kh, kw = arg.long() // 3, arg.long() % 3
+    ii = torch.arange(h // 2, device=DEV).view(1, 1, -1, 1)
+    jj = torch.arange(w // 2, device=DEV).view(1, 1, 1, -1)
+    assert torch.equal((2 * ii - 1 + kh) * w + (2 * jj - 1 + kw), idx)
+    flat = (~(y <= 0)).permute(0, 2, 3, 1).reshape(-1, 8).to(torch.uint8)
+    assert torch.equal(bits, (flat << torch.arange(8, dtype=torch.uint8, device=DEV)).sum(1).to(torch.uint8))
+    ga = torch.randn(want.shape, generator=gen).to(DEV).contiguous(memory_format=cl)
+    gb = torch.randn(want.shape, generator=gen).to(DEV).contiguous(memory_format=cl)
+    ref = torch.ops.aten.max_pool2d_with_indices_backward(ga + gb, y, [3, 3], [2, 2], [1, 1], [1, 1], False, idx)
+    ref = torch.ops.aten.threshold_backward(ref, y, 0)
+    generic = _hip.maxpool_bwd_relu(ga, idx.contiguous(memory_format=cl), y, torch.full_like(y, float("nan")), 3, 2, 1, gb=gb)
+    got = _hip.maxpool3s2_bwd_relu(ga, arg, bits, torch.full_like(y, float("nan")), gb=gb)
+    assert not torch.isnan(got).any() and torch.equal(got, generic)
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape,k,s,p", [((4, 64, 112, 112), 3, 2, 1), ((2, 8, 9, 13), 3, 2, 1), ((2, 16, 12, 12), 2, 2, 0)])
 def test_maxpool_backward_relu_kernel_on_device(shape, k, s, p):
     """ta_maxpool_bwd_relu on MI355X against the three ATen passes it replaces (junction add, max_pool2d_with_indices_backward

@@ -165,7 +165,7 @@ def test_abi_symbols_exported():
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ta_abi_version() == _hip.ABI_VERSION == 12
+    assert lib.ta_abi_version() == _hip.ABI_VERSION == 13
     assert lib.ta_l1_workspace_floats(32, 150528) == 2 * 32 * 49
     assert lib.ta_update_tiles(150528) == 49 and lib.ta_conv_tiles(15, 224, 224) == 7 and lib.ta_conv_tiles(9, 224, 224) == 14 and lib.ta_dim_bwd_tiles(224, 246) == 28
 

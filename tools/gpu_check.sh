@@ -24,6 +24,9 @@ newtests6)
 coldranks)
   # bench.py --gpus 2 on ONE device with fresh MIOpen databases: rank 0 warms up first vs both together (tools/cold_start_ranks.py)
   timeout 2400 python tools/cold_start_ranks.py --runs ${TA_COLD_RUNS:-one,one:warm,staged,together} 2> $OUT/cold_start_ranks.err | tee $OUT/cold_start_ranks.jsonl ;;
+pool)
+  # the stem pool pair (ta_maxpool3s2_fwd / _bwd_relu) against ATen on the device, and the surrogate around it
+  timeout 900 python -m pytest tests/test_hip_configs.py -q -m gpu -s -p no:cacheprovider -k "stem_pool or maxpool or fused_glue" 2>&1 | grep -v Warning | tee $OUT/pool_pytest.txt | tail -15 ;;
 stem)
   timeout 300 python tools/stem_microbench.py 2>&1 | tee $OUT/stem_microbench.txt ;;
 asrlong)

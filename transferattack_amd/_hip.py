@@ -65,6 +65,8 @@ SIGNATURES = {
     "ta_bias_add_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "ta_relu_mask": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ta_maxpool_bwd_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "ta_maxpool3s2_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
+    "ta_maxpool3s2_bwd_relu": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
     "ta_scale_copies_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "ta_scale_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "ta_sum_copies_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
@@ -84,7 +86,7 @@ SIGNATURES = {
     "ta_quantize_u8_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class HipExtensionError(RuntimeError):
@@ -798,6 +800,48 @@ def maxpool_bwd_relu(ga, idx, y, out, kernel, stride, padding, gb=None):
     flat = lambda t, dt: _ptr(t.detach().as_strided((t.numel(),), (1,)), dt, "operand")       # noqa: E731
     _call("ta_maxpool_bwd_relu", y, flat(ga, torch.float32), None if gb is None else flat(gb, torch.float32),
           flat(idx, torch.int64), flat(y, torch.float32), flat(out, torch.float32), n, c, h, w, ph, pw, kernel, stride, padding)
+    return out
+
+
+def maxpool3s2_takes(y, pool):
+    """is ``pool`` (a MaxPool2d) over the channels_last activation ``y`` the stem pool ``maxpool3s2_fwd`` implements"""
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)                                  # noqa: E731
+    return (pair(pool.kernel_size) == (3, 3) and pair(pool.stride) == (2, 2) and pair(pool.padding) == (1, 1)
+            and pair(pool.dilation) == (1, 1) and not pool.ceil_mode and y.dim() == 4 and y.dtype == torch.float32
+            and y.shape[1] % 8 == 0 and y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0 and y.shape[2] >= 2 and y.shape[3] >= 2
+            and y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous() and y.numel() < 2 ** 32 - 2 ** 12)
+
+
+def maxpool3s2_fwd(y):
+    """(pooled, arg, mask) of the 3 x 3 / stride 2 / padding 1 max-pool over the channels_last activation ``y`` [n, c, h, w]:
+    ``pooled`` = F.max_pool2d(y, 3, 2, 1) (channels_last), ``arg`` [n, c, h/2, w/2] uint8 (channels_last) the winning tap
+    kh * 3 + kw of each window -- the element max_pool2d_with_indices names -- and ``mask`` the pass bits of ``y`` itself;
+    what ``maxpool3s2_bwd_relu`` needs, 1 1/8 byte per element where (int64 indices, y) are 12"""
+    n, c, h, w = y.shape
+    cl = torch.channels_last
+    pooled = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=y.device, memory_format=cl)
+    arg = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=y.device, memory_format=cl)
+    mask = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device)
+    flat = lambda t, dt: _ptr(t.detach().as_strided((t.numel(),), (1,)), dt, "operand")       # noqa: E731
+    _call("ta_maxpool3s2_fwd", y, flat(y, torch.float32), flat(pooled, torch.float32), flat(arg, torch.uint8), _ptr(mask, torch.uint8, "mask"),
+          n, c, h, w)
+    return pooled, arg, mask
+
+
+def maxpool3s2_bwd_relu(ga, arg, mask, out, gb=None):
+    """out <- threshold_backward(max_pool2d_with_indices_backward(ga [+ gb], .), y, 0) from what ``maxpool3s2_fwd(y)`` left"""
+    n, c, h, w = out.shape
+    cl = torch.channels_last
+    ok = (all(t.is_contiguous(memory_format=cl) for t in (ga, arg, out) + (() if gb is None else (gb,)))
+          and tuple(ga.shape) == tuple(arg.shape) == (n, c, h // 2, w // 2) and (gb is None or gb.shape == ga.shape)
+          and arg.dtype == torch.uint8 and mask.dtype == torch.uint8 and mask.numel() * 8 == out.numel() and c % 8 == 0
+          and h % 2 == 0 and w % 2 == 0)
+    if not ok:
+        raise ValueError("maxpool3s2_bwd_relu: operands do not belong to one maxpool3s2_fwd call")
+    _wrote(out)
+    flat = lambda t, dt: _ptr(t.detach().as_strided((t.numel(),), (1,)), dt, "operand")       # noqa: E731
+    _call("ta_maxpool3s2_bwd_relu", out, flat(ga, torch.float32), None if gb is None else flat(gb, torch.float32),
+          flat(arg, torch.uint8), _ptr(mask, torch.uint8, "mask"), flat(out, torch.float32), n, c, h, w)
     return out
 
 

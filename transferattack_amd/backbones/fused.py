@@ -278,7 +278,14 @@ class _ResNetFn(torch.autograd.Function):
         bits = os.environ.get("TA_RELU_BITS", "1") != "0"
         new_bits = (lambda t: _hip.pass_bits_like(t)) if bits else (lambda t: None)
         stem = _site_stem_bias_relu(x, net.conv1)
-        pooled, idx = F.max_pool2d(stem, net.maxpool.kernel_size, net.maxpool.stride, net.maxpool.padding, return_indices=True)
+        # the stem pool: its own kernel where it is THE stem pool (3 x 3 / 2 / 1, NHWC) -- leaves a byte per pooled element for the
+        # argmax and the pass bits of ``stem``; the backward then needs neither ATen's int64 indices nor ``stem`` itself
+        if os.environ.get("TA_POOL_KERNEL", "1") != "0" and _hip.maxpool3s2_takes(stem, net.maxpool):
+            pooled, idx, stem_bits = _hip.maxpool3s2_fwd(stem)
+            stem = None
+        else:
+            pooled, idx = F.max_pool2d(stem, net.maxpool.kernel_size, net.maxpool.stride, net.maxpool.padding, return_indices=True)
+            stem_bits = None
         saved, masks, cur = [], [], pooled
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             for blk in layer:
@@ -301,7 +308,7 @@ class _ResNetFn(torch.autograd.Function):
         # with retain_graph (vaifgsm.py:49 -- one gradient per auxiliary loss; adaea.py:44,51) finds them still there, and
         # an in-place write to a saved map by anybody is caught by the version check
         ctx.net, ctx.bottleneck = net, bottleneck
-        flat = [x, stem, pooled, idx]
+        flat = [x, stem, pooled, idx, stem_bits]
         for a, b, y in saved:
             flat += [a, b, y] if bottleneck else [a, y]
         for ma, mb, my in masks:          # pass bits per activation, None where there are none (TA_RELU_BITS=0, an odd size, a fused site)
@@ -314,11 +321,11 @@ class _ResNetFn(torch.autograd.Function):
     def backward(ctx, g_logits):
         net, bottleneck = ctx.net, ctx.bottleneck
         flat = ctx.saved_tensors
-        x, stem, pooled, idx = flat[:4]
+        x, stem, pooled, idx, stem_bits = flat[:5]
         per = 3 if bottleneck else 2
         blocks = [blk for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for blk in layer]
-        end = 4 + per * len(blocks)
-        saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(4, end, per)]
+        end = 5 + per * len(blocks)
+        saved = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(5, end, per)]
         masks = [(flat[j], flat[j + 1] if bottleneck else None, flat[j + per - 1]) for j in range(end, end + per * len(blocks), per)]
         last_y = saved[-1][2]
         n, c, h, w = last_y.shape
@@ -349,7 +356,13 @@ class _ResNetFn(torch.autograd.Function):
         mp = net.maxpool
         k, st, pd = _pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding)
         cl = torch.channels_last
-        if (os.environ.get("TA_POOL_KERNEL", "1") != "0" and k[0] == k[1] and st[0] == st[1] and pd[0] == pd[1]
+        if stem_bits is not None:                                              # the forward ran csrc/glue.hip's stem pool
+            n_, c_, ph_, pw_ = pooled.shape
+            g_stem = torch.empty((n_, c_, 2 * ph_, 2 * pw_), dtype=pooled.dtype, device=pooled.device, memory_format=cl)
+            if not (g.is_contiguous(memory_format=cl) and pending.is_contiguous(memory_format=cl)):
+                g, pending = g.contiguous(memory_format=cl), pending.contiguous(memory_format=cl)
+            _hip.maxpool3s2_bwd_relu(g, idx, stem_bits, g_stem, gb=pending)
+        elif (os.environ.get("TA_POOL_KERNEL", "1") != "0" and k[0] == k[1] and st[0] == st[1] and pd[0] == pd[1]
                 and _pair(mp.dilation) == [1, 1] and not mp.ceil_mode and stem.shape[1] % 4 == 0
                 and all(t.is_contiguous(memory_format=cl) and not t.is_contiguous() for t in (stem, idx, g, pending))):
             g_stem = _hip.maxpool_bwd_relu(g, idx, stem, torch.empty_like(stem), k[0], st[0], pd[0], gb=pending)

@@ -263,6 +263,119 @@ __global__ __launch_bounds__(kBlock) void maxpool_bwd_relu_kernel(const float* _
     *reinterpret_cast<float4*>(out + at) = acc;
 }
 
+
+// ---- the stem's max-pool as the backward needs it (round 6) ----
+// 3 x 3 / stride 2 / padding 1 over an even-sized NHWC map (every torchvision-style ResNet stem).  ATen's max_pool2d_with_indices
+// leaves an int64 argmax per pooled element (8 B where the pooled value itself is 4) and the backward then reads the stem's
+// activation again for the ReLU's sign test: 200 + 401 MB of a 1.2 GB pass at batch 125.  Here the forward leaves
+//   arg    one BYTE per pooled element: the tap kh * 3 + kw that won -- ATen's scan order and update rule (strictly greater, or
+//          NaN), so the same element wins a tie as in max_pool2d_with_indices;
+//   mask   the pass bits of the ACTIVATION it pools (layout of the kernels above): a window (i, j) owns the pixels
+//          (2i + {0, 1}, 2j + {0, 1}) -- taps kh, kw >= 1 -- and a lane handles eight channels, one whole byte per owned pixel.
+// and the backward reads 1 + 1/8 byte where it read 8 + 4; the activation is not kept for the backward at all.
+__global__ __launch_bounds__(kBlock) void maxpool3s2_fwd_kernel(const float* __restrict__ y, float* __restrict__ pooled,
+                                                                uint8_t* __restrict__ arg, uint8_t* __restrict__ mask, int channels,
+                                                                int h, int w, int ph, int pw, unsigned total8) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;              // (n, i, j, c8): eight channels of one window
+    if (q >= total8) return;
+    const unsigned c8n = static_cast<unsigned>(channels) / 8u;
+    const unsigned c8 = q % c8n, win = q / c8n;
+    const int j = static_cast<int>(win % static_cast<unsigned>(pw));
+    const unsigned t = win / static_cast<unsigned>(pw);
+    const int i = static_cast<int>(t % static_cast<unsigned>(ph));
+    const unsigned n = t / static_cast<unsigned>(ph);
+    const unsigned first = (i == 0 ? 3u : 0u) + (j == 0 ? 1u : 0u);   // ATen starts the argmax at the window's first valid tap
+    float4 lo = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), hi = lo;
+    unsigned alo = first * 0x01010101u, ahi = alo;                     // four argmax bytes each
+#define TA_POOL_TAKE(best, v, word, shift, code) \
+    if ((v) > (best) || (v) != (v)) { (best) = (v); (word) = ((word) & ~(0xffu << (shift))) | ((code) << (shift)); }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = 2 * i - 1 + kh;
+        if (ih < 0) continue;                                          // ih <= h - 1 always: h is even, ph = h / 2
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = 2 * j - 1 + kw;
+            if (iw < 0) continue;
+            const int64_t o = ((static_cast<int64_t>(n) * h + ih) * w + iw) * channels + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(y + o), b = *reinterpret_cast<const float4*>(y + o + 4);
+            const unsigned code = static_cast<unsigned>(kh * 3 + kw);
+            TA_POOL_TAKE(lo.x, a.x, alo, 0, code) TA_POOL_TAKE(lo.y, a.y, alo, 8, code)
+            TA_POOL_TAKE(lo.z, a.z, alo, 16, code) TA_POOL_TAKE(lo.w, a.w, alo, 24, code)
+            TA_POOL_TAKE(hi.x, b.x, ahi, 0, code) TA_POOL_TAKE(hi.y, b.y, ahi, 8, code)
+            TA_POOL_TAKE(hi.z, b.z, ahi, 16, code) TA_POOL_TAKE(hi.w, b.w, ahi, 24, code)
+            if (kh >= 1 && kw >= 1) mask[o >> 3] = static_cast<uint8_t>(pass_bits(a) | (pass_bits(b) << 4));
+        }
+    }
+#undef TA_POOL_TAKE
+    const int64_t po = ((static_cast<int64_t>(n) * ph + i) * pw + j) * channels + 8 * c8;
+    *reinterpret_cast<float4*>(pooled + po) = lo;
+    *reinterpret_cast<float4*>(pooled + po + 4) = hi;
+    *reinterpret_cast<uint2*>(arg + po) = make_uint2(alo, ahi);
+}
+
+// The backward on what the kernel above left.  maxpool_bwd_relu_kernel gathers per input pixel: the <= 4 windows over it are
+// loaded by each of the pixels they cover (2.25 loads of every pooled element, 81 B of cache traffic per 16 B written -- the
+// kernel ran at 2.4 TB/s of HBM traffic, bound by L2 -> L1).  Here a lane owns the 2 x 2 pixels (2i + {0,1}, 2j + {0,1}) x four
+// channels: the windows over them are (i, j), (i, j+1), (i+1, j), (i+1, j+1) -- four loads serve four pixels.  Same windows
+// in the same order and the same sums per pixel as the gather (a window that does not exist adds 0.0f to a sum that is never -0).
+__device__ __forceinline__ void pool_take(float4& acc, const float4& g, unsigned won, unsigned here) {
+    acc.x += (won & 0xffu) == here ? g.x : 0.0f;
+    acc.y += ((won >> 8) & 0xffu) == here ? g.y : 0.0f;
+    acc.z += ((won >> 16) & 0xffu) == here ? g.z : 0.0f;
+    acc.w += (won >> 24) == here ? g.w : 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void maxpool3s2_bwd_relu_kernel(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                                     const uint8_t* __restrict__ arg, const uint8_t* __restrict__ mask,
+                                                                     float* __restrict__ out, int channels, int h, int w, int ph,
+                                                                     int pw, unsigned total4) {
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;              // (n, i, j, c4)
+    if (q >= total4) return;
+    const unsigned c4n = static_cast<unsigned>(channels) / 4u;
+    const unsigned c4 = q % c4n, win = q / c4n;
+    const int j = static_cast<int>(win % static_cast<unsigned>(pw));
+    const unsigned t = win / static_cast<unsigned>(pw);
+    const int i = static_cast<int>(t % static_cast<unsigned>(ph));
+    const unsigned n = t / static_cast<unsigned>(ph);
+    const bool right = j + 1 < pw, down = i + 1 < ph;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g[4];
+    unsigned won[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {                                      // v = 2 * di + dj: window (i + di, j + dj)
+        const bool there = ((v & 1) == 0 || right) && ((v & 2) == 0 || down);
+        g[v] = zero;
+        won[v] = 0xffffffffu;                                          // no tap has this code
+        if (there) {
+            const int64_t o = ((static_cast<int64_t>(n) * ph + i + (v >> 1)) * pw + j + (v & 1)) * channels + 4 * c4;
+            g[v] = *reinterpret_cast<const float4*>(ga + o);
+            if (gb != nullptr) {
+                const float4 g2 = *reinterpret_cast<const float4*>(gb + o);
+                g[v].x += g2.x; g[v].y += g2.y; g[v].z += g2.z; g[v].w += g2.w;
+            }
+            won[v] = *reinterpret_cast<const unsigned*>(arg + o);
+        }
+    }
+    // the tap of window v that pixel (2i + a, 2j + b) is: rows 2(i + di) - 1 + kh, columns alike
+    float4 px[4] = {zero, zero, zero, zero};                            // pixel 2 * a + b
+    pool_take(px[0], g[0], won[0], 4u);
+    pool_take(px[1], g[0], won[0], 5u); pool_take(px[1], g[1], won[1], 3u);
+    pool_take(px[2], g[0], won[0], 7u); pool_take(px[2], g[2], won[2], 1u);
+    pool_take(px[3], g[0], won[0], 8u); pool_take(px[3], g[1], won[1], 6u); pool_take(px[3], g[2], won[2], 2u); pool_take(px[3], g[3], won[3], 0u);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int64_t at = ((static_cast<int64_t>(n) * h + 2 * i + (v >> 1)) * w + 2 * j + (v & 1)) * channels + 4 * c4;
+        const unsigned pass = load_pass_bits(mask, static_cast<unsigned>(at));
+        float4 r = px[v];
+        r.x = (pass & 1u) ? r.x : 0.0f;
+        r.y = (pass & 2u) ? r.y : 0.0f;
+        r.z = (pass & 4u) ? r.z : 0.0f;
+        r.w = (pass & 8u) ? r.w : 0.0f;
+        *reinterpret_cast<float4*>(out + at) = r;
+    }
+}
+
 }  // namespace ta
 
 extern "C" int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64_t* idx, const float* y, float* out, int64_t n,
@@ -278,4 +391,32 @@ extern "C" int ta_maxpool_bwd_relu(const float* ga, const float* gb, const int64
                        static_cast<hipStream_t>(stream), ga, gb, idx, y, out, channels, h, w, ph, pw, k, s, p,
                        static_cast<unsigned>(total4));
     return check_launch("maxpool_bwd_relu");
+}
+
+extern "C" int ta_maxpool3s2_fwd(const float* y, float* pooled, uint8_t* arg, uint8_t* mask, int64_t n, int channels, int h, int w,
+                                 void* stream) {
+    TA_REQUIRE(y && pooled && arg && mask && aligned16(y) && aligned16(pooled) && (reinterpret_cast<uintptr_t>(arg) & 7u) == 0,
+               "null or unaligned pointer");
+    TA_REQUIRE(n > 0 && channels > 0 && channels % 8 == 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
+               "shape (n=%lld, c=%d, %dx%d): channels %% 8 == 0 and an even map", (long long)n, channels, h, w);
+    const int64_t total8 = n * (h / 2) * (w / 2) * (channels / 8);
+    TA_REQUIRE(n * h * w * channels < (1ll << 32) - 4 * kBlock, "too many elements for one launch");
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(static_cast<unsigned>(ceil_div(total8, kBlock))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), y, pooled, arg, mask, channels, h, w, h / 2, w / 2,
+                       static_cast<unsigned>(total8));
+    return check_launch("maxpool3s2_fwd");
+}
+
+extern "C" int ta_maxpool3s2_bwd_relu(const float* ga, const float* gb, const uint8_t* arg, const uint8_t* mask, float* out, int64_t n,
+                                      int channels, int h, int w, void* stream) {
+    TA_REQUIRE(ga && arg && mask && out && aligned16(ga) && aligned16(out) && (reinterpret_cast<uintptr_t>(arg) & 3u) == 0 &&
+               (gb == nullptr || aligned16(gb)), "null or unaligned pointer");
+    TA_REQUIRE(n > 0 && channels > 0 && channels % 8 == 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
+               "shape (n=%lld, c=%d, %dx%d): channels %% 8 == 0 and an even map", (long long)n, channels, h, w);
+    const int64_t total4 = n * (h / 2) * (w / 2) * (channels / 4);
+    TA_REQUIRE(n * h * w * channels < (1ll << 32) - 4 * kBlock, "too many elements for one launch");
+    hipLaunchKernelGGL(maxpool3s2_bwd_relu_kernel, dim3(static_cast<unsigned>(ceil_div(total4, kBlock))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), ga, gb, arg, mask, out, channels, h, w, h / 2, w / 2,
+                       static_cast<unsigned>(total4));
+    return check_launch("maxpool3s2_bwd_relu");
 }
