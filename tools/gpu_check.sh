@@ -14,7 +14,7 @@ tests)
   # the driver's tier (-m gpu, <= 900 s wanted against its 1200 s step limit), timed as the driver times it; then the 1000-image
   # forms of the two slowest ASR jobs (-m gpu_long)
   t0=$(date +%s)
-  timeout 1500 python -m pytest tests -m gpu -x -q --timeout 1200 -p no:cacheprovider -s --durations=25 > $OUT/pytest_gpu.log 2>&1
+  timeout ${TA_TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --timeout 1200 -p no:cacheprovider -s --durations=25 > $OUT/pytest_gpu.log 2>&1
   echo "pytest -m gpu -x -q wall: $(( $(date +%s) - t0 )) s" | tee -a $OUT/pytest_gpu.log
   grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu.log | head -30 ;;
 newtests6)
